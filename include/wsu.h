@@ -1,0 +1,114 @@
+/* wsu.h -- C ABI of the MI355X-native UNet pixel-predictor hot path (libwsu.so).
+ *
+ * The reference (uibk-uncover/ws-unet) is pure Python on PyTorch and has NO FFI /
+ * plugin interface; the compute this library replaces is what `UNet.forward`
+ * (src/unet/model/unet.py:137-189) dispatches to ATen.  Each entry point below
+ * names the reference call site it stands in for.  The Python host side
+ * (ws_unet_amd/model/unet.py) binds these with ctypes and keeps the reference's
+ * own module / evaluate API on top.
+ *
+ * Conventions
+ *  - plain C types only; every buffer pointer is a DEVICE pointer owned by the
+ *    caller (PyTorch-ROCm caching allocator in our host code); the library
+ *    allocates nothing and keeps no global mutable state (re-entrant; one host
+ *    thread per GPU may call concurrently);
+ *  - `stream` is a hipStream_t passed as void*; all work is asynchronous on it;
+ *  - returns 0 on success, a negative code on bad arguments / HIP error, message
+ *    via wsu_last_error() (thread-local);  never throws;
+ *  - activations are NHWC (N*H*W*C contiguous).  With C == 1 this coincides with
+ *    the reference's NCHW, so model input (N,1,H,W) and output (N,1,H,W) need no
+ *    re-layout;
+ *  - `mode` selects storage + arithmetic:
+ *      WSU_MODE_F32    = 0  fp32 storage, exact fp32 MFMA (v_mfma_f32_32x32x2_f32)
+ *      WSU_MODE_BF16X3 = 1  fp32 storage, split-bf16 (hi*hi + hi*lo + lo*hi) on
+ *                           v_mfma_f32_32x32x16_bf16, fp32 accumulate (~2^-17 rel. error)
+ *      WSU_MODE_BF16   = 2  bf16 storage, bf16 MFMA, fp32 accumulate
+ */
+#ifndef WSU_H
+#define WSU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WSU_VERSION 100
+
+enum { WSU_MODE_F32 = 0, WSU_MODE_BF16X3 = 1, WSU_MODE_BF16 = 2 };
+
+enum {
+    WSU_OK = 0,
+    WSU_ERR_ARG = -1,      /* bad argument (shape, mode, null pointer) */
+    WSU_ERR_HIP = -2,      /* a HIP call / launch failed */
+    WSU_ERR_UNSUPPORTED = -3
+};
+
+int wsu_version(void);
+const char* wsu_last_error(void);
+
+/* Bytes per activation element for a mode (4, 4, 2). */
+int wsu_act_elem_size(int mode);
+
+/* ---- weight packing (done once per weight update; replaces nothing in the reference:
+ *      it re-lays nn.Conv2d's OIHW fp32 weight, unet.py:82-132, for the MFMA A operand) */
+size_t wsu_conv3x3_packed_bytes(int cin, int cout, int mode);
+int wsu_conv3x3_pack(const float* w_oihw, void* w_packed, int cin, int cout, int mode, void* stream);
+/* transposed: packs w^T flipped (for the data-gradient pass), from the same OIHW source */
+int wsu_conv3x3_pack_dgrad(const float* w_oihw, void* w_packed, int cin, int cout, int mode, void* stream);
+size_t wsu_convt2x2_packed_bytes(int cin, int cout, int mode);
+/* w is nn.ConvTranspose2d's (Cin, Cout, 2, 2) fp32 weight, unet.py:125,130 */
+int wsu_convt2x2_pack(const float* w_iohw, void* w_packed, int cin, int cout, int mode, void* stream);
+
+/* ---- K1 (+K2, K4): y = [relu](conv3x3_reflect(cat[x1, x2]) + bias), optional fused 2x2 max-pool.
+ *      Replaces nn.Conv2d(k3, pad 1, reflect) + F.relu (unet.py:141-186), torch.cat (unet.py:178,184)
+ *      and nn.MaxPool2d (unet.py:144,149).
+ *      x1: (N,H,W,C1), x2: (N,H,W,C2) or NULL (C2 == 0); channels of x1 come first (upsampled, then skip).
+ *      C1, C2 multiples of 16 (fp32 modes) / 32 (bf16); Cout multiple of 64; H, W >= 2.
+ *      y: (N,H,W,Cout).  y_pool: (N,H/2,W/2,Cout) or NULL.  pool_idx: uint8 (N,H/2,W/2,Cout) argmax in
+ *      row-major window order with first-max-wins ties, or NULL.  pad_zero != 0 selects zero instead of
+ *      reflect padding (used by the data-gradient pass). */
+int wsu_conv3x3_fwd(const void* x1, const void* x2, const void* w_packed, const float* bias,
+                    void* y, void* y_pool, uint8_t* pool_idx,
+                    int n, int h, int w, int c1, int c2, int cout,
+                    int mode, int relu, int pad_zero, void* stream);
+
+/* ---- first layer: conv3x3 reflect on a few input planes given as NCHW fp32 (the model input).
+ *      Replaces e11 (unet.py:82,141).  cin <= 8, cout multiple of 8.  w is plain OIHW fp32. */
+int wsu_conv3x3_first_fwd(const float* x_nchw, const float* w_oihw, const float* bias, void* y,
+                          int n, int h, int w, int cin, int cout, int mode, int relu, void* stream);
+
+/* ---- K2 standalone 2x2/2 max-pool (used when not fused). */
+int wsu_maxpool2x2_fwd(const void* x, void* y, uint8_t* pool_idx, int n, int h, int w, int c, int mode, void* stream);
+
+/* ---- K3: y[n,2i+a,2j+b,co] = bias[co] + sum_ci x[n,i,j,ci] * w[ci,co,a,b]   (unet.py:177,183) */
+int wsu_convt2x2_fwd(const void* x, const void* w_packed, const float* bias, void* y,
+                     int n, int h, int w, int cin, int cout, int mode, void* stream);
+
+/* ---- K5: out[n,co,y,x] = sigmoid(b[co] + sum_c x[n,y,x,c] * w[co,c])   (unet.py:189).
+ *      w: (cout, c) fp32 (outconv.weight squeezed), out: NCHW fp32; logit: optional NCHW fp32 pre-sigmoid. */
+int wsu_conv1x1_sigmoid_fwd(const void* x, const float* w, const float* bias, float* out, float* logit,
+                            int n, int h, int w_, int c, int cout, int mode, void* stream);
+
+/* ---- K6: UniformDropout (unet.py:32-42) on plane `channel` of an NCHW fp32 tensor, out of place:
+ *      y = x*mask + KB(x)*(1-mask).  mask: (N,1,H,W) fp32 keep-mask, or NULL to draw it from a
+ *      counter-based hash of (seed, element index) with keep probability keep_prob. */
+int wsu_uniform_dropout_fwd(const float* x, float* y, const float* mask, float* mask_out,
+                            int n, int c, int h, int w, int channel,
+                            float keep_prob, uint64_t seed, void* stream);
+
+/* ---- K10: per-image WS residual statistics (src/unet/evaluate.py:125-132).
+ *      x_u8: (N,H,W) cover/stego pixels; y01: (N,H,W) fp32 network output in [0,1].
+ *      Over the interior [1:-1,1:-1]:  xhat = y*255;  beta_hat = mean((x - (x^1)) * (x - xhat));
+ *      l1 = mean|x - xhat|.  Deterministic (fixed-order fp64 tree). */
+int wsu_ws_residual_stats(const uint8_t* x_u8, const float* y01, float* beta_hat, float* l1,
+                          int n, int h, int w, void* stream);
+
+/* ---- u8 -> [0,1] fp32, numpy float32 division semantics of evaluate.py:45 (x / 255.) */
+int wsu_u8_to_unit_f32(const uint8_t* x, float* y, size_t count, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WSU_H */

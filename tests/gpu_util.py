@@ -1,0 +1,55 @@
+"""Helpers shared by the -m gpu parity tests: layout conversion and oracle plumbing."""
+import numpy as np
+import torch
+
+from ws_unet_amd import formula, ops
+from ws_unet_amd.model import get_model
+from oracle import unet_ref
+
+DEV = "cuda"
+MODE_NAMES = ["f32", "bf16x3", "bf16"]
+# absolute tolerance on the [0,1] sigmoid output / relative tolerance on activations, per precision mode
+OUT_ATOL = {"f32": 2e-6, "bf16x3": 2e-5, "bf16": 3e-2}
+ACT_RTOL = {"f32": 2e-5, "bf16x3": 1e-4, "bf16": 6e-2}
+
+
+def to_nhwc(x_nchw: torch.Tensor, mode: str) -> torch.Tensor:
+    """CPU NCHW fp32 -> device NHWC in the activation dtype of ``mode``."""
+    dt = ops.act_dtype(ops.mode_id(mode))
+    return x_nchw.permute(0, 2, 3, 1).contiguous().to(DEV).to(dt)
+
+
+def from_nhwc(y: torch.Tensor) -> torch.Tensor:
+    """device NHWC (any dtype) -> CPU NCHW fp32."""
+    return y.float().permute(0, 3, 1, 2).contiguous().cpu()
+
+
+def rand_act(shape, key, scale=1.0, relu=True):
+    """Deterministic NCHW activation tensor (post-ReLU like real inputs of the 3x3 convs)."""
+    a = formula.formula_tensor(key, shape, scale)
+    if relu:
+        a = np.maximum(a, 0)
+    return torch.from_numpy(a)
+
+
+def images01(n, h, w, seed):
+    u8 = formula.synthetic_images(n, h, w, seed)
+    return u8, torch.from_numpy(u8.astype(np.float32) / np.float32(255.))[:, None]
+
+
+def gpu_model(nsteps, variant="he", mode="f32", drop_rate=None):
+    m = get_model(f"unet_{nsteps}", in_channels=1, out_channels=1, channel=[0], drop_rate=drop_rate, mode=mode)
+    sd = formula.formula_state_dict(nsteps, variant)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    return m.to(DEV)
+
+
+def oracle_forward(x, nsteps, variant="he", intermediates=None):
+    sd = unet_ref.to_torch_state(formula.formula_state_dict(nsteps, variant))
+    with torch.no_grad():
+        return unet_ref.unet_forward(x.clone(), sd, nsteps, intermediates=intermediates)
+
+
+def err_stats(got: torch.Tensor, ref: torch.Tensor):
+    d = (got.double() - ref.double()).abs()
+    return {"max": d.max().item(), "mean": d.mean().item(), "refmax": ref.abs().max().item()}

@@ -1,0 +1,254 @@
+"""GPU parity tests of the forward hot path: every libwsu kernel against the CPU oracle on the same
+seeded inputs, the whole network against the golden vectors generated from the reference, and the
+BASELINE 1e-4 MAE gate at 512x512.  All calls go through the C ABI (ws_unet_amd.ops -> ctypes)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from gpu_util import (DEV, MODE_NAMES, OUT_ATOL, ACT_RTOL, to_nhwc, from_nhwc, rand_act, images01, gpu_model,
+                      oracle_forward, err_stats)
+from ws_unet_amd import formula, ops
+from oracle import unet_ref, np_ops
+
+pytestmark = pytest.mark.gpu
+
+
+def _assert_close(got, ref, mode, what):
+    s = err_stats(got, ref)
+    tol = ACT_RTOL[mode] * max(1.0, s["refmax"])
+    assert s["max"] <= tol, f"{what} [{mode}]: max err {s['max']:.3e} > {tol:.3e} (ref max {s['refmax']:.3e})"
+
+
+@pytest.mark.parametrize("mode", MODE_NAMES)
+@pytest.mark.parametrize("shape", [
+    # (n, h, w, c1, c2, cout)
+    (2, 16, 32, 64, 0, 64),       # exact tiles
+    (1, 24, 40, 64, 0, 128),      # ragged tiles in both directions, two cout blocks
+    (2, 8, 8, 128, 128, 128),     # fused concat, tile mostly out of image
+    (1, 2, 2, 64, 64, 64),        # smallest legal image (reflect of a 2x2)
+    (1, 40, 72, 256, 0, 64),      # many chunks
+])
+def test_conv3x3_reflect_bias_relu(mode, shape):
+    n, h, w, c1, c2, cout = shape
+    m = ops.mode_id(mode)
+    x1 = rand_act((n, c1, h, w), f"t/x1/{shape}")
+    x2 = rand_act((n, c2, h, w), f"t/x2/{shape}") if c2 else None
+    wt = torch.from_numpy(formula.formula_tensor(f"t/w/{shape}", (cout, c1 + c2, 3, 3), (6.0 / (9 * (c1 + c2))) ** 0.5))
+    b = torch.from_numpy(formula.formula_tensor(f"t/b/{shape}", (cout,), 0.1))
+    xin = x1 if x2 is None else torch.cat([x1, x2], 1)
+    ref = F.relu(unet_ref.conv3x3_reflect(xin, wt, b))
+    wp = ops.pack_conv3x3(wt.to(DEV), m)
+    y = ops.conv3x3(to_nhwc(x1, mode), None if x2 is None else to_nhwc(x2, mode), wp, b.to(DEV), cout, m, relu=True)
+    torch.cuda.synchronize()
+    _assert_close(from_nhwc(y), ref, mode, f"conv3x3 {shape}")
+    # no-relu / no-bias / zero-padding variants share the kernel
+    y2 = ops.conv3x3(to_nhwc(x1, mode), None if x2 is None else to_nhwc(x2, mode), wp, None, cout, m, relu=False, pad_zero=True)
+    _assert_close(from_nhwc(y2), F.conv2d(xin, wt, None, padding=1), mode, f"conv3x3 zero-pad {shape}")
+
+
+@pytest.mark.parametrize("mode", MODE_NAMES)
+def test_conv3x3_fused_pool_and_argmax(mode):
+    n, h, w, c, cout = 2, 24, 40, 64, 64
+    m = ops.mode_id(mode)
+    x = rand_act((n, c, h, w), "pool/x")
+    wt = torch.from_numpy(formula.formula_tensor("pool/w", (cout, c, 3, 3), (6.0 / (9 * c)) ** 0.5))
+    b = torch.from_numpy(formula.formula_tensor("pool/b", (cout,), 0.5))
+    wp = ops.pack_conv3x3(wt.to(DEV), m)
+    y, yp, idx = ops.conv3x3(to_nhwc(x, mode), None, wp, b.to(DEV), cout, m, relu=True, pool=True, pool_idx=True)
+    yc = from_nhwc(y)
+    # pooled output must be EXACTLY the pool of the kernel's own full-resolution output (bitwise), with
+    # first-max-wins argmax in row-major window order (ties are common: ReLU zeros)
+    ref_pool, ref_arg = np_ops.maxpool2x2(yc.numpy())
+    np.testing.assert_array_equal(from_nhwc(yp).numpy(), ref_pool)
+    np.testing.assert_array_equal(idx.permute(0, 3, 1, 2).cpu().numpy(), ref_arg)
+    assert (ref_pool == 0).mean() > 0.01                       # the tie case is really exercised
+    # stand-alone pool kernel agrees
+    yp2, idx2 = ops.maxpool2x2(y, m, want_idx=True)
+    assert torch.equal(yp2, yp) and torch.equal(idx2, idx)
+
+
+@pytest.mark.parametrize("mode", MODE_NAMES)
+@pytest.mark.parametrize("shape", [(2, 8, 32, 128, 64), (1, 5, 37, 256, 128), (1, 1, 1, 64, 64)])
+def test_convt2x2(mode, shape):
+    n, h, w, cin, cout = shape
+    m = ops.mode_id(mode)
+    x = rand_act((n, cin, h, w), f"ct/x/{shape}")
+    wt = torch.from_numpy(formula.formula_tensor(f"ct/w/{shape}", (cin, cout, 2, 2), (6.0 / cin) ** 0.5))
+    b = torch.from_numpy(formula.formula_tensor(f"ct/b/{shape}", (cout,), 0.1))
+    ref = F.conv_transpose2d(x, wt, b, stride=2)
+    y = ops.convt2x2(to_nhwc(x, mode), ops.pack_convt2x2(wt.to(DEV), m), b.to(DEV), cout, m)
+    _assert_close(from_nhwc(y), ref, mode, f"convt2x2 {shape}")
+
+
+@pytest.mark.parametrize("mode", MODE_NAMES)
+@pytest.mark.parametrize("cin", [1, 2, 4])
+def test_first_layer(mode, cin):
+    m = ops.mode_id(mode)
+    x = rand_act((2, cin, 20, 36), f"first/x/{cin}", relu=False)
+    wt = torch.from_numpy(formula.formula_tensor(f"first/w/{cin}", (64, cin, 3, 3), 0.5))
+    b = torch.from_numpy(formula.formula_tensor(f"first/b/{cin}", (64,), 0.1))
+    ref = F.relu(unet_ref.conv3x3_reflect(x, wt, b))
+    y = ops.conv3x3_first(x.to(DEV), wt.to(DEV), b.to(DEV), m)
+    _assert_close(from_nhwc(y), ref, mode, "first layer")
+
+
+@pytest.mark.parametrize("mode", MODE_NAMES)
+@pytest.mark.parametrize("cout", [1, 3])
+def test_head_conv1x1_sigmoid(mode, cout):
+    m = ops.mode_id(mode)
+    x = rand_act((2, 64, 10, 12), "head/x")
+    wt = torch.from_numpy(formula.formula_tensor(f"head/w/{cout}", (cout, 64, 1, 1), 0.4))
+    b = torch.from_numpy(formula.formula_tensor(f"head/b/{cout}", (cout,), 0.1))
+    xq = from_nhwc(to_nhwc(x, mode))                           # what the kernel really sees (bf16 rounding of the input)
+    z = F.conv2d(xq, wt, b)
+    out, logit = ops.conv1x1_sigmoid(to_nhwc(x, mode), wt.to(DEV), b.to(DEV), m, want_logit=True)
+    np.testing.assert_allclose(logit.cpu().numpy(), z.numpy(), atol=2e-5, rtol=0)
+    np.testing.assert_allclose(out.cpu().numpy(), torch.sigmoid(z).numpy(), atol=5e-6, rtol=0)
+
+
+def test_uniform_dropout_golden(golden):
+    g = golden["dropout"]
+    _, x = images01(2, 32, 32, seed=21)
+    mask = torch.from_numpy(formula.bernoulli_mask((2, 1, 32, 32), keep_prob=0.9, seed=4242))
+    y = ops.uniform_dropout(x.to(DEV), mask.to(DEV))
+    np.testing.assert_allclose(y.cpu().numpy(), g["drop_x_after"], atol=1e-7, rtol=0)
+    # drawn mask: Bernoulli(keep) statistics, reproducible for a (seed) and different across seeds
+    xb = torch.rand(4, 1, 64, 64, device=DEV)
+    y1, m1 = ops.uniform_dropout(xb, None, keep_prob=0.9, seed=5, want_mask=True)
+    y2, m2 = ops.uniform_dropout(xb, None, keep_prob=0.9, seed=5, want_mask=True)
+    _, m3 = ops.uniform_dropout(xb, None, keep_prob=0.9, seed=6, want_mask=True)
+    assert torch.equal(m1, m2) and torch.equal(y1, y2) and not torch.equal(m1, m3)
+    assert abs(m1.mean().item() - 0.9) < 0.02 and set(m1.unique().tolist()) <= {0.0, 1.0}
+    # module: identity at p=0 but still rewrites in place (reference behaviour), external mask honoured
+    model = gpu_model(1, "he", "f32", drop_rate=0.1)
+    model.input_dropout.next_mask = mask
+    xin = x.clone().to(DEV)
+    with torch.no_grad():
+        out = model(xin)
+    np.testing.assert_allclose(xin.cpu().numpy(), g["drop_x_inplace"], atol=1e-7, rtol=0)
+    np.testing.assert_allclose(out.cpu().numpy(), g["drop_y_unet1"], atol=OUT_ATOL["f32"], rtol=0)
+    model0 = gpu_model(1, "he", "f32", drop_rate=0.)
+    with torch.no_grad():
+        out0 = model0(x.clone().to(DEV))
+    np.testing.assert_allclose(out0.cpu().numpy(), g["drop0_y_unet1"], atol=OUT_ATOL["f32"], rtol=0)
+
+
+def test_u8_to_unit_and_ws_stats_bit_exact():
+    u8 = formula.synthetic_images(3, 64, 48, seed=9, smooth=False)
+    y = ops.u8_to_unit(torch.from_numpy(u8).to(DEV))
+    np.testing.assert_array_equal(y.cpu().numpy(), u8.astype(np.float32) / np.float32(255.))   # IEEE division, bitwise
+    pred = torch.from_numpy(formula.formula_tensor("stats/pred", (3, 64, 48), 0.5) + 0.5)
+    beta, l1 = ops.ws_residual_stats(torch.from_numpy(u8).to(DEV), pred.to(DEV))
+    for i in range(3):
+        xhat = pred[i].numpy()[1:-1, 1:-1] * np.float32(255.)
+        b_ref, l_ref = np_ops.ws_stats(u8[i][1:-1, 1:-1], xhat)
+        assert abs(beta[i].item() - b_ref) <= 1e-6 * max(1, abs(b_ref))
+        assert abs(l1[i].item() - l_ref) <= 1e-6 * max(1, abs(l_ref))
+    # integer LSB path is exact: a perfect predictor gives exactly 0, the flipped image exactly 1
+    xf = torch.from_numpy(u8.astype(np.float32) / np.float32(255.))
+    b0, l0 = ops.ws_residual_stats(torch.from_numpy(u8).to(DEV), xf.to(DEV))
+    flipped = torch.from_numpy((u8 ^ 1).astype(np.float32) / np.float32(255.))
+    b1, l1_ = ops.ws_residual_stats(torch.from_numpy(u8).to(DEV), flipped.to(DEV))
+    assert torch.all(b0.abs() < 1e-5) and torch.all(l0 < 1e-5)
+    assert torch.all((b1 - 1).abs() < 1e-5) and torch.all((l1_ - 1).abs() < 1e-5)
+    # determinism: fixed-order reduction -> bitwise identical on repeat
+    b2, l2 = ops.ws_residual_stats(torch.from_numpy(u8).to(DEV), pred.to(DEV))
+    assert torch.equal(beta, b2) and torch.equal(l1, l2)
+
+
+@pytest.mark.parametrize("mode", MODE_NAMES)
+@pytest.mark.parametrize("ns", [0, 1, 2, 3, 4])
+def test_unet_forward_golden_small(golden, mode, ns):
+    g = golden["unet_fwd_small"]
+    model = gpu_model(ns, "he", mode)
+    _, x = images01(2, 32, 32, seed=1)
+    with torch.no_grad():
+        y = model(x.to(DEV))
+    assert y.shape == (2, 1, 32, 32) and y.dtype == torch.float32
+    np.testing.assert_allclose(y.cpu().numpy(), g[f"y_unet{ns}_he"], atol=OUT_ATOL[mode], rtol=0)
+
+
+@pytest.mark.parametrize("mode", MODE_NAMES)
+def test_unet_intermediates_golden(golden, mode):
+    g = golden["unet_fwd_small"]
+    model = gpu_model(2, "he", mode)
+    _, x = images01(1, 32, 32, seed=2)
+    keep = {}
+    out = model.forward_features(x.to(DEV), keep=keep)
+    np.testing.assert_allclose(out.cpu().numpy(), g["inter_y"], atol=OUT_ATOL[mode], rtol=0)
+    for k in ["xe11", "xe12", "xp1", "xe21", "xe22", "xp2", "xe31", "xe32", "xu3", "xd31", "xd32", "xu4", "xd41", "xd42"]:
+        ref = torch.from_numpy(g[f"inter_{k}_sub"])
+        _assert_close(from_nhwc(keep[k])[:, ::8], ref, mode, k)
+    np.testing.assert_allclose(keep["logit"].cpu().numpy()[:, ::8], g["inter_logit_sub"], atol=50 * OUT_ATOL[mode], rtol=0)
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16x3"])
+def test_unet_default_variant_and_ragged_shape(golden, mode):
+    g = golden["unet_fwd_small"]
+    _, x = images01(2, 32, 32, seed=1)
+    with torch.no_grad():
+        y = gpu_model(2, "default", mode)(x.to(DEV))
+    np.testing.assert_allclose(y.cpu().numpy(), g["y_unet2_default"], atol=OUT_ATOL[mode], rtol=0)
+    _, x = images01(2, 24, 40, seed=3)
+    with torch.no_grad():
+        y = gpu_model(2, "he", mode)(x.to(DEV))
+    np.testing.assert_allclose(y.cpu().numpy(), g["y_unet2_he_24x40"], atol=OUT_ATOL[mode], rtol=0)
+
+
+@pytest.mark.parametrize("variant", ["he", "default"])
+@pytest.mark.parametrize("mode", MODE_NAMES)
+def test_unet_forward_512_golden(golden, mode, variant):
+    g = golden["unet_fwd_512"]
+    _, x = images01(1, 512, 512, seed=7)
+    with torch.no_grad():
+        y = gpu_model(2, variant, mode)(x.to(DEV)).cpu().numpy()[0, 0]
+    atol = OUT_ATOL[mode]
+    np.testing.assert_allclose(y[224:288, 224:288], g[f"f512_{variant}_crop"], atol=atol, rtol=0)
+    np.testing.assert_allclose(np.stack([y[0], y[511], y[:, 0], y[:, 511]]), g[f"f512_{variant}_border"], atol=atol, rtol=0)
+    ts = y.astype(np.float64).reshape(8, 64, 8, 64).sum(axis=(1, 3))
+    np.testing.assert_allclose(ts, g[f"f512_{variant}_tilesum"], atol=4096 * atol * 0.25, rtol=0)
+
+
+def test_mae_gate_512_batch():
+    """BASELINE.json: predictions within 1e-4 MAE of the reference CPU path ([0,1] units), checked on
+    full-range ('he') formula weights at 512x512, batch 4.  bf16 storage mode is reported, not gated."""
+    _, x = images01(4, 512, 512, seed=77)
+    ref = oracle_forward(x, 2, "he")
+    assert ref.std().item() > 0.05                              # non-degenerate output (spans (0,1))
+    maes = {}
+    for mode in MODE_NAMES:
+        with torch.no_grad():
+            y = gpu_model(2, "he", mode)(x.to(DEV)).cpu()
+        maes[mode] = (y - ref).abs().mean().item()
+    print("MAE vs CPU oracle @512x512 batch 4:", maes)
+    assert maes["f32"] <= 1e-6
+    assert maes["bf16x3"] <= 1e-4                               # the north-star tolerance
+    assert maes["bf16"] <= 1e-2
+
+
+def test_forward_is_deterministic_and_batch_invariant():
+    """Size-independent properties at full size: same input twice -> bitwise equal; an image's prediction
+    does not depend on its position in the batch or on the batch size."""
+    model = gpu_model(2, "he", "bf16x3")
+    _, x = images01(3, 512, 512, seed=5)
+    xd = x.to(DEV)
+    with torch.no_grad():
+        y1 = model(xd.clone())
+        y2 = model(xd.clone())
+        y_single = model(xd[1:2].clone())
+        y_perm = model(xd[[2, 0, 1]].clone())
+    assert torch.equal(y1, y2)
+    assert torch.equal(y1[1:2], y_single)
+    assert torch.equal(y1[[2, 0, 1]], y_perm)
+
+
+def test_cpu_tensors_are_refused():
+    from ws_unet_amd._lib import WsuError
+    model = gpu_model(0, "he", "f32")
+    with pytest.raises(WsuError):
+        model(torch.zeros(1, 1, 8, 8))
+    with pytest.raises(ValueError):
+        gpu_model(2, "he", "f32")(torch.zeros(1, 1, 30, 32, device=DEV))       # not divisible by 4
+    with pytest.raises(ValueError):
+        gpu_model(2, "he", "f32")(torch.zeros(1, 1, 4, 4, device=DEV))         # bottom level would be 1x1

@@ -1,0 +1,73 @@
+"""ctypes binding of libwsu.so (the C ABI declared in include/wsu.h).
+
+The product path has NO CPU fallback: if the shared library is missing or a call
+fails, an exception is raised.  Build with ``python -c "import __graft_entry__ as g; g.build()"``
+or ``make -C ws_unet_amd/csrc``.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_size_t, c_uint64, c_void_p
+from pathlib import Path
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = _HERE / "libwsu.so"
+
+MODE_F32, MODE_BF16X3, MODE_BF16 = 0, 1, 2
+MODES = {"f32": MODE_F32, "bf16x3": MODE_BF16X3, "bf16": MODE_BF16}
+
+
+class WsuError(RuntimeError):
+    pass
+
+
+# name -> (restype, argtypes); must list every symbol of include/wsu.h (tests/test_capi_symbols.py checks)
+_P = c_void_p
+SIGNATURES = {
+    "wsu_version": (c_int, []),
+    "wsu_last_error": (c_char_p, []),
+    "wsu_act_elem_size": (c_int, [c_int]),
+    "wsu_conv3x3_packed_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "wsu_conv3x3_pack": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
+    "wsu_conv3x3_pack_dgrad": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
+    "wsu_convt2x2_packed_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "wsu_convt2x2_pack": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
+    "wsu_conv3x3_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P] + [c_int] * 9 + [_P]),
+    "wsu_conv3x3_first_fwd": (c_int, [_P, _P, _P, _P] + [c_int] * 7 + [_P]),
+    "wsu_maxpool2x2_fwd": (c_int, [_P, _P, _P] + [c_int] * 5 + [_P]),
+    "wsu_convt2x2_fwd": (c_int, [_P, _P, _P, _P] + [c_int] * 6 + [_P]),
+    "wsu_conv1x1_sigmoid_fwd": (c_int, [_P, _P, _P, _P, _P] + [c_int] * 6 + [_P]),
+    "wsu_uniform_dropout_fwd": (c_int, [_P, _P, _P, _P] + [c_int] * 5 + [c_float, c_uint64, _P]),
+    "wsu_ws_residual_stats": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P]),
+    "wsu_u8_to_unit_f32": (c_int, [_P, _P, c_size_t, _P]),
+}
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load libwsu.so once; raise loudly if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = Path(os.environ.get("WSU_LIB", LIB_PATH))
+    if not path.exists():
+        raise WsuError(
+            f"{path} not found: the HIP extension is not built. Run `make -C {_HERE / 'csrc'}` "
+            "(or __graft_entry__.build()). There is no CPU fallback for the UNet hot path.")
+    lib = ctypes.CDLL(str(path))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    if lib.wsu_version() < 100:
+        raise WsuError("libwsu.so is older than this Python package; rebuild it")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().wsu_last_error()
+        raise WsuError(f"{what} failed (code {rc}): {msg.decode() if msg else '?'}")

@@ -1,0 +1,265 @@
+// K3: 2x2 stride-2 transposed convolution + bias as four independent GEMMs on the matrix cores.
+//
+// Replaces nn.ConvTranspose2d(k=2, stride=2) of the reference (src/unet/model/unet.py:74,125,130; used at
+// :177,183):   y[n, 2i+a, 2j+b, co] = bias[co] + sum_ci x[n, i, j, ci] * w[ci, co, a, b]
+// Stride == kernel, so outputs never overlap: each of the 4 sub-positions (a,b) is a plain GEMM
+// [64 co] x [Cin] x [pixels]; one wave per sub-position, 64 co x 64 input pixels (2 rows x 32) per wave.
+// Same operand staging as conv3x3.hip (granule-planar LDS, register double buffering).  The epilogue
+// interleaves the 4 sub-position tiles into a [4 x 64 output pixels][64 co] LDS tile so that the NHWC
+// stores are whole 16-byte pieces of contiguous output rows.
+#include "wsu_device.h"
+
+namespace {
+
+constexpr int TW = 32, TH = 2;                          // input-pixel tile
+constexpr int NPIX = TW * TH;                            // 64
+constexpr int PLANE_IN = NPIX * 16 + 32;                 // 1056 B
+constexpr int LDS_IN = WSU_GRAN * PLANE_IN;              // 4224
+constexpr int LDS_W = 4 * WSU_GRAN * WSU_COB * 16;       // 16384
+constexpr int LDS_MAIN = LDS_IN + LDS_W;
+constexpr int NT = 256;
+constexpr int W_VEC = LDS_W / 16 / NT;                   // 4
+
+struct CtArgs {
+    const char* x; const char* wp; const float* bias; char* y;
+    int n, h, w, cin, cout, tiles_x, tiles_y, ncb, nch;
+};
+
+
+template <int MODE>
+__device__ __forceinline__ void ct_load(const CtArgs& a, int cb, int c, int tid, bool has_item, const char* xsrc,
+                                        u32x4 (&st_in)[2], u32x4 (&st_w)[W_VEC]) {
+    constexpr int ESZ = (MODE == WSU_MODE_BF16) ? 2 : 4;
+    constexpr int CK = (MODE == WSU_MODE_BF16) ? 32 : 16;
+    st_in[0] = mk_u4(0, 0, 0, 0); st_in[1] = st_in[0];
+    if (has_item) {
+        const u32x4* g = reinterpret_cast<const u32x4*>(xsrc + (size_t)c * CK * ESZ);
+        st_in[0] = g[0];
+        if constexpr (MODE == WSU_MODE_BF16X3) st_in[1] = g[1];
+    }
+    const u32x4* wsrc = reinterpret_cast<const u32x4*>(a.wp + ((size_t)cb * a.nch + c) * LDS_W);
+    WSU_STATIC_FOR(W_VEC, k, st_w[k] = wsrc[tid + k * NT];);
+}
+
+template <int MODE>
+__device__ __forceinline__ void ct_commit(char* smem, int tid, bool has_item, int ldsoff,
+                                          const u32x4 (&st_in)[2], const u32x4 (&st_w)[W_VEC]) {
+    if (has_item) {
+        if constexpr (MODE == WSU_MODE_BF16X3) {
+            u32x4 hi, lo;
+            wsu_split8(__builtin_bit_cast(f32x4, st_in[0]), __builtin_bit_cast(f32x4, st_in[1]), hi, lo);
+            *reinterpret_cast<u32x4*>(smem + ldsoff) = hi;
+            *reinterpret_cast<u32x4*>(smem + ldsoff + 2 * PLANE_IN) = lo;
+        } else {
+            *reinterpret_cast<u32x4*>(smem + ldsoff) = st_in[0];
+        }
+    }
+    u32x4* wdst = reinterpret_cast<u32x4*>(smem + LDS_IN);
+    WSU_STATIC_FOR(W_VEC, k, wdst[tid + k * NT] = st_w[k];);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(NT, 2) void convt2x2_kernel(const CtArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int ESZ = (MODE == WSU_MODE_BF16) ? 2 : 4;
+    constexpr int STRIDE = WSU_COB * ESZ + 16;
+    constexpr int VPP = WSU_COB * ESZ / 16;
+
+    const int tid = threadIdx.x;
+    const unsigned lid = wsu_xcd_remap(blockIdx.x, gridDim.x);
+    const int cb = lid % a.ncb;
+    int tile = lid / a.ncb;
+    const int tx = tile % a.tiles_x; tile /= a.tiles_x;
+    const int ty = tile % a.tiles_y;
+    const int n = tile / a.tiles_y;
+    const int y0 = ty * TH, x0 = tx * TW;
+
+    // staging plan: F32/BF16: 256 items (pixel, granule); BF16X3: 128 items (pixel, half) of 32 B
+    constexpr int NITEMS = (MODE == WSU_MODE_BF16X3) ? NPIX * 2 : NPIX * 4;
+    const int pix = (MODE == WSU_MODE_BF16X3) ? (tid >> 1) : (tid >> 2);
+    const int sub = (MODE == WSU_MODE_BF16X3) ? (tid & 1) : (tid & 3);
+    const int pr = (pix / TW) % TH, pc = pix % TW;
+    const int yy = min(y0 + pr, a.h - 1), xx = min(x0 + pc, a.w - 1);   // clamp: out-of-image lanes are never stored
+    const size_t pidx = (size_t)(n * a.h + yy) * a.w + xx;
+    const bool has_item = tid < NITEMS;
+    const int ldsoff = sub * PLANE_IN + (pix % NPIX) * 16;
+
+    u32x4 st_in[2]; u32x4 st_w[W_VEC];
+    const char* xsrc = a.x + pidx * a.cin * ESZ + sub * ((MODE == WSU_MODE_BF16X3) ? 32 : 16);
+
+    const int wv = tid >> 6, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;   // wave = sub-position a*2+b
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][q][r] = 0.f;
+    const char* ldsA = smem + LDS_IN + ((wv * WSU_GRAN) * 64 + l31) * 16;      // + (g*64 + m*32)*16
+    const char* ldsB = smem + l31 * 16;                                         // + g*PLANE_IN + q*32*16
+
+    ct_load<MODE>(a, cb, 0, tid, has_item, xsrc, st_in, st_w);
+    for (int c = 0; c < a.nch; ++c) {
+        __syncthreads();
+        ct_commit<MODE>(smem, tid, has_item, ldsoff, st_in, st_w);
+        __syncthreads();
+        if (c + 1 < a.nch) ct_load<MODE>(a, cb, c + 1, tid, has_item, xsrc, st_in, st_w);
+        if constexpr (MODE == WSU_MODE_BF16X3) {
+            u32x4 ahi[2], alo[2], bhi[2], blo[2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                ahi[m] = *reinterpret_cast<const u32x4*>(ldsA + (hh * 64 + m * 32) * 16);
+                alo[m] = *reinterpret_cast<const u32x4*>(ldsA + ((2 + hh) * 64 + m * 32) * 16);
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                bhi[q] = *reinterpret_cast<const u32x4*>(ldsB + hh * PLANE_IN + q * TW * 16);
+                blo[q] = *reinterpret_cast<const u32x4*>(ldsB + (2 + hh) * PLANE_IN + q * TW * 16);
+            }
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    wsu_mfma_step<MODE>(alo[m], bhi[q], acc[m][q]);
+                    wsu_mfma_step<MODE>(ahi[m], blo[q], acc[m][q]);
+                    wsu_mfma_step<MODE>(ahi[m], bhi[q], acc[m][q]);
+                }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int g = 2 * ks + hh;
+                u32x4 av[2], bv[2];
+#pragma unroll
+                for (int m = 0; m < 2; ++m) av[m] = *reinterpret_cast<const u32x4*>(ldsA + (g * 64 + m * 32) * 16);
+#pragma unroll
+                for (int q = 0; q < 2; ++q) bv[q] = *reinterpret_cast<const u32x4*>(ldsB + g * PLANE_IN + q * TW * 16);
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) wsu_mfma_step<MODE>(av[m], bv[q], acc[m][q]);
+            }
+        }
+    }
+
+    // ---- epilogue: [4 output rows x 64 output cols][64 co] tile in LDS --------------------------------
+    __syncthreads();
+    const int sa = wv >> 1, sb = wv & 1;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const int co = m * 32 + 8 * g4 + 4 * hh;
+            f32x4 b4 = mk_f4(0.f, 0.f, 0.f, 0.f);
+            if (a.bias) b4 = *reinterpret_cast<const f32x4*>(a.bias + cb * WSU_COB + co);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const float v0 = acc[m][q][4 * g4 + 0] + b4.x, v1 = acc[m][q][4 * g4 + 1] + b4.y;
+                const float v2 = acc[m][q][4 * g4 + 2] + b4.z, v3 = acc[m][q][4 * g4 + 3] + b4.w;
+                const int opx = (2 * q + sa) * (2 * TW) + 2 * l31 + sb;
+                if constexpr (ESZ == 4) *reinterpret_cast<f32x4*>(smem + opx * STRIDE + co * 4) = mk_f4(v0, v1, v2, v3);
+                else *reinterpret_cast<u32x2*>(smem + opx * STRIDE + co * 2) = mk_u2(wsu_pack_bf16x2(v0, v1), wsu_pack_bf16x2(v2, v3));
+            }
+        }
+    }
+    __syncthreads();
+    const int oh = 2 * a.h, ow = 2 * a.w;
+#pragma unroll
+    for (int k = 0; k < 4 * NPIX * VPP / NT; ++k) {
+        const int i = tid + k * NT;
+        const int opx = i / VPP, v = i % VPP;
+        const int r = opx / (2 * TW), c = opx % (2 * TW);
+        const int oy = 2 * y0 + r, ox = 2 * x0 + c;
+        if (oy < oh && ox < ow) {
+            const u32x4 val = *reinterpret_cast<const u32x4*>(smem + opx * STRIDE + v * 16);
+            *reinterpret_cast<u32x4*>(a.y + (((size_t)(n * oh + oy) * ow + ox) * a.cout + cb * WSU_COB) * ESZ + v * 16) = val;
+        }
+    }
+}
+
+template <int MODE>
+int launch_ct(const CtArgs& a, hipStream_t s) {
+    constexpr int ESZ = (MODE == WSU_MODE_BF16) ? 2 : 4;
+    constexpr int EPI = 4 * NPIX * (WSU_COB * ESZ + 16);
+    const int lds = EPI > LDS_MAIN ? EPI : LDS_MAIN;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&convt2x2_kernel<MODE>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) { wsu_set_error("hipFuncSetAttribute(convt2x2): %s", hipGetErrorString(e)); return WSU_ERR_HIP; }
+        attr_done = true;
+    }
+    const long long nblk = (long long)a.n * a.tiles_x * a.tiles_y * a.ncb;
+    if (nblk <= 0 || nblk > 0x7FFFFFFFLL) { wsu_set_error("convt2x2: grid of %lld workgroups out of range", nblk); return WSU_ERR_ARG; }
+    hipLaunchKernelGGL(convt2x2_kernel<MODE>, dim3((unsigned)nblk), dim3(NT), lds, s, a);
+    return wsu_check_launch("convt2x2_kernel");
+}
+
+// (Cin, Cout, 2, 2) fp32 -> [cob][chunk][sub = a*2+b][granule][co 64][16 B]
+template <int MODE>
+__global__ void pack_convt_kernel(const float* __restrict__ w, char* __restrict__ dst, int cin, int cout) {
+    constexpr int CK = (MODE == WSU_MODE_BF16) ? 32 : 16;
+    constexpr int EPG = (MODE == WSU_MODE_F32) ? 4 : 8;
+    const int nch = cin / CK;
+    const long long total = (long long)(cout / WSU_COB) * nch * 4 * WSU_GRAN * WSU_COB * EPG;
+    for (long long d = (long long)blockIdx.x * blockDim.x + threadIdx.x; d < total; d += (long long)gridDim.x * blockDim.x) {
+        long long t = d;
+        const int e = t % EPG; t /= EPG;
+        const int co = t % WSU_COB; t /= WSU_COB;
+        const int g = t % WSU_GRAN; t /= WSU_GRAN;
+        const int sub = t % 4; t /= 4;
+        const int c = t % nch; t /= nch;
+        const int cb = (int)t;
+        int ci, part = 0;
+        if (MODE == WSU_MODE_F32) ci = c * CK + 4 * g + e;
+        else if (MODE == WSU_MODE_BF16) ci = c * CK + 8 * g + e;
+        else { ci = c * CK + 8 * (g & 1) + e; part = g >> 1; }
+        const float val = w[((size_t)ci * cout + cb * WSU_COB + co) * 4 + sub];
+        if (MODE == WSU_MODE_F32) reinterpret_cast<float*>(dst)[d] = val;
+        else {
+            const __bf16 hv = (__bf16)(part ? wsu_bf16_lo_residual(val) : val);
+            reinterpret_cast<uint16_t*>(dst)[d] = __builtin_bit_cast(uint16_t, hv);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t wsu_convt2x2_packed_bytes(int cin, int cout, int mode) {
+    if (cin <= 0 || cout <= 0 || mode < 0 || mode > 2) return 0;
+    return (size_t)cin * cout * 4 * (mode == WSU_MODE_BF16 ? 2 : 4);
+}
+
+int wsu_convt2x2_pack(const float* w_iohw, void* w_packed, int cin, int cout, int mode, void* stream) {
+    WSU_REQUIRE(w_iohw && w_packed, "convt2x2_pack: null pointer");
+    WSU_REQUIRE(mode >= 0 && mode <= 2, "convt2x2_pack: bad mode %d", mode);
+    WSU_REQUIRE(cin > 0 && cin % wsu_chunk_channels(mode) == 0, "convt2x2_pack: cin=%d not a multiple of %d", cin, wsu_chunk_channels(mode));
+    WSU_REQUIRE(cout > 0 && cout % WSU_COB == 0, "convt2x2_pack: cout=%d not a multiple of %d", cout, WSU_COB);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (mode == WSU_MODE_F32) hipLaunchKernelGGL(pack_convt_kernel<WSU_MODE_F32>, dim3(512), dim3(256), 0, s, w_iohw, (char*)w_packed, cin, cout);
+    else if (mode == WSU_MODE_BF16X3) hipLaunchKernelGGL(pack_convt_kernel<WSU_MODE_BF16X3>, dim3(512), dim3(256), 0, s, w_iohw, (char*)w_packed, cin, cout);
+    else hipLaunchKernelGGL(pack_convt_kernel<WSU_MODE_BF16>, dim3(512), dim3(256), 0, s, w_iohw, (char*)w_packed, cin, cout);
+    return wsu_check_launch("pack_convt_kernel");
+}
+
+int wsu_convt2x2_fwd(const void* x, const void* w_packed, const float* bias, void* y,
+                     int n, int h, int w, int cin, int cout, int mode, void* stream) {
+    WSU_REQUIRE(mode >= 0 && mode <= 2, "convt2x2: bad mode %d", mode);
+    WSU_REQUIRE(x && w_packed && y, "convt2x2: null pointer");
+    WSU_REQUIRE(n > 0 && h > 0 && w > 0, "convt2x2: bad shape n=%d h=%d w=%d", n, h, w);
+    WSU_REQUIRE(cin > 0 && cin % wsu_chunk_channels(mode) == 0, "convt2x2: cin=%d not a multiple of %d", cin, wsu_chunk_channels(mode));
+    WSU_REQUIRE(cout > 0 && cout % WSU_COB == 0, "convt2x2: cout=%d not a multiple of %d", cout, WSU_COB);
+    WSU_REQUIRE((long long)n * h * w * 4 < 0x7FFFFFFFLL, "convt2x2: output pixel count overflows int32");
+    CtArgs a;
+    a.x = (const char*)x; a.wp = (const char*)w_packed; a.bias = bias; a.y = (char*)y;
+    a.n = n; a.h = h; a.w = w; a.cin = cin; a.cout = cout;
+    a.tiles_x = (w + TW - 1) / TW; a.tiles_y = (h + TH - 1) / TH; a.ncb = cout / WSU_COB;
+    a.nch = cin / wsu_chunk_channels(mode);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (mode == WSU_MODE_F32) return launch_ct<WSU_MODE_F32>(a, s);
+    if (mode == WSU_MODE_BF16X3) return launch_ct<WSU_MODE_BF16X3>(a, s);
+    return launch_ct<WSU_MODE_BF16>(a, s);
+}
+
+}  // extern "C"
