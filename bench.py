@@ -76,7 +76,14 @@ def cpu_baseline(sample_u8, budget_s=25.0):
     src/unet/evaluate.py:48), fp32, all host threads.  Bounded: stops after `budget_s` seconds."""
     from ws_unet_amd import formula
     from oracle import unet_ref
-    torch.set_num_threads(os.cpu_count() or 1)
+    # the box's CPU share (cgroup / affinity), not the host's core count: oversubscribing oneDNN's thread
+    # pool on a 16-core share of a 256-core host made the baseline 10x slower than it should be
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncpu = os.cpu_count() or 1
+    ncpu = max(1, min(ncpu, int(os.environ.get("WSU_CPU_THREADS", "16"))))
+    torch.set_num_threads(ncpu)
     ref = unet_ref.build_ref(2, formula.formula_state_dict(2, "he"))
     outs, times = [], []
     x_all = torch.from_numpy(sample_u8.astype(np.float32) / np.float32(255.))[:, None]

@@ -8,6 +8,12 @@ from __future__ import annotations
 
 import ctypes
 import os
+
+# torch MUST be imported before libwsu.so is dlopen'ed: the PyTorch-ROCm wheel bundles its own HIP runtime
+# (torch/lib/libamdhip64.so, SONAME libamdhip64.so.7).  Loaded first, it also satisfies libwsu's DT_NEEDED
+# libamdhip64.so.7, so kernels, streams and device pointers live in ONE runtime.  Loaded second, the system
+# runtime from libwsu's RUNPATH would be a second, device-less runtime ("no ROCm-capable device").
+import torch  # noqa: F401
 from ctypes import c_char_p, c_float, c_int, c_size_t, c_uint64, c_void_p
 from pathlib import Path
 
