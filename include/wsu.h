@@ -108,6 +108,64 @@ int wsu_ws_residual_stats(const uint8_t* x_u8, const float* y01, float* beta_hat
 /* ---- u8 -> [0,1] fp32, numpy float32 division semantics of evaluate.py:45 (x / 255.) */
 int wsu_u8_to_unit_f32(const uint8_t* x, float* y, size_t count, void* stream);
 
+/* ======================= backward / train step (K7, K8, K9) =======================
+ * The reference publishes no UNet training script; these entry points are the autograd of
+ * UNet.forward (unet.py:137-189) + the loss classes (src/_defs/losses.py:28-121) + torch.optim.AdamW as used
+ * by the detector loop (src/detector/train.py:55-95,228).  Gradients are exact-fp32 / split-bf16 on fp32 storage;
+ * every reduction is two-stage in a fixed order (bitwise reproducible, no float atomics).
+ * "g" always denotes a PRE-activation gradient (dLoss/d(conv output before ReLU)). */
+
+/* dx of conv3x3-reflect: zero-padded transposed conv on the matrix cores + reflect-adjoint border fold.
+ * g: (N,H,W,Cout) fp32.  dx1: (N,H,W,csplit), dx2: (N,H,W,cin-csplit) or NULL (the two inputs of a fused concat).
+ * relu_mask1/2 (optional, shapes of dx1/dx2): saved post-ReLU activations; where they are <= 0 the gradient is zeroed,
+ * which makes dx the pre-activation gradient of the producing layers.  mode: WSU_MODE_F32 or WSU_MODE_BF16X3. */
+int wsu_conv3x3_bwd_data(const void* g, const void* w_packed_dgrad, const float* w_oihw,
+                         void* dx1, void* dx2, int csplit, const void* relu_mask1, const void* relu_mask2,
+                         int n, int h, int w, int cin, int cout, int mode, void* stream);
+
+/* dW (OIHW, Cout x (c1+c2) x 3 x 3) and db (Cout, optional) of conv3x3-reflect on cat[x1, x2]; exact fp32 MFMA. */
+size_t wsu_wgrad_workspace_bytes(int cm, int cn, int ntaps);
+int wsu_conv3x3_bwd_weight(const float* g, const float* x1, const float* x2, float* dw, float* db,
+                           float* workspace, size_t workspace_bytes,
+                           int n, int h, int w, int c1, int c2, int cout, void* stream);
+
+/* first layer: dW (Cout x cin x 3 x 3), db from g (N,H,W,Cout) and the NCHW fp32 input planes. */
+size_t wsu_first_bwd_workspace_bytes(int n, int h, int w, int cin, int cout);
+int wsu_conv3x3_first_bwd_weight(const float* g, const float* x_nchw, float* dw, float* db,
+                                 float* workspace, size_t workspace_bytes, int n, int h, int w, int cin, int cout, void* stream);
+
+/* transposed conv: dW (Cin x Cout x 2 x 2), db (Cout, optional) from x (N,h,w,Cin) and dy (N,2h,2w,Cout) ... */
+int wsu_convt2x2_bwd_weight(const float* x, const float* dy, float* dw, float* db,
+                            float* workspace, size_t workspace_bytes,
+                            int n, int h, int w, int cin, int cout, void* stream);
+/* ... and dx (N,h,w,Cin), optionally masked by the saved post-ReLU activation of the producing layer. */
+size_t wsu_convt2x2_packed_dgrad_bytes(int cin, int cout, int mode);
+int wsu_convt2x2_pack_dgrad(const float* w_iohw, void* w_packed, int cin, int cout, int mode, void* stream);
+int wsu_convt2x2_bwd_data(const void* dy, const void* w_packed_dgrad, void* dx, const void* relu_mask,
+                          int n, int h, int w, int cin, int cout, int mode, void* stream);
+
+/* 2x2 max-pool backward into the full-resolution gradient buffer (accumulate != 0: add to what the skip path
+ * already stored there).  pool_idx from the forward; xp_relu_mask: pooled activation (gradient only where > 0). */
+int wsu_maxpool2x2_bwd(float* g_full, const float* dy_pool, const uint8_t* pool_idx, const float* xp_relu_mask,
+                       int n, int h, int w, int c, int accumulate, void* stream);
+
+/* head: gx (N,H,W,C) = relu_mask(x) * W^T (dout * out * (1-out)); dw (cout x C), db (cout); cout <= 4. */
+size_t wsu_head_bwd_workspace_bytes(int c, int cout);
+int wsu_conv1x1_sigmoid_bwd(const float* x, const float* w, const float* out, const float* dout,
+                            float* gx, float* dw, float* db, float* workspace, size_t workspace_bytes,
+                            int n, int h, int w_, int c, int cout, int apply_relu_mask, void* stream);
+
+/* K8: L1 + WS loss and dLoss/dout in one call (losses.py:33-36,47-89,99-116). */
+size_t wsu_l1ws_loss_workspace_bytes(int n);
+int wsu_l1ws_loss_fwd_bwd(const float* out, const float* covers, const float* inputs, const float* alphas,
+                          float* loss, float* loss_parts, float* dout, float* beta_hat, void* workspace, size_t workspace_bytes,
+                          int n, long long per_image, int use_l1, int use_ws, void* stream);
+
+/* K9: multi-tensor AdamW (decoupled weight decay), one launch for all parameters.
+ * table: DEVICE array of ntensors records {float* p; const float* g; float* m; float* v; int64 n; int64 first_block}. */
+int wsu_adamw_multi_tensor(const void* table, int ntensors, long long total_blocks,
+                           float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

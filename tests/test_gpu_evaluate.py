@@ -1,0 +1,115 @@
+"""GPU tests of the predictor / evaluate API against the oracle restatement of src/unet/evaluate.py."""
+import json
+
+import numpy as np
+import pandas as pd
+import pytest
+import torch
+from PIL import Image
+
+from conftest import GOLDEN
+from gpu_util import DEV, gpu_model
+from ws_unet_amd import evaluate, formula, get_unet_estimator
+from ws_unet_amd.imread import imread4_f32
+from oracle import evaluate_ref, unet_ref
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ref_model():
+    return unet_ref.build_ref(2, formula.formula_state_dict(2, "he"))
+
+
+@pytest.mark.parametrize("mode,tol", [("f32", 2e-3), ("bf16x3", 6e-3)])
+def test_infere_single_and_predict_unet_on_real_cover(ref_model, mode, tol):
+    """cover_10.png is one of the reference's own 512x512 covers; tolerances are in 0..255 units
+    (tol/255 on the [0,1] output: 8e-6 / 2.4e-5)."""
+    fname = GOLDEN / "cover_10.png"
+    x = imread4_f32(fname)[..., 3:]
+    model = gpu_model(2, "he", mode, drop_rate=0.)                 # get_pretrained builds with drop_rate=0.
+    y = evaluate.infere_single(x, model)
+    y_ref = evaluate_ref.infere_single(x, ref_model)
+    assert y.shape == (510, 510, 1) and y.dtype == np.float32
+    assert np.abs(y - y_ref).max() <= tol
+    assert x.max() > 1.0                                            # the caller's array is not modified in place
+    res = evaluate.predict_unet(fname, model, name="images/10.png", height=512, width=512)
+    ref = evaluate_ref.predict_unet_array(x, ref_model)
+    assert set(res) == {"name", "height", "width", "beta_hat", "l1"}
+    assert abs(res["beta_hat"] - ref["beta_hat"]) <= 1e-4 and abs(res["l1"] - ref["l1"]) <= 1e-4
+
+
+def _make_dataset(root, n=5):
+    (root / "images").mkdir()
+    u8 = formula.synthetic_images(n, 512, 512, seed=50)
+    names = []
+    for i, k in enumerate((3, 10, 1, 22, 7)[:n]):
+        Image.fromarray(u8[i]).save(root / "images" / f"{k}.png")
+        names.append(f"images/{k}.png")
+    (root / "images" / "files.csv").write_text("name,height,width\n" + "".join(f"{n_},512,512\n" for n_ in names))
+    sdir = root / "stego_LSBR_alpha_0.4"
+    sdir.mkdir()
+    for i, k in enumerate((3, 10)):
+        Image.fromarray(formula.lsbr_embed(u8[i], 0.4, seed=k)).save(sdir / f"{k}.png")
+    (sdir / "files.csv").write_text("name,height,width,stego_method,alpha\n" + "".join(
+        f"stego_LSBR_alpha_0.4/{k}.png,512,512,LSBR,0.4\n" for k in (3, 10)))
+    return u8
+
+
+def test_evaluate_loop_per_image_vs_batched(tmp_path, ref_model):
+    u8 = _make_dataset(tmp_path)
+    model = gpu_model(2, "he", "f32", drop_rate=0.)
+    df = evaluate.predict_unet_cover(tmp_path, model=model, progress_on=False)
+    dfb = evaluate.predict_unet_cover_batched(tmp_path, model=model)
+    assert list(df.columns) == ["name", "height", "width", "beta_hat", "l1"] == list(dfb.columns)
+    assert df["name"].tolist() == ["images/1.png", "images/10.png", "images/22.png", "images/3.png", "images/7.png"] == dfb["name"].tolist()
+    np.testing.assert_allclose(dfb["beta_hat"].to_numpy(float), df["beta_hat"].to_numpy(float), atol=2e-5)
+    np.testing.assert_allclose(dfb["l1"].to_numpy(float), df["l1"].to_numpy(float), atol=2e-5)
+    # oracle for the first row (images/1.png is u8[2])
+    ref = evaluate_ref.predict_unet_array(u8[2][..., None].astype(np.float32), ref_model)
+    assert abs(df["beta_hat"][0] - ref["beta_hat"]) <= 1e-4 and abs(df["l1"][0] - ref["l1"]) <= 1e-4
+    st = evaluate.predict_unet_stego(tmp_path, model=model, stego_method="LSBR")
+    stb = evaluate.predict_unet_stego_batched(tmp_path, model=model, stego_method="LSBR", alpha=0.4)
+    assert list(st.columns) == ["name", "height", "width", "stego_method", "alpha", "beta_hat", "l1"] == list(stb.columns)
+    np.testing.assert_allclose(stb["beta_hat"].to_numpy(float), st["beta_hat"].to_numpy(float), atol=2e-5)
+    take = evaluate.predict_unet_cover_batched(tmp_path, model=model, take_num_images=2, skip_num_images=1)
+    assert take["name"].tolist() == ["images/10.png", "images/22.png"]
+
+
+def test_model_discovery_and_checkpoint_roundtrip(tmp_path):
+    sd = formula.formula_state_dict(2, "he")
+    run = tmp_path / "LSBR" / "240101000000-1-unet_2-test"
+    (run / "model").mkdir(parents=True)
+    cfg = {"stego_method": "LSBR", "alpha": "0.400", "loss": "l1ws", "network": "unet_2", "drop_rate": 0.0, "debug": False}
+    (run / "config.json").write_text(json.dumps(cfg))
+    torch.save({"epoch": 7, "state_dict": {k: torch.from_numpy(v) for k, v in sd.items()}, "best_val_loss": 0.1,
+                "patience": 3, "optimizer": None, "scheduler": None}, run / "model" / "best_model.pt.tar")
+    dbg = tmp_path / "LSBR" / "debug-run"
+    (dbg / "model").mkdir(parents=True)
+    (dbg / "config.json").write_text(json.dumps({**cfg, "debug": True}))
+    torch.save({"epoch": 1, "state_dict": {}}, dbg / "model" / "best_model.pt.tar")
+    nock = tmp_path / "LSBR" / "no-checkpoint"
+    nock.mkdir()
+    (nock / "config.json").write_text(json.dumps(cfg))
+    name = evaluate.get_model_name("LSBR", model_dir=tmp_path)
+    assert name == run.name
+    assert evaluate.get_model_config(tmp_path, "LSBR", name)["network"] == "unet_2"
+    model = evaluate.get_pretrained(tmp_path / "LSBR", (3,), model_name=name, mode="f32")
+    assert model.nsteps == 2 and model.input_dropout is not None and next(model.parameters()).is_cuda
+    np.testing.assert_array_equal(model.e32.weight.detach().cpu().numpy(), sd["e32.weight"])
+    with pytest.raises(RuntimeError, match="no model for"):
+        evaluate.get_model_name("HILLR", model_dir=tmp_path)
+    dup = tmp_path / "LSBR" / "second-run"
+    (dup / "model").mkdir(parents=True)
+    (dup / "config.json").write_text(json.dumps(cfg))
+    torch.save({"epoch": 2, "state_dict": {}}, dup / "model" / "best_model.pt.tar")
+    with pytest.raises(RuntimeError, match="multiple models for"):
+        evaluate.get_model_name("LSBR", model_dir=tmp_path)
+    # the closure used by the WS estimator callers
+    predict = get_unet_estimator(tmp_path / "LSBR", (3,), model_name=name)
+    x = formula.synthetic_images(1, 512, 512, seed=3)[0][..., None].astype(np.float32)
+    y = predict(x)
+    assert y.shape == (510, 510, 1) and 0 <= y.min() and y.max() <= 255
+    from ws_unet_amd.model import get_model
+    with pytest.raises(NotImplementedError):
+        get_model("cnn_1", in_channels=1)

@@ -1,0 +1,139 @@
+"""CPU tests of the host-side mirror of the reference interface: fabrika iterator (against golden rows
+produced by the reference's fabrika), input transform, image reading."""
+import json
+from pathlib import Path
+
+import numpy as np
+import pandas as pd
+import pytest
+import torch
+
+from conftest import GOLDEN
+from ws_unet_amd import fabrika
+from ws_unet_amd.data import get_timm_transform, center_crop, to_tensor
+from ws_unet_amd.imread import imread4_u8, imread4_f32, imread_u8
+from oracle import evaluate_ref
+
+
+def echo(fname, **kw):
+    return {**kw, "fname": str(fname)}
+
+
+cover_it = fabrika.precovers(iterator="python", convert_to="pandas", ignore_missing=False, n_jobs=-1)(echo)
+stego_it = fabrika.stego_spatial(iterator="python", convert_to="pandas", ignore_missing=False, n_jobs=-1)(echo)
+
+
+def make_syn(tmp: Path):
+    """Same layout as tests/golden/make_golden.py:gen_fabrika builds for the reference."""
+    (tmp / "images").mkdir()
+    names = [f"images/{i}.png" for i in (1, 10, 11, 2, 20, 3)]
+    (tmp / "images" / "files.csv").write_text("name,height,width\n" + "".join(f"{n},512,512\n" for n in names))
+    (tmp / "images_b").mkdir()
+    (tmp / "images_b" / "files.csv").write_text("name,height,width\nimages_b/7.png,256,256\n")
+    sd = tmp / "stego_X_alpha_0.4"
+    sd.mkdir()
+    sd.joinpath("files.csv").write_text("name,height,width,stego_method,alpha\n" + "".join(
+        f"stego_X_alpha_0.4/{i}.png,512,512,X,0.4\n" for i in (1, 10, 2)))
+
+
+def rows(df, root):
+    out = json.loads(df.to_json(orient="records"))
+    for r in out:
+        r["fname"] = r["fname"].replace(str(root), "<DATASET>")
+    return out
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return json.loads((GOLDEN / "fabrika.json").read_text())
+
+
+def test_fabrika_matches_reference_rows(tmp_path, gold):
+    make_syn(tmp_path)
+    assert rows(cover_it(tmp_path), tmp_path) == gold["syn_covers"]
+    assert rows(cover_it(tmp_path, take_num_images=2), tmp_path) == gold["syn_covers_take2"]
+    assert rows(cover_it(tmp_path, shuffle_seed=5), tmp_path) == gold["syn_covers_shuffle5"]
+    assert rows(stego_it(tmp_path, stego_method="X", alpha=0.4), tmp_path) == gold["syn_stego"]
+    # lexical order: images/1, images/10, images/11, images/2 ...
+    assert [r["name"] for r in gold["syn_covers"]][:4] == ["images/1.png", "images/10.png", "images/11.png", "images/2.png"]
+    with pytest.raises(Exception, match="pre_fn\\(\\) returned empty dataframe"):
+        stego_it(tmp_path, stego_method="nope")
+    assert gold["syn_stego_empty_error"] == "pre_fn() returned empty dataframe"
+
+
+def test_fabrika_reference_dataset_rows_recorded(gold):
+    """What the reference's own data dir yields (recorded, the dir itself does not travel): 5 covers in
+    lexical order, one cover in split_te.csv, 30 LSBR stego rows."""
+    assert [r["name"] for r in gold["ref_covers"]] == [f"images/{i}.png" for i in (10, 6, 7, 8, 9)]
+    assert [r["name"] for r in gold["ref_covers_split_te"]] == ["images/10.png"]
+    assert len(gold["ref_stego_lsbr"]) == 30 and len(gold["ref_stego_lsbr_04"]) == 5
+
+
+def test_fabrika_iterators_and_errors(tmp_path):
+    make_syn(tmp_path)
+    batched = fabrika.precovers(iterator="batched", convert_to="pandas", batch_size=4)(
+        lambda fnames, kws: [{**kw, "fname": str(f)} for f, kw in zip(fnames, kws)])
+    pd.testing.assert_frame_equal(batched(tmp_path), cover_it(tmp_path))
+    as_np = fabrika.precovers(iterator="python", convert_to="numpy")(lambda f, **kw: kw["height"])
+    assert as_np(tmp_path).tolist() == [512] * 6 + [256]
+    whole = fabrika.precovers(iterator=None, convert_to=None)(lambda df, **kw: list(df["name"]))
+    assert whole(tmp_path)[0] == str(tmp_path / "images/1.png")
+    with pytest.raises(NotImplementedError, match="unknown iterator"):
+        fabrika.precovers(iterator="spark")(echo)(tmp_path)
+    with pytest.raises(NotImplementedError, match="unknown convertor"):
+        fabrika.precovers(convert_to="arrow")(echo)(tmp_path)
+    jl = fabrika.precovers(iterator="joblib", convert_to="pandas", n_jobs=2)(echo)
+    pd.testing.assert_frame_equal(jl(tmp_path), cover_it(tmp_path))
+    # extra kwargs flow to fn merged over the row (fabrika.py:86-89)
+    df = cover_it(tmp_path, tag="t1", take_num_images=1)
+    assert df["tag"].tolist() == ["t1"]
+    assert fabrika.filename_to_image_seed("a/b/10.png") == fabrika.filename_to_image_seed("10.jpg")
+    assert 0 <= fabrika.filename_to_image_seed("x") < 2 ** 31
+
+
+def test_cover_stego_pairs(tmp_path):
+    make_syn(tmp_path)
+    # cover rows need a stego_method column to be split; emulate a split csv carrying both kinds
+    rows_ = ["name,height,width,stego_method,alpha"]
+    rows_ += [f"images/{i}.png,512,512,," for i in (1, 10, 2)]
+    rows_ += [f"stego_X_alpha_0.4/{i}.png,512,512,X,0.4" for i in (1, 10)]
+    (tmp_path / "split.csv").write_text("\n".join(rows_) + "\n")
+    pairs = fabrika.cover_stego_spatial(iterator="python", convert_to="pandas")(echo)(tmp_path, split="split.csv", stego_method="X")
+    assert pairs["name_c"].tolist() == ["images/1.png", "images/10.png", "images/2.png"]
+    assert pairs["name_s"].tolist()[:2] == ["stego_X_alpha_0.4/1.png", "stego_X_alpha_0.4/10.png"]
+    assert pd.isna(pairs["name_s"].tolist()[2])
+
+
+def test_transform_semantics():
+    tf = get_timm_transform(mean=None, std=None, grayscale=True)
+    x = np.random.default_rng(0).integers(0, 256, (512, 512, 1)).astype(np.float32)
+    t = tf(x / 255.)
+    assert t.shape == (1, 512, 512) and t.dtype == torch.float32
+    np.testing.assert_array_equal(t.numpy()[0], (x / 255.)[..., 0])            # identity on 512x512 gray
+    assert torch.equal(t, evaluate_ref.transform_gray((x / 255.).astype(np.float32)))
+    # 4-plane input keeps plane 3; larger / smaller images are centre-cropped / zero-padded
+    x4 = np.random.default_rng(1).random((600, 520, 4)).astype(np.float32)
+    t4 = tf(x4)
+    assert torch.equal(t4, evaluate_ref.transform_gray(x4))
+    np.testing.assert_array_equal(t4.numpy()[0], x4[44:556, 4:516, 3])
+    small = np.ones((100, 101, 1), np.float32)
+    ts = tf(small)
+    assert ts.shape == (1, 512, 512) and ts.sum().item() == 100 * 101
+    assert torch.equal(ts, evaluate_ref.transform_gray(small))
+    assert ts[0, 206, 205].item() == 1 and ts[0, 205, 205].item() == 0 and ts[0, 206, 204].item() == 0
+    # uint8 ToTensor scales, float does not
+    assert to_tensor(np.full((2, 2, 1), 255, np.uint8)).max().item() == 1.0
+    # optional oracles append planes
+    tp = get_timm_transform(None, None, grayscale=True, parity_oracle=True, demosaic_oracle=True)(x / 255.)
+    assert tp.shape == (5, 512, 512)
+    np.testing.assert_array_equal(tp[1].numpy(), (x[..., 0].astype(np.int64) & 1).astype(np.float32))
+    assert tp[2, 0, 0] == 1 and tp[3, 0, 1] == 1 and tp[3, 1, 0] == 1 and tp[4, 1, 1] == 1
+
+
+def test_imread_gray_png():
+    x4 = imread4_u8(GOLDEN / "cover_10.png")
+    assert x4.shape == (512, 512, 4) and x4.dtype == np.uint8
+    for c in range(3):
+        np.testing.assert_array_equal(x4[..., c], x4[..., 3])
+    np.testing.assert_array_equal(x4[..., 3:], imread_u8(GOLDEN / "cover_10.png"))
+    assert imread4_f32(GOLDEN / "cover_10.png").dtype == np.float32

@@ -14,7 +14,7 @@ import os
 # libamdhip64.so.7, so kernels, streams and device pointers live in ONE runtime.  Loaded second, the system
 # runtime from libwsu's RUNPATH would be a second, device-less runtime ("no ROCm-capable device").
 import torch  # noqa: F401
-from ctypes import c_char_p, c_float, c_int, c_size_t, c_uint64, c_void_p
+from ctypes import c_char_p, c_float, c_int, c_longlong, c_size_t, c_uint64, c_void_p
 from pathlib import Path
 
 _HERE = Path(__file__).resolve().parent
@@ -47,6 +47,22 @@ SIGNATURES = {
     "wsu_uniform_dropout_fwd": (c_int, [_P, _P, _P, _P] + [c_int] * 5 + [c_float, c_uint64, _P]),
     "wsu_ws_residual_stats": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P]),
     "wsu_u8_to_unit_f32": (c_int, [_P, _P, c_size_t, _P]),
+    # ---- backward / train step
+    "wsu_conv3x3_bwd_data": (c_int, [_P, _P, _P, _P, _P, c_int, _P, _P] + [c_int] * 6 + [_P]),
+    "wsu_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "wsu_conv3x3_bwd_weight": (c_int, [_P, _P, _P, _P, _P, _P, c_size_t] + [c_int] * 6 + [_P]),
+    "wsu_first_bwd_workspace_bytes": (c_size_t, [c_int] * 5),
+    "wsu_conv3x3_first_bwd_weight": (c_int, [_P, _P, _P, _P, _P, c_size_t] + [c_int] * 5 + [_P]),
+    "wsu_convt2x2_bwd_weight": (c_int, [_P, _P, _P, _P, _P, c_size_t] + [c_int] * 5 + [_P]),
+    "wsu_convt2x2_packed_dgrad_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "wsu_convt2x2_pack_dgrad": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
+    "wsu_convt2x2_bwd_data": (c_int, [_P, _P, _P, _P] + [c_int] * 6 + [_P]),
+    "wsu_maxpool2x2_bwd": (c_int, [_P, _P, _P, _P] + [c_int] * 5 + [_P]),
+    "wsu_head_bwd_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "wsu_conv1x1_sigmoid_bwd": (c_int, [_P] * 8 + [c_size_t] + [c_int] * 6 + [_P]),
+    "wsu_l1ws_loss_workspace_bytes": (c_size_t, [c_int]),
+    "wsu_l1ws_loss_fwd_bwd": (c_int, [_P] * 9 + [c_size_t, c_int, c_longlong, c_int, c_int, _P]),
+    "wsu_adamw_multi_tensor": (c_int, [_P, c_int, c_longlong] + [c_float] * 5 + [c_int, c_float, _P]),
 }
 
 _lib = None

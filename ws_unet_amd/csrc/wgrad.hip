@@ -1,0 +1,269 @@
+// K7 (weight / bias gradients) of the 3x3 reflect convolution and of the 2x2 transposed convolution,
+// exact fp32 on the matrix cores (v_mfma_f32_32x32x2_f32), deterministic.
+//
+// autograd of nn.Conv2d(k3, reflect) / nn.ConvTranspose2d(k2, s2) in the reference's train step
+// (src/unet/model/unet.py:82-132; loop pattern src/detector/train.py:55-95):
+//   conv :  dW[co, ci, u, v] = sum_{n,y,x} g[n,y,x,co] * xpad[n, y+u-1, x+v-1, ci]      db[co] = sum g[.., co]
+//   convT:  dW[ci, co, a, b] = sum_{n,i,j} x[n,i,j,ci] * dy[n, 2i+a, 2j+b, co]          db[co] = sum dy[.., co]
+// Both are GEMMs with the PIXEL index as the reduction dimension:  D_t[m, n] = sum_p U[p, m] * V_t[p, n]
+//   conv :  U = g  (m = co),  V_t = x shifted by tap t (n = ci; two sources for the fused concat), 9 taps
+//   convT:  U = x  (m = ci),  V_t = dy gathered at sub-position t (n = co),                          4 taps
+// With NHWC fp32 tiles in LDS as [pixel][64 channels], lane (i = lane&31, k = lane>>5) of the 32x32x2 MFMA reads
+// U[pixel 2s+k][i] / V[pixel' 2s+k][i]: 32 consecutive floats per half-wave, conflict free, no transpose.
+// One workgroup = 64 m x 64 n x all taps, 4 waves as 2x2 of 32x32 tiles, NTAPS accumulator tiles per wave.
+// Split-K over pixel tiles: workgroup (split, mb, nb) walks its share of the tiles and writes one partial
+// slab; wgrad_reduce sums the slabs in a fixed order into the OIHW / IOHW gradient (bitwise reproducible --
+// no float atomics).
+#include "wsu_device.h"
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int TW = 32;
+
+struct WgArgs {
+    const float* u;                 // (N, Hu, Wu, cu)  unshifted operand
+    const float* v1; const float* v2;   // gathered operand(s): (N, Hv, Wv, cv1) [, (N, Hv, Wv, cv2)]
+    float* part;                    // [nsplit][nmb][nnb][NTAPS][64][64]
+    float* bpart;                   // [nsplit][nmb][64] column sums of U (written by nb == 0 workgroups) or null
+    int n, hu, wu, cu, cv1, cv2;
+    int tiles_x, tiles_y, ntiles, nsplit, nmb, nnb, tiles_per_split;
+};
+
+// KIND 0: conv3x3 (TH = 2, V tile (TH+2) x (TW+2), reflect);  KIND 1: convT2x2 (TH = 1, V tile 2TH x 2TW)
+template <int KIND> struct Geo {
+    static constexpr int NTAPS = KIND == 0 ? 9 : 4;
+    static constexpr int TH = KIND == 0 ? 2 : 1;
+    static constexpr int VH = KIND == 0 ? TH + 2 : 2 * TH;
+    static constexpr int VW = KIND == 0 ? TW + 2 : 2 * TW;
+    static constexpr int U_BYTES = TH * TW * 256;
+    static constexpr int V_BYTES = VH * VW * 256;
+    static constexpr int LDS = U_BYTES + V_BYTES;
+};
+
+template <int KIND>
+__global__ __launch_bounds__(NT, 2) void wgrad_kernel(const WgArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using G = Geo<KIND>;
+    constexpr int NTAPS = G::NTAPS, TH = G::TH, VH = G::VH, VW = G::VW;
+    float* ul = reinterpret_cast<float*>(smem);                    // [TH*TW][64]
+    float* vl = reinterpret_cast<float*>(smem + G::U_BYTES);       // [VH*VW][64]
+
+    const int tid = threadIdx.x;
+    int b = blockIdx.x;
+    const int nb = b % a.nnb; b /= a.nnb;
+    const int mb = b % a.nmb;
+    const int split = b / a.nmb;
+    const int hv = KIND == 0 ? a.hu : 2 * a.hu, wv = KIND == 0 ? a.wu : 2 * a.wu;
+    const float* vsrc; int cv, vch0;
+    if (nb * 64 < a.cv1) { vsrc = a.v1; cv = a.cv1; vch0 = nb * 64; }
+    else                 { vsrc = a.v2; cv = a.cv2; vch0 = nb * 64 - a.cv1; }
+
+    const int wv_ = tid >> 6, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+    const int wm = wv_ >> 1, wn = wv_ & 1;
+    f32x16 acc[NTAPS];
+#pragma unroll
+    for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    float bsum = 0.f;                                               // column sum of U for channel tid&63, pixels == tid>>6 mod 4
+
+    const int t0 = split * a.tiles_per_split;
+    const int t1 = min(t0 + a.tiles_per_split, a.ntiles);
+    for (int tile = t0; tile < t1; ++tile) {
+        int tt = tile;
+        const int tx = tt % a.tiles_x; tt /= a.tiles_x;
+        const int ty = tt % a.tiles_y;
+        const int n = tt / a.tiles_y;
+        const int y0 = ty * TH, x0 = tx * TW;
+        __syncthreads();                                            // previous tile fully consumed
+        // ---- stage U (zero outside the image) and V (reflect / clamp: finite values, weighted by U == 0 outside)
+        for (int i = tid; i < TH * TW * 16; i += NT) {
+            const int p = i >> 4, gq = i & 15;
+            const int r = p / TW, c = p % TW;
+            u32x4 val = mk_u4(0, 0, 0, 0);
+            if (y0 + r < a.hu && x0 + c < a.wu)
+                val = *reinterpret_cast<const u32x4*>(a.u + ((size_t)(n * a.hu + y0 + r) * a.wu + x0 + c) * a.cu + mb * 64 + gq * 4);
+            *reinterpret_cast<u32x4*>(ul + p * 64 + gq * 4) = val;
+        }
+        for (int i = tid; i < VH * VW * 16; i += NT) {
+            const int p = i >> 4, gq = i & 15;
+            const int r = p / VW, c = p % VW;
+            int yy, xx;
+            if (KIND == 0) { yy = wsu_reflect(y0 - 1 + r, hv); xx = wsu_reflect(x0 - 1 + c, wv); }
+            else           { yy = min(2 * y0 + r, hv - 1);     xx = min(2 * x0 + c, wv - 1); }
+            *reinterpret_cast<u32x4*>(vl + p * 64 + gq * 4) =
+                *reinterpret_cast<const u32x4*>(vsrc + ((size_t)(n * hv + yy) * wv + xx) * cv + vch0 + gq * 4);
+        }
+        __syncthreads();
+        if (a.bpart && nb == 0) {
+            const int ch = tid & 63;
+            for (int p = tid >> 6; p < TH * TW; p += 4) bsum += ul[p * 64 + ch];
+        }
+        // ---- MFMA over pixel pairs
+#pragma unroll
+        for (int r = 0; r < TH; ++r) {
+            for (int c2 = 0; c2 < TW / 2; ++c2) {
+                const int c = 2 * c2 + hh;
+                const float av = ul[(r * TW + c) * 64 + wm * 32 + l31];
+#pragma unroll
+                for (int t = 0; t < NTAPS; ++t) {
+                    int vp;
+                    if (KIND == 0) vp = (r + t / 3) * VW + c + t % 3;
+                    else           vp = (2 * r + (t >> 1)) * VW + 2 * c + (t & 1);
+                    const float bv = vl[vp * 64 + wn * 32 + l31];
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // ---- partial slab: part[((split*nmb + mb)*nnb + nb)*NTAPS + t][m][n]
+    float* dst = a.part + ((size_t)((split * a.nmb + mb) * a.nnb + nb) * NTAPS) * 4096;
+#pragma unroll
+    for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            dst[(size_t)t * 4096 + m * 64 + wn * 32 + l31] = acc[t][r];
+        }
+    if (a.bpart && nb == 0) {
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);
+        red[tid] = bsum;
+        __syncthreads();
+        if (tid < 64) a.bpart[(size_t)(split * a.nmb + mb) * 64 + tid] = (red[tid] + red[tid + 64]) + (red[tid + 128] + red[tid + 192]);
+    }
+}
+
+// dW (conv: OIHW [M = co][Ntot = ci][3][3]; convT: IOHW [M = ci][Ntot = co][2][2]) = sum over splits, fixed order
+template <int KIND>
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bpart,
+                                                           float* __restrict__ dw, float* __restrict__ db,
+                                                           int nsplit, int nmb, int nnb) {
+    constexpr int NTAPS = Geo<KIND>::NTAPS;
+    const int mtot = nmb * 64, ntot = nnb * 64;
+    const long long total = (long long)mtot * ntot * NTAPS;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        // thread index ordered like the partial slabs (n fastest) for coalesced reads
+        long long t = i;
+        const int nl = t % 64; t /= 64;
+        const int ml = t % 64; t /= 64;
+        const int tap = t % NTAPS; t /= NTAPS;
+        const int nb = t % nnb; const int mb = (int)(t / nnb);
+        float s = 0.f;
+        for (int sp = 0; sp < nsplit; ++sp)
+            s += part[((size_t)((sp * nmb + mb) * nnb + nb) * NTAPS + tap) * 4096 + ml * 64 + nl];
+        const int m = mb * 64 + ml, n = nb * 64 + nl;
+        dw[((size_t)m * ntot + n) * NTAPS + tap] = s;
+    }
+    if (db && bpart) {
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < mtot; i += gridDim.x * blockDim.x) {
+            float s = 0.f;
+            for (int sp = 0; sp < nsplit; ++sp) s += bpart[(size_t)sp * mtot + i];
+            db[i] = s;
+        }
+    }
+}
+
+// plain per-channel sum over pixels (bias gradient of the transposed conv: db[co] = sum dy[..., co])
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, float* __restrict__ part, long long npix, int c, int chunk) {
+    // grid = (nchunks, c/64); block: 64 channels x 4 pixel groups
+    const int ch = blockIdx.y * 64 + (threadIdx.x & 63);
+    const long long p0 = (long long)blockIdx.x * chunk, p1 = min(p0 + chunk, npix);
+    float s = 0.f;
+    for (long long p = p0 + (threadIdx.x >> 6); p < p1; p += 4) s += x[p * c + ch];
+    __shared__ float red[256];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x < 64) part[(size_t)blockIdx.x * c + ch] = (red[threadIdx.x] + red[threadIdx.x + 64]) + (red[threadIdx.x + 128] + red[threadIdx.x + 192]);
+}
+__global__ void colsum_final_kernel(const float* __restrict__ part, float* __restrict__ out, int nchunks, int c) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= c) return;
+    float s = 0.f;
+    for (int k = 0; k < nchunks; ++k) s += part[(size_t)k * c + ch];
+    out[ch] = s;
+}
+
+template <int KIND>
+int run_wgrad(WgArgs a, float* dw, float* db, float* workspace, size_t workspace_bytes, hipStream_t s) {
+    using G = Geo<KIND>;
+    a.tiles_x = (a.wu + TW - 1) / TW; a.tiles_y = (a.hu + G::TH - 1) / G::TH;
+    a.ntiles = a.n * a.tiles_x * a.tiles_y;
+    a.nmb = a.cu / 64; a.nnb = (a.cv1 + a.cv2) / 64;
+    // enough workgroups to fill 256 CUs x 2, bounded by the tile count and the workspace
+    int nsplit = (512 + a.nmb * a.nnb - 1) / (a.nmb * a.nnb);
+    nsplit = max(1, min(nsplit, a.ntiles));
+    const size_t slab = (size_t)a.nmb * a.nnb * G::NTAPS * 4096 * sizeof(float);
+    const size_t bslab = (size_t)a.nmb * 64 * sizeof(float);
+    while (nsplit > 1 && nsplit * (slab + bslab) > workspace_bytes) --nsplit;
+    if (nsplit * (slab + bslab) > workspace_bytes) {
+        wsu_set_error("wgrad: workspace of %zu bytes too small (need >= %zu)", workspace_bytes, slab + bslab);
+        return WSU_ERR_ARG;
+    }
+    a.nsplit = nsplit;
+    a.tiles_per_split = (a.ntiles + nsplit - 1) / nsplit;
+    a.part = workspace;
+    a.bpart = db ? workspace + (size_t)nsplit * slab / sizeof(float) : nullptr;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<KIND>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
+        if (e != hipSuccess) { wsu_set_error("hipFuncSetAttribute(wgrad): %s", hipGetErrorString(e)); return WSU_ERR_HIP; }
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(wgrad_kernel<KIND>, dim3(nsplit * a.nmb * a.nnb), dim3(NT), G::LDS, s, a);
+    int rc = wsu_check_launch("wgrad_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(wgrad_reduce_kernel<KIND>, dim3(512), dim3(256), 0, s, a.part, a.bpart, dw, db, nsplit, a.nmb, a.nnb);
+    return wsu_check_launch("wgrad_reduce_kernel");
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t wsu_wgrad_workspace_bytes(int cm, int cn, int ntaps) {
+    // room for up to 512 partial slabs' worth of workgroups: ceil(512 / blocks) splits, each (cm/64)(cn/64) slabs
+    if (cm <= 0 || cn <= 0 || ntaps <= 0) return 0;
+    const size_t nmb = cm / 64, nnb = cn / 64;
+    size_t nsplit = (512 + nmb * nnb - 1) / (nmb * nnb);
+    return nsplit * (nmb * nnb * ntaps * 4096 + nmb * 64) * sizeof(float);
+}
+
+int wsu_conv3x3_bwd_weight(const float* g, const float* x1, const float* x2, float* dw, float* db,
+                           float* workspace, size_t workspace_bytes,
+                           int n, int h, int w, int c1, int c2, int cout, void* stream) {
+    WSU_REQUIRE(g && x1 && dw && workspace, "conv3x3_bwd_weight: null pointer");
+    WSU_REQUIRE(n > 0 && h >= 2 && w >= 2, "conv3x3_bwd_weight: bad shape");
+    WSU_REQUIRE(c1 > 0 && c1 % 64 == 0 && c2 >= 0 && c2 % 64 == 0 && (c2 == 0) == (x2 == nullptr), "conv3x3_bwd_weight: c1=%d c2=%d must be multiples of 64", c1, c2);
+    WSU_REQUIRE(cout > 0 && cout % 64 == 0, "conv3x3_bwd_weight: cout=%d must be a multiple of 64", cout);
+    WgArgs a{};
+    a.u = g; a.v1 = x1; a.v2 = x2; a.n = n; a.hu = h; a.wu = w; a.cu = cout; a.cv1 = c1; a.cv2 = c2;
+    return run_wgrad<0>(a, dw, db, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+}
+
+int wsu_convt2x2_bwd_weight(const float* x, const float* dy, float* dw, float* db,
+                            float* workspace, size_t workspace_bytes,
+                            int n, int h, int w, int cin, int cout, void* stream) {
+    WSU_REQUIRE(x && dy && dw && workspace, "convt2x2_bwd_weight: null pointer");
+    WSU_REQUIRE(n > 0 && h > 0 && w > 0, "convt2x2_bwd_weight: bad shape");
+    WSU_REQUIRE(cin > 0 && cin % 64 == 0 && cout > 0 && cout % 64 == 0, "convt2x2_bwd_weight: cin=%d cout=%d must be multiples of 64", cin, cout);
+    WgArgs a{};
+    a.u = x; a.v1 = dy; a.v2 = nullptr; a.n = n; a.hu = h; a.wu = w; a.cu = cin; a.cv1 = cout; a.cv2 = 0;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int rc = run_wgrad<1>(a, dw, nullptr, workspace, workspace_bytes, s);
+    if (rc || !db) return rc;
+    // db[co] = sum over all output pixels of dy (two-stage, fixed order)
+    const long long npix = (long long)n * h * w * 4;
+    const int chunk = 4096;
+    int nchunks = (int)((npix + chunk - 1) / chunk);
+    WSU_REQUIRE((size_t)nchunks * cout * sizeof(float) <= workspace_bytes, "convt2x2_bwd_weight: workspace too small for the bias reduction");
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nchunks, cout / 64), dim3(256), 0, s, dy, workspace, npix, cout, chunk);
+    rc = wsu_check_launch("colsum_partial_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((cout + 63) / 64), dim3(64), 0, s, workspace, db, nchunks, cout);
+    return wsu_check_launch("colsum_final_kernel");
+}
+
+}  // extern "C"

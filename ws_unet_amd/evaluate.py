@@ -1,0 +1,183 @@
+"""Predictor / evaluate API of the reference (src/unet/evaluate.py:31-188) on the MI355X model.
+
+Kept verbatim in name, arguments and result layout: `infere_single`, `get_model_name`, `predict_unet`,
+`predict_unet_cover`, `predict_unet_stego`, `get_model_config`, `get_pretrained`.  Differences that a
+drop-in user should know:
+  * the model runs on the GPU; the `device` arguments are accepted for signature compatibility but the
+    model's own device is used (there is no CPU path -- the reference hard-wires CPU, evaluate.py:27);
+  * `infere_single` runs without building an autograd graph (the reference forgets no_grad, :48);
+  * additions: `predict_unet_batch` + `predict_unet_cover_batched` / `predict_unet_stego_batched` evaluate
+    whole batches on the device and bring back 8 bytes per image (WS statistic fused in
+    wsu_ws_residual_stats), with the same rows / columns / order as the per-image functions.
+"""
+from __future__ import annotations
+
+import glob
+import json
+import logging
+import pathlib
+import typing
+from pathlib import Path
+
+import numpy as np
+import pandas as pd
+import torch
+
+from . import fabrika, ops
+from .data import get_timm_transform
+from .imread import imread4_f32, imread4_u8
+from .model import get_model
+
+DEVICE = torch.device("cuda")
+
+
+def _model_device(model) -> torch.device:
+    try:
+        return next(model.parameters()).device
+    except (StopIteration, AttributeError):
+        return DEVICE
+
+
+def infere_single(
+    x: np.ndarray,
+    model: typing.Callable,
+    device=None,
+) -> np.ndarray:
+    """(H,W,1) float32 in 0..255  ->  (510,510,1) float32 prediction in 0..255 (evaluate.py:31-52)."""
+    transform = get_timm_transform(
+        mean=None, std=None, grayscale=True, demosaic_oracle=False, post_flip=False, post_rotate=False,
+    )
+    x_ = transform(x / 255.)[None].to(_model_device(model))
+    with torch.no_grad():
+        y_ = model(x_)
+    y = y_.detach().cpu().numpy()[0, 0, 1:-1, 1:-1] * 255.
+    return y[..., None]
+
+
+def get_model_name(
+    stego_method: str = "LSBR",
+    model_dir: pathlib.Path = pathlib.Path("../models/unet"),
+    device=None,
+) -> str:
+    """The single non-debug run under <model_dir>/<stego_method>/ whose config names `stego_method` and whose
+    best checkpoint exists (evaluate.py:55-105).  RuntimeError unless exactly one matches."""
+    found = []
+    for cfg_file in map(pathlib.Path, glob.glob(str(pathlib.Path(model_dir) / stego_method / "*" / "config.json"))):
+        run = cfg_file.parent.name
+        with open(cfg_file) as f:
+            config = json.load(f)
+        try:
+            ckpt = torch.load(cfg_file.parent / "model" / "best_model.pt.tar", map_location="cpu", weights_only=True)
+        except FileNotFoundError:
+            logging.warning(f"no model found for {run}, skipped")
+            continue
+        if config.get("debug", False):
+            logging.warning(f"debug model {run} skipped")
+            continue
+        alpha = float(config["alpha"]) if config["alpha"] else config["alpha"]
+        found.append({
+            "model_name": run, "stego_method": config["stego_method"], "alpha": alpha, "loss": config["loss"],
+            "network": config["network"], "drop_rate": config["drop_rate"], "epochs": ckpt["epoch"],
+        })
+    df = pd.DataFrame(found)
+    if len(df):
+        df = df[df.stego_method == stego_method]
+    if len(df) < 1:
+        raise RuntimeError(f"no model for {stego_method=} found")
+    if len(df) > 1:
+        raise RuntimeError(f"multiple models for {stego_method=} found")
+    return df["model_name"].iloc[0]
+
+
+def predict_unet(
+    fname: str,
+    model: torch.nn.Module,
+    *,
+    device=None,
+    imread: typing.Callable = imread4_f32,
+    **kw,
+):
+    """Per-image WS estimate and MAE exactly as the reference computes them on the host (evaluate.py:109-139)."""
+    x = imread(fname)[..., 3:]
+    x_hat = infere_single(x, model=model, device=device)
+    x = x[1:-1, 1:-1]
+    x_bar = (x.astype("uint8") ^ 1).astype("float32")          # integer LSB flip
+    beta_hat = np.mean((x - x_bar) * (x - x_hat))
+    l1_hat = np.mean(np.abs(x - x_hat))
+    return {**kw, "beta_hat": beta_hat, "l1": l1_hat}
+
+
+@fabrika.precovers(iterator="python", convert_to="pandas", ignore_missing=False, n_jobs=-1)
+def predict_unet_cover(*args, **kw):
+    return predict_unet(*args, **kw)
+
+
+@fabrika.stego_spatial(iterator="python", convert_to="pandas", ignore_missing=False, n_jobs=-1)
+def predict_unet_stego(*args, **kw):
+    return predict_unet(*args, **kw)
+
+
+# ---- batched device path ------------------------------------------------------------------------------
+
+def predict_u8_batch(x_u8: torch.Tensor, model: torch.nn.Module):
+    """x_u8: (N,H,W) uint8 on the model's device -> (beta_hat[N], l1[N]) fp32 device tensors.
+    u8 -> /255 (wsu_u8_to_unit_f32) -> UNet forward -> WS residual statistics (wsu_ws_residual_stats)."""
+    x01 = ops.u8_to_unit(x_u8)[:, None]
+    with torch.no_grad():
+        y = model(x01)
+    return ops.ws_residual_stats(x_u8, y[:, 0].contiguous())
+
+
+def predict_unet_batch(fnames, kws, *, model: torch.nn.Module, imread: typing.Callable = imread4_u8, device=None, **_ignored):
+    """Batched predict_unet for `fabrika` iterator='batched': one result dict per (fname, kw)."""
+    imgs = [np.ascontiguousarray(imread(f)[..., 3]) for f in fnames]
+    shapes = {im.shape for im in imgs}
+    if shapes != {(512, 512)}:
+        # CenterCrop(512) would change the geometry; only the per-image path defines what happens then
+        return [predict_unet(f, model, imread=imread4_f32, **kw) for f, kw in zip(fnames, kws)]
+    dev = _model_device(model)
+    x_u8 = torch.from_numpy(np.stack(imgs)).to(dev, non_blocking=True)
+    beta, l1 = predict_u8_batch(x_u8, model)
+    beta, l1 = beta.cpu().numpy(), l1.cpu().numpy()
+    return [{**kw, "beta_hat": beta[i], "l1": l1[i]} for i, kw in enumerate(kws)]
+
+
+def _drop_model_kw(fn):
+    def wrapped(fnames, kws):
+        model = kws[0]["model"]
+        extra = {k: kws[0][k] for k in ("imread",) if k in kws[0]}
+        clean = [{k: v for k, v in kw.items() if k not in ("model", "imread", "device")} for kw in kws]
+        return fn(fnames, clean, model=model, **extra)
+    return wrapped
+
+
+predict_unet_cover_batched = fabrika.precovers(iterator="batched", convert_to="pandas", ignore_missing=False)(
+    _drop_model_kw(predict_unet_batch))
+predict_unet_stego_batched = fabrika.stego_spatial(iterator="batched", convert_to="pandas", ignore_missing=False)(
+    _drop_model_kw(predict_unet_batch))
+
+
+def get_model_config(model_dir: pathlib.Path, stego_method: str, model_name: str) -> typing.Dict[str, typing.Any]:
+    with open(pathlib.Path(model_dir) / stego_method / model_name / "config.json") as f:
+        return json.load(f)
+
+
+def get_pretrained(
+    model_path,
+    channels,
+    *,
+    model_name: str = None,
+    device=None,
+    mode: str = None,
+):
+    """Build the network named in <model_path>/<model_name>/config.json and load model/best_model.pt.tar
+    (evaluate.py:162-188).  `channels` is accepted and ignored like in the reference."""
+    model_path = Path(model_path)
+    with open(model_path / model_name / "config.json") as f:
+        config = json.load(f)
+    dev = torch.device(device) if device is not None and torch.device(device).type == "cuda" else DEVICE
+    model = get_model(config["network"], in_channels=1, out_channels=1, channel=[0], drop_rate=0., mode=mode).to(dev)
+    checkpoint = torch.load(model_path / model_name / "model" / "best_model.pt.tar", map_location=dev, weights_only=True)
+    model.load_state_dict(checkpoint["state_dict"])
+    logging.info(f"model {model_name} loaded")
+    return model

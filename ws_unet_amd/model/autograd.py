@@ -1,0 +1,113 @@
+"""Training path of the UNet: one torch.autograd.Function whose forward and backward are libwsu kernels.
+
+The reference has no hand-written backward -- it relies on autograd through
+src/unet/model/unet.py:137-189.  Here the whole network is ONE autograd node: forward saves the NHWC
+activations (and 2-bit pool argmax), backward walks the layers in reverse calling the K7 kernels
+(include/wsu.h).  All activations stay fp32; `model.train_mode` picks the arithmetic of the forward /
+data-gradient GEMMs ('f32' exact, default, or 'bf16x3'); weight gradients are always exact fp32 MFMA.
+
+Conventions inside backward: `g` is the PRE-activation gradient of the layer being processed; every kernel
+that produces the gradient w.r.t. a post-ReLU activation applies that activation's ReLU mask itself
+(relu'(0) = 0 as in PyTorch), so `g` can be fed straight to the next weight / data gradient.
+"""
+from __future__ import annotations
+
+from typing import Dict, List
+
+import torch
+
+from .. import ops
+from .unet import ENC, dec_names
+
+
+def _param_list(model) -> List[torch.nn.Parameter]:
+    return [p for _, p in model.named_parameters()]
+
+
+def _forward_train(model, x: torch.Tensor, m: int) -> Dict[str, torch.Tensor]:
+    """Same dataflow as UNet.forward_features, keeping what backward needs."""
+    t: Dict[str, torch.Tensor] = {}
+    e11 = model.e11
+    cur = t["xe11"] = ops.conv3x3_first(x, e11.weight.detach(), e11.bias.detach(), m, relu=True)
+    for lvl in range(model.nsteps + 1):
+        a, b = ENC[lvl]
+        if lvl >= 1:
+            la = getattr(model, a)
+            cur = t["x" + a] = ops.conv3x3(cur, None, model._packed(a, m, "conv"), la.bias.detach(), la.out_channels, m)
+        lb = getattr(model, b)
+        if lvl < model.nsteps:
+            full, cur, idx = ops.conv3x3(cur, None, model._packed(b, m, "conv"), lb.bias.detach(), lb.out_channels, m,
+                                         pool=True, pool_idx=True)
+            t["x" + b], t[f"xp{lvl + 1}"], t[f"idx{lvl + 1}"] = full, cur, idx
+        else:
+            cur = t["x" + b] = ops.conv3x3(cur, None, model._packed(b, m, "conv"), lb.bias.detach(), lb.out_channels, m)
+    for depth in range(model.nsteps, 0, -1):
+        up, c1, c2 = dec_names(depth)
+        lu, l1, l2 = getattr(model, up), getattr(model, c1), getattr(model, c2)
+        xu = t["xu" + up[-1]] = ops.convt2x2(cur, model._packed(up, m, "convt"), lu.bias.detach(), lu.out_channels, m)
+        skip = t["x" + ENC[depth - 1][1]]
+        cur = t["x" + c1] = ops.conv3x3(xu, skip, model._packed(c1, m, "conv"), l1.bias.detach(), l1.out_channels, m)
+        cur = t["x" + c2] = ops.conv3x3(cur, None, model._packed(c2, m, "conv"), l2.bias.detach(), l2.out_channels, m)
+    t["last"] = cur
+    t["out"] = ops.conv1x1_sigmoid(cur, model.outconv.weight.detach(), model.outconv.bias.detach(), m)
+    return t
+
+
+class _UNetFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, x, *params):
+        if x.requires_grad:
+            raise NotImplementedError("gradient w.r.t. the network input (saliency, src/saliency.py:159-174) is a "
+                                      "'next' item (SURVEY.md 8f-3); only parameter gradients are implemented")
+        m = ops.mode_id(getattr(model, "train_mode", "f32"))
+        if m == ops.MODE_BF16:
+            raise ValueError("train_mode must be 'f32' or 'bf16x3' (activations are kept in fp32 for the backward pass)")
+        t = _forward_train(model, x, m)
+        ctx.model, ctx.t, ctx.x, ctx.m = model, t, x, m
+        return t["out"]
+
+    @staticmethod
+    def backward(ctx, dout):
+        model, t, x, m = ctx.model, ctx.t, ctx.x, ctx.m
+        grads: Dict[str, torch.Tensor] = {}
+        dout = dout.contiguous().float()
+
+        def conv_bwd(name, g, x1, x2, mask1, mask2, need_dx=True):
+            layer = getattr(model, name)
+            grads[name + ".weight"], grads[name + ".bias"] = ops.conv3x3_bwd_weight(g, x1, x2)
+            if not need_dx:
+                return None, None
+            csplit = x1.shape[3]
+            return ops.conv3x3_bwd_data(g, model._packed(name, m, "dgrad"), layer.weight, csplit, mask1, mask2, m)
+
+        g, grads["outconv.weight"], grads["outconv.bias"] = ops.conv1x1_sigmoid_bwd(t["last"], model.outconv.weight, t["out"], dout)
+        skip_g: Dict[int, torch.Tensor] = {}
+        for depth in range(1, model.nsteps + 1):
+            up, c1, c2 = dec_names(depth)
+            xc1, xu, skip = t["x" + c1], t["xu" + up[-1]], t["x" + ENC[depth - 1][1]]
+            g, _ = conv_bwd(c2, g, xc1, None, xc1, None)                        # -> pre-activation grad of c1
+            dxu, skip_g[depth] = conv_bwd(c1, g, xu, skip, None, skip)           # upconv output has no ReLU; skip is masked
+            below = t["x" + (dec_names(depth + 1)[2] if depth < model.nsteps else ENC[model.nsteps][1])]
+            lu = getattr(model, up)
+            grads[up + ".weight"], grads[up + ".bias"] = ops.convt2x2_bwd_weight(below, dxu)
+            g = ops.convt2x2_bwd_data(dxu, model._packed(up, m, "convt_dgrad"), lu.in_channels, below, m)
+        for lvl in range(model.nsteps, -1, -1):
+            a, b = ENC[lvl]
+            if lvl < model.nsteps:
+                # g is the gradient w.r.t. the pooled tensor xp{lvl+1}; route it onto the argmax and add the skip path
+                g = ops.maxpool2x2_bwd(skip_g[lvl + 1], g, t[f"idx{lvl + 1}"], t[f"xp{lvl + 1}"])
+            xa = t["x" + a]
+            g, _ = conv_bwd(b, g, xa, None, xa, None)                            # -> pre-activation grad of conv a
+            if lvl == 0:
+                grads[a + ".weight"], grads[a + ".bias"] = ops.conv3x3_first_bwd_weight(g, x)
+            else:
+                g, _ = conv_bwd(a, g, t[f"xp{lvl}"], None, None, None)           # pooled tensor: no ReLU of its own
+        ctx.t = None
+        out = [None, None]
+        for name, p in model.named_parameters():
+            out.append(grads[name] if p.requires_grad else None)
+        return tuple(out)
+
+
+def unet_apply(model, x: torch.Tensor) -> torch.Tensor:
+    return _UNetFn.apply(model, x, *_param_list(model))

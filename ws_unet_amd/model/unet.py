@@ -75,6 +75,7 @@ class UNet(nn.Module):
             raise NotImplementedError("the reference defines at most 4 pooling steps (unet.py:85-132)")
         self.nsteps = nsteps
         self.mode = mode or os.environ.get("WSU_MODE", "bf16x3")
+        self.train_mode = os.environ.get("WSU_TRAIN_MODE", "f32")      # arithmetic of the autograd path ('f32' | 'bf16x3')
         ops.mode_id(self.mode)                                    # validate early
         conv_kw = {"kernel_size": 3, "padding": 1, "padding_mode": "reflect"}
         ups_kw = {"kernel_size": 2, "stride": 2}
@@ -114,6 +115,8 @@ class UNet(nn.Module):
             packed = ops.pack_conv3x3(p, mode)
         elif kind == "dgrad":
             packed = ops.pack_conv3x3(p, mode, dgrad=True)
+        elif kind == "convt_dgrad":
+            packed = ops.pack_convt2x2_dgrad(p, mode)
         else:
             packed = ops.pack_convt2x2(p, mode)
         self._pack_cache[key] = (tag, packed)

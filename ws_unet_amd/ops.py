@@ -229,3 +229,184 @@ def u8_to_unit(x_u8: torch.Tensor) -> torch.Tensor:
     y = torch.empty(x_u8.shape, dtype=torch.float32, device=x_u8.device)
     check(lib.wsu_u8_to_unit_f32(x_u8.data_ptr(), y.data_ptr(), x_u8.numel(), _stream()), "wsu_u8_to_unit_f32")
     return y
+
+
+# ---- backward ops (fp32 storage; g = pre-activation gradient, NHWC) -------------------------------------
+
+_ws_cache = {}
+
+
+def workspace(nbytes: int, device) -> torch.Tensor:
+    """Grow-only scratch buffer per device (fp32 view), reused by all backward reductions on the stream."""
+    key = str(device)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() * 4 < nbytes:
+        buf = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def pack_convt2x2_dgrad(w: torch.Tensor, mode: int) -> torch.Tensor:
+    lib = _lib.load()
+    w = w.detach()
+    _dev_check(w)
+    cin, cout = w.shape[:2]
+    out = torch.empty(lib.wsu_convt2x2_packed_dgrad_bytes(cin, cout, mode), dtype=torch.uint8, device=w.device)
+    check(lib.wsu_convt2x2_pack_dgrad(w.data_ptr(), out.data_ptr(), cin, cout, mode, _stream()), "wsu_convt2x2_pack_dgrad")
+    return out
+
+
+def conv3x3_bwd_data(g: torch.Tensor, w_packed_dgrad: torch.Tensor, w_oihw: torch.Tensor, csplit: int,
+                     mask1: Optional[torch.Tensor], mask2: Optional[torch.Tensor], mode: int):
+    """Returns dx1 (N,H,W,csplit) and dx2 (N,H,W,cin-csplit) or None."""
+    lib = _lib.load()
+    w_oihw = w_oihw.detach()
+    _dev_check(g, w_packed_dgrad, w_oihw, mask1, mask2)
+    n, h, w, cout = g.shape
+    cin = w_oihw.shape[1]
+    assert g.dtype == torch.float32 and w_oihw.shape[0] == cout
+    dx1 = torch.empty((n, h, w, csplit), dtype=torch.float32, device=g.device)
+    dx2 = torch.empty((n, h, w, cin - csplit), dtype=torch.float32, device=g.device) if csplit < cin else None
+    meta = {"flops": 2.0 * 9 * cin * cout * n * h * w}
+    check(_launch("conv3x3_bwd_data", meta, lambda: lib.wsu_conv3x3_bwd_data(
+        g.data_ptr(), w_packed_dgrad.data_ptr(), w_oihw.data_ptr(), dx1.data_ptr(), _ptr(dx2), csplit, _ptr(mask1), _ptr(mask2),
+        n, h, w, cin, cout, mode, _stream())), "wsu_conv3x3_bwd_data")
+    return dx1, dx2
+
+
+def conv3x3_bwd_weight(g: torch.Tensor, x1: torch.Tensor, x2: Optional[torch.Tensor], want_bias: bool = True):
+    lib = _lib.load()
+    _dev_check(g, x1, x2)
+    n, h, w, cout = g.shape
+    c1 = x1.shape[3]
+    c2 = 0 if x2 is None else x2.shape[3]
+    dw = torch.empty((cout, c1 + c2, 3, 3), dtype=torch.float32, device=g.device)
+    db = torch.empty(cout, dtype=torch.float32, device=g.device) if want_bias else None
+    nbytes = lib.wsu_wgrad_workspace_bytes(cout, c1 + c2, 9)
+    ws = workspace(nbytes, g.device)
+    meta = {"flops": 2.0 * 9 * (c1 + c2) * cout * n * h * w}
+    check(_launch("conv3x3_bwd_weight", meta, lambda: lib.wsu_conv3x3_bwd_weight(
+        g.data_ptr(), x1.data_ptr(), _ptr(x2), dw.data_ptr(), _ptr(db), ws.data_ptr(), ws.numel() * 4,
+        n, h, w, c1, c2, cout, _stream())), "wsu_conv3x3_bwd_weight")
+    return dw, db
+
+
+def conv3x3_first_bwd_weight(g: torch.Tensor, x_nchw: torch.Tensor, want_bias: bool = True):
+    lib = _lib.load()
+    _dev_check(g, x_nchw)
+    n, h, w, cout = g.shape
+    cin = x_nchw.shape[1]
+    dw = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=g.device)
+    db = torch.empty(cout, dtype=torch.float32, device=g.device) if want_bias else None
+    ws = workspace(lib.wsu_first_bwd_workspace_bytes(n, h, w, cin, cout), g.device)
+    check(_launch("conv3x3_first_bwd_weight", {}, lambda: lib.wsu_conv3x3_first_bwd_weight(
+        g.data_ptr(), x_nchw.data_ptr(), dw.data_ptr(), _ptr(db), ws.data_ptr(), ws.numel() * 4, n, h, w, cin, cout, _stream())),
+        "wsu_conv3x3_first_bwd_weight")
+    return dw, db
+
+
+def convt2x2_bwd_weight(x: torch.Tensor, dy: torch.Tensor, want_bias: bool = True):
+    lib = _lib.load()
+    _dev_check(x, dy)
+    n, h, w, cin = x.shape
+    cout = dy.shape[3]
+    assert dy.shape == (n, 2 * h, 2 * w, cout)
+    dw = torch.empty((cin, cout, 2, 2), dtype=torch.float32, device=x.device)
+    db = torch.empty(cout, dtype=torch.float32, device=x.device) if want_bias else None
+    nbytes = max(lib.wsu_wgrad_workspace_bytes(cin, cout, 4), (n * h * w * 4 + 4095) // 4096 * cout * 4)
+    ws = workspace(nbytes, x.device)
+    meta = {"flops": 2.0 * 4 * cin * cout * n * h * w}
+    check(_launch("convt2x2_bwd_weight", meta, lambda: lib.wsu_convt2x2_bwd_weight(
+        x.data_ptr(), dy.data_ptr(), dw.data_ptr(), _ptr(db), ws.data_ptr(), ws.numel() * 4, n, h, w, cin, cout, _stream())),
+        "wsu_convt2x2_bwd_weight")
+    return dw, db
+
+
+def convt2x2_bwd_data(dy: torch.Tensor, w_packed_dgrad: torch.Tensor, cin: int, mask: Optional[torch.Tensor], mode: int) -> torch.Tensor:
+    lib = _lib.load()
+    _dev_check(dy, w_packed_dgrad, mask)
+    n, oh, ow, cout = dy.shape
+    h, w = oh // 2, ow // 2
+    dx = torch.empty((n, h, w, cin), dtype=torch.float32, device=dy.device)
+    meta = {"flops": 2.0 * 4 * cin * cout * n * h * w}
+    check(_launch("convt2x2_bwd_data", meta, lambda: lib.wsu_convt2x2_bwd_data(
+        dy.data_ptr(), w_packed_dgrad.data_ptr(), dx.data_ptr(), _ptr(mask), n, h, w, cin, cout, mode, _stream())),
+        "wsu_convt2x2_bwd_data")
+    return dx
+
+
+def maxpool2x2_bwd(g_full: Optional[torch.Tensor], dy_pool: torch.Tensor, idx: torch.Tensor, xp_mask: Optional[torch.Tensor]) -> torch.Tensor:
+    """Adds the routed pooled gradient into ``g_full`` (allocated zero-initialised when None)."""
+    lib = _lib.load()
+    _dev_check(g_full, dy_pool, idx, xp_mask)
+    n, hp, wp, c = dy_pool.shape
+    accumulate = g_full is not None
+    if g_full is None:
+        g_full = torch.empty((n, 2 * hp, 2 * wp, c), dtype=torch.float32, device=dy_pool.device)
+    h, w = g_full.shape[1:3]
+    check(_launch("maxpool2x2_bwd", {}, lambda: lib.wsu_maxpool2x2_bwd(
+        g_full.data_ptr(), dy_pool.data_ptr(), idx.data_ptr(), _ptr(xp_mask), n, h, w, c, int(accumulate), _stream())),
+        "wsu_maxpool2x2_bwd")
+    return g_full
+
+
+def conv1x1_sigmoid_bwd(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, dout: torch.Tensor, relu_mask: bool = True):
+    """x: (N,H,W,C) saved input of the head; out/dout: (N,cout,H,W).  Returns gx (N,H,W,C), dw (cout,C,1,1), db (cout)."""
+    lib = _lib.load()
+    w2 = w.detach().reshape(w.shape[0], -1)
+    _dev_check(x, w2, out, dout)
+    n, h, wd, c = x.shape
+    cout = w2.shape[0]
+    gx = torch.empty_like(x)
+    dw = torch.empty((cout, c, 1, 1), dtype=torch.float32, device=x.device)
+    db = torch.empty(cout, dtype=torch.float32, device=x.device)
+    ws = workspace(lib.wsu_head_bwd_workspace_bytes(c, cout), x.device)
+    check(_launch("conv1x1_sigmoid_bwd", {}, lambda: lib.wsu_conv1x1_sigmoid_bwd(
+        x.data_ptr(), w2.data_ptr(), out.data_ptr(), dout.data_ptr(), gx.data_ptr(), dw.data_ptr(), db.data_ptr(),
+        ws.data_ptr(), ws.numel() * 4, n, h, wd, c, cout, int(relu_mask), _stream())), "wsu_conv1x1_sigmoid_bwd")
+    return gx, dw, db
+
+
+def l1ws_loss_fwd_bwd(out: torch.Tensor, covers: torch.Tensor, inputs: torch.Tensor, alphas: torch.Tensor,
+                      use_l1: bool = True, use_ws: bool = True):
+    """Returns (loss scalar tensor, dLoss/dout, parts[l1, ws], beta_hat[N])."""
+    lib = _lib.load()
+    _dev_check(out, covers, inputs, alphas)
+    assert out.shape == covers.shape == inputs.shape and out.dtype == torch.float32
+    n = out.shape[0]
+    per = out.numel() // n
+    loss = torch.empty((), dtype=torch.float32, device=out.device)
+    parts = torch.empty(2, dtype=torch.float32, device=out.device)
+    beta = torch.empty(n, dtype=torch.float32, device=out.device)
+    dout = torch.empty_like(out)
+    ws = torch.empty((lib.wsu_l1ws_loss_workspace_bytes(n) + 7) // 8, dtype=torch.float64, device=out.device)
+    alphas = alphas.to(torch.float32).contiguous()
+    check(lib.wsu_l1ws_loss_fwd_bwd(out.data_ptr(), covers.data_ptr(), inputs.data_ptr(), alphas.data_ptr(), loss.data_ptr(),
+                                    parts.data_ptr(), dout.data_ptr(), beta.data_ptr(), ws.data_ptr(), ws.numel() * 8,
+                                    n, per, int(use_l1), int(use_ws), _stream()), "wsu_l1ws_loss_fwd_bwd")
+    return loss, dout, parts, beta
+
+
+class AdamWTable:
+    """Device-side descriptor table for wsu_adamw_multi_tensor over a fixed list of (param, grad, m, v)."""
+
+    def __init__(self, params, grads, exp_avg, exp_avg_sq):
+        import numpy as np
+        rows, first = [], 0
+        for p, g, m, v in zip(params, grads, exp_avg, exp_avg_sq):
+            _dev_check(p, g, m, v)
+            assert p.dtype == g.dtype == m.dtype == v.dtype == torch.float32 and p.numel() == g.numel()
+            rows.append([p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), first])
+            first += (p.numel() + 1023) // 1024
+        self.total_blocks = first
+        self.ntensors = len(rows)
+        self.table = torch.from_numpy(np.array(rows, dtype=np.int64)).to(params[0].device)
+        self.ptrs = [r[:4] for r in rows]
+
+    def matches(self, params, grads):
+        return all(p.data_ptr() == r[0] and g.data_ptr() == r[1] for p, g, r in zip(params, grads, self.ptrs))
+
+    def step(self, step: int, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, grad_scale=1.0):
+        lib = _lib.load()
+        check(lib.wsu_adamw_multi_tensor(self.table.data_ptr(), self.ntensors, self.total_blocks, lr, betas[0], betas[1],
+                                         eps, weight_decay, step, grad_scale, _stream()), "wsu_adamw_multi_tensor")

@@ -1,0 +1,190 @@
+"""Reconstructed UNet train step and epoch loop (the reference publishes none: SURVEY.md F2 / 3.4).
+
+Pattern taken from the detector's loop (src/detector/train.py:55-95 train_one_epoch, :228 AdamW(params, lr),
+:281-304 checkpoint / best copy / patience) with the UNet-specific pieces: criterion(outputs, (covers, alphas),
+inputs) from src/_defs/losses.py, meters MAEMeter / WSMeter (src/_defs/metrics.py:64-142), scalar tags
+train|val/{loss, mae, ws}, run naming src/_defs/defs.py:47-74, config.json schema of models/unet/*/.
+
+One step = zero_grad -> forward -> loss -> backward -> [sum all-reduce of the flat gradient bucket] -> AdamW.
+Every stage is a libwsu kernel; parameters, gradients and AdamW moments live in three flat fp32 buffers
+(parameters are views into the first), so the optimiser is ONE kernel launch and DP needs ONE collective.
+"""
+from __future__ import annotations
+
+import json
+import shutil
+import time
+from pathlib import Path
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import losses, metrics, ops, parallel
+
+
+def create_run_name(args: Dict) -> str:
+    """Run-directory suffix, same composition rules as src/_defs/defs.py:47-74."""
+    parts = [str(args["network"])]
+    if args.get("no_stem_stride"):
+        parts[0] += "-nostride"
+    name = parts[0] + "-"
+    if args.get("alpha"):
+        name += f"alpha_{args['alpha']}_"
+    name += "grayscale_" if args.get("grayscale") else "color_" + "".join(map(str, args.get("channel", [])))
+    if args.get("demosaic"):
+        name += "_".join(args["demosaic"]) + "_"
+    if args.get("demosaic_oracle"):
+        name += "oracle_"
+    if args.get("loss"):
+        name += args["loss"] + "_"
+        if args["loss"] == "l1ws":
+            name += f"{args['loss_lambda']:.02f}_"
+    if args.get("learning_rate"):
+        name += f"lr_{args['learning_rate']}_"
+    if args.get("drop_rate"):
+        name += f"dr_{args['drop_rate']}"
+    return name
+
+
+class FlatAdamW:
+    """AdamW over one flat parameter buffer (defaults of torch.optim.AdamW: betas (.9,.999), eps 1e-8, wd 1e-2)."""
+
+    def __init__(self, model: torch.nn.Module, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2):
+        self.model, self.lr, self.betas, self.eps, self.weight_decay = model, lr, betas, eps, weight_decay
+        params = [p for p in model.parameters() if p.requires_grad]
+        dev = params[0].device
+        n = sum(p.numel() for p in params)
+        self.flat_param = torch.empty(n, dtype=torch.float32, device=dev)
+        self.flat_grad = torch.zeros(n, dtype=torch.float32, device=dev)
+        off = 0
+        for p in params:
+            k = p.numel()
+            self.flat_param[off:off + k].copy_(p.data.reshape(-1))
+            p.data = self.flat_param[off:off + k].view(p.shape)          # parameters become views of the flat buffer
+            p.grad = self.flat_grad[off:off + k].view(p.shape)           # autograd accumulates into the flat bucket
+            off += k
+        self.params = params
+        self.exp_avg = torch.zeros_like(self.flat_param)
+        self.exp_avg_sq = torch.zeros_like(self.flat_param)
+        self.step_count = 0
+        self._table = ops.AdamWTable([self.flat_param], [self.flat_grad], [self.exp_avg], [self.exp_avg_sq])
+        if hasattr(model, "invalidate_packed"):
+            model.invalidate_packed()
+
+    def zero_grad(self):
+        self.flat_grad.zero_()
+        off = 0
+        for p in self.params:                                           # re-attach views if something replaced .grad
+            k = p.numel()
+            if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + off * 4:
+                p.grad = self.flat_grad[off:off + k].view(p.shape)
+            off += k
+
+    def step(self, grad_scale: float = 1.0):
+        self.step_count += 1
+        self._table.step(self.step_count, self.lr, self.betas, self.eps, self.weight_decay, grad_scale)
+        if hasattr(self.model, "invalidate_packed"):
+            self.model.invalidate_packed()                               # flat update bypasses tensor version counters
+
+    def state_dict(self):
+        return {"step": self.step_count, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq,
+                "lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": self.weight_decay}
+
+    def load_state_dict(self, sd):
+        self.step_count = int(sd["step"])
+        self.exp_avg.copy_(sd["exp_avg"])
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+
+
+class Trainer:
+    def __init__(self, model: torch.nn.Module, loss: str = "l1ws", lr: float = 1e-4, out_dir: Optional[Path] = None,
+                 config: Optional[Dict] = None, patience: int = 10):
+        self.model = model
+        self.criterion = losses.get_loss(loss)
+        self.opt = FlatAdamW(model, lr)
+        self.rank, self.world = parallel.world_info()
+        parallel.broadcast_parameters(model)                             # identical replicas before the first step
+        self.out_dir = Path(out_dir) if out_dir else None
+        self.config = dict(config or {})
+        self.patience0 = self.patience = patience
+        self.best_val_loss = np.inf
+        self.scalars = []                                                # (epoch, tag, value) rows, tags as in the tfevents
+        if self.out_dir and self.rank == 0:
+            (self.out_dir / "model").mkdir(parents=True, exist_ok=True)
+            (self.out_dir / "log").mkdir(parents=True, exist_ok=True)
+            with open(self.out_dir / "config.json", "w") as f:
+                json.dump(self.config, f, indent=4, sort_keys=True)
+
+    # ---- one optimisation step on this rank's shard of the global batch --------------------------------
+    def train_step(self, inputs: torch.Tensor, covers: torch.Tensor, alphas: torch.Tensor):
+        self.opt.zero_grad()
+        outputs = self.model(inputs)
+        loss = self.criterion(outputs, (covers, alphas), inputs)
+        loss.backward()
+        scale = parallel.allreduce_flat_(self.opt.flat_grad)             # C1: one 7.45 MB fp32 bucket over xGMI
+        self.opt.step(grad_scale=scale)
+        return loss.detach(), outputs.detach()
+
+    @torch.no_grad()
+    def eval_step(self, inputs, covers, alphas):
+        outputs = self.model(inputs)
+        loss, _, parts, _ = ops.l1ws_loss_fwd_bwd(outputs, covers.contiguous(), inputs.contiguous(),
+                                                   torch.as_tensor(alphas, dtype=torch.float32, device=outputs.device),
+                                                   self.criterion.use_l1, self.criterion.use_ws)
+        return loss, outputs
+
+    def _run_epoch(self, loader, train: bool, epoch: int):
+        lm, mae, ws = metrics.LossMeter(), metrics.MAEMeter(multiplier=1), metrics.WSMeter()
+        for inputs, (covers, alphas) in loader:
+            dev = next(self.model.parameters()).device
+            inputs, covers = inputs.to(dev), covers.to(dev)
+            alphas = torch.as_tensor(alphas, dtype=torch.float32, device=dev)
+            loss, outputs = (self.train_step if train else self.eval_step)(inputs.clone(), covers, alphas)
+            lm.update(loss.item(), inputs.shape[0])
+            o = outputs.cpu().numpy()
+            mae.update(covers.cpu().numpy(), o)
+            ws.update(inputs.cpu().numpy(), o, alphas.cpu().numpy())
+        prefix = "train/" if train else "val/"
+        for meter in (lm, mae, ws):
+            self.scalars.append((epoch, prefix + meter.name, float(meter.avg)))
+        return lm.avg
+
+    def save_checkpoint(self, epoch: int, val_loss: float):
+        """Checkpoint dict keys and files as src/detector/train.py:281-296 writes them."""
+        if not self.out_dir or self.rank != 0:
+            return
+        latest = self.out_dir / "model" / "latest_model.pt.tar"
+        torch.save({
+            "epoch": epoch,
+            "state_dict": {k: v.detach().clone() for k, v in self.model.state_dict().items()},
+            "best_val_loss": self.best_val_loss,
+            "patience": self.patience,
+            "optimizer": self.opt.state_dict(),
+            "scheduler": None,
+        }, latest)
+        if val_loss < self.best_val_loss:
+            shutil.copyfile(latest, self.out_dir / "model" / "best_model.pt.tar")
+        with open(self.out_dir / "log" / "scalars.csv", "w") as f:
+            f.write("epoch,tag,value\n" + "".join(f"{e},{t},{v}\n" for e, t, v in self.scalars))
+
+    def fit(self, tr_loader, va_loader, num_epochs: int):
+        for epoch in range(num_epochs):
+            self._run_epoch(tr_loader, True, epoch)
+            val_loss = self._run_epoch(va_loader, False, epoch)
+            self.save_checkpoint(epoch, val_loss)
+            if val_loss < self.best_val_loss:
+                self.patience = self.patience0
+                self.best_val_loss = val_loss
+            else:
+                self.patience -= 1
+            if self.patience <= 0:                                       # early stopping, train.py:298-304
+                break
+        return self.best_val_loss
+
+
+def resume(model: torch.nn.Module, run_dir: Path, device) -> int:
+    """Load only the weights of another run's best model (src/detector/train.py:235-249)."""
+    ckpt = torch.load(Path(run_dir) / "model" / "best_model.pt.tar", map_location=device, weights_only=True)
+    model.load_state_dict(ckpt["state_dict"])
+    return int(ckpt["epoch"])
