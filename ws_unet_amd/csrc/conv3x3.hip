@@ -18,6 +18,7 @@
 // The epilogue re-uses the LDS as a [pixel][channel] tile: bias + ReLU (+ReLU-mask for the data-gradient
 // pass), coalesced 16-byte NHWC stores, and the fused 2x2 max-pool with first-max-wins argmax.
 #include "wsu_device.h"
+#include <cstdlib>
 
 namespace {
 
@@ -28,9 +29,19 @@ constexpr int PLANE_IN = NPIX_IN * 16 + 96;              // 5536 B: planes 8 dwo
 constexpr int LDS_IN = WSU_GRAN * PLANE_IN;              // 22144
 constexpr int LDS_W = 9 * WSU_GRAN * WSU_COB * 16;       // 36864
 constexpr int LDS_MAIN = LDS_IN + LDS_W;                 // 59008
-constexpr int NT = 256;
-constexpr int W_VEC = LDS_W / 16 / NT;                   // 9 x 16 B per thread
-constexpr int IN_VEC = 6;                                // ceil(1360 / 256) x 16 B per thread
+constexpr int W_ITEMS = LDS_W / 16;                      // 2304 x 16 B
+constexpr int IN_ITEMS = NPIX_IN * WSU_GRAN;             // 1360 x 16 B (680 x 32 B for BF16X3)
+// Workgroup shapes on the same 8x32-pixel x 64-channel tile:
+//   NW = 4: 256 threads, wave tile 64 co x 64 px (4 MFMA tiles), 2 waves/SIMD
+//   NW = 8: 512 threads, wave tile 32 co x 64 px (2 MFMA tiles), <= 128 VGPRs -> 4 waves/SIMD
+template <int NW> struct Shape {
+    static constexpr int NT = NW * 64;
+    static constexpr int MT = NW == 4 ? 2 : 1;           // 32-channel MFMA row tiles per wave
+    static constexpr int W_VEC = (W_ITEMS + NT - 1) / NT;
+    static constexpr int IN_VEC = (IN_ITEMS + NT - 1) / NT;
+    static constexpr int IN_VEC3 = (NPIX_IN * 2 + NT - 1) / NT;   // BF16X3 items of 32 B
+    static constexpr int ST_IN = IN_VEC > 2 * IN_VEC3 ? IN_VEC : 2 * IN_VEC3;
+};
 
 struct ConvArgs {
     const char* x1; const char* x2; const char* wp; const float* bias;
@@ -38,6 +49,7 @@ struct ConvArgs {
     int n, h, w, c1, c2, cout, csplit;
     int tiles_x, tiles_y, ncb, nch1, nch;
     int relu, pad_zero;
+    int ablate;        // timing-only experiment mask (WSU_CONV_ABLATE), 0 in production
 };
 
 template <int MODE> struct Epi {
@@ -49,12 +61,13 @@ template <int MODE> struct Epi {
 
 
 // Global -> registers for chunk c (input tile items + this workgroup's packed-weight slice).
-template <int MODE>
-__device__ __forceinline__ void stage_load(const ConvArgs& a, int cb, int c, int tid, const int (&pixidx)[IN_VEC],
-                                           u32x4 (&st_in)[IN_VEC], u32x4 (&st_w)[W_VEC]) {
+template <int MODE, int NW>
+__device__ __forceinline__ void stage_load(const ConvArgs& a, int cb, int c, int tid, const int (&pixidx)[Shape<NW>::IN_VEC],
+                                           u32x4 (&st_in)[Shape<NW>::ST_IN], u32x4 (&st_w)[Shape<NW>::W_VEC]) {
+    constexpr int NT = Shape<NW>::NT, W_VEC = Shape<NW>::W_VEC;
     constexpr int ESZ = Epi<MODE>::ESZ;
     constexpr int CK = (MODE == WSU_MODE_BF16) ? 32 : 16;
-    constexpr int NLOOP = (MODE == WSU_MODE_BF16X3) ? 3 : IN_VEC;
+    constexpr int NLOOP = (MODE == WSU_MODE_BF16X3) ? Shape<NW>::IN_VEC3 : Shape<NW>::IN_VEC;
     const char* src; int csrc, ch0;
     if (c < a.nch1) { src = a.x1; csrc = a.c1; ch0 = c * CK; }
     else            { src = a.x2; csrc = a.c2; ch0 = (c - a.nch1) * CK; }
@@ -78,14 +91,16 @@ __device__ __forceinline__ void stage_load(const ConvArgs& a, int cb, int c, int
     }
     const u32x4* wsrc = reinterpret_cast<const u32x4*>(a.wp + ((size_t)cb * a.nch + c) * LDS_W);
 #pragma unroll
-    for (int k = 0; k < W_VEC; ++k) st_w[k] = wsrc[tid + k * NT];
+    for (int k = 0; k < W_VEC; ++k)
+        if (W_ITEMS % NT == 0 || tid + k * NT < W_ITEMS) st_w[k] = wsrc[tid + k * NT];
 }
 
 // Registers -> LDS (granule-planar input tile, linear weight tile); BF16X3 splits fp32 into bf16 hi/lo here.
-template <int MODE>
-__device__ __forceinline__ void stage_commit(char* smem, int tid, const int (&pixidx)[IN_VEC], const int (&ldsoff)[IN_VEC],
-                                             const u32x4 (&st_in)[IN_VEC], const u32x4 (&st_w)[W_VEC]) {
-    constexpr int NLOOP = (MODE == WSU_MODE_BF16X3) ? 3 : IN_VEC;
+template <int MODE, int NW>
+__device__ __forceinline__ void stage_commit(char* smem, int tid, const int (&pixidx)[Shape<NW>::IN_VEC], const int (&ldsoff)[Shape<NW>::IN_VEC],
+                                             const u32x4 (&st_in)[Shape<NW>::ST_IN], const u32x4 (&st_w)[Shape<NW>::W_VEC]) {
+    constexpr int NT = Shape<NW>::NT, W_VEC = Shape<NW>::W_VEC;
+    constexpr int NLOOP = (MODE == WSU_MODE_BF16X3) ? Shape<NW>::IN_VEC3 : Shape<NW>::IN_VEC;
 #pragma unroll
     for (int j = 0; j < NLOOP; ++j) {
         if (pixidx[j] != -2) {
@@ -101,13 +116,15 @@ __device__ __forceinline__ void stage_commit(char* smem, int tid, const int (&pi
     }
     u32x4* wdst = reinterpret_cast<u32x4*>(smem + LDS_IN);
 #pragma unroll
-    for (int k = 0; k < W_VEC; ++k) wdst[tid + k * NT] = st_w[k];
+    for (int k = 0; k < W_VEC; ++k)
+        if (W_ITEMS % NT == 0 || tid + k * NT < W_ITEMS) wdst[tid + k * NT] = st_w[k];
 }
 
-template <int MODE>
-__global__ __launch_bounds__(NT, 2) void conv3x3_kernel(const ConvArgs a) {
+template <int MODE, int NW>
+__global__ __launch_bounds__(NW * 64, NW / 2) void conv3x3_kernel(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int ESZ = Epi<MODE>::ESZ;
+    constexpr int NT = Shape<NW>::NT, MT = Shape<NW>::MT, IN_VEC = Shape<NW>::IN_VEC;
     const int tid = threadIdx.x;
     const unsigned lid = wsu_xcd_remap(blockIdx.x, gridDim.x);
     const int cb = lid % a.ncb;
@@ -121,7 +138,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_kernel(const ConvArgs a) {
     int pixidx[IN_VEC];      // linear pixel index (n*H + y)*W + x of the source, -1 = zero, -2 = no item
     int ldsoff[IN_VEC];
     constexpr int NITEMS = (MODE == WSU_MODE_BF16X3) ? NPIX_IN * 2 : NPIX_IN * 4;
-    constexpr int NLOOP = (MODE == WSU_MODE_BF16X3) ? 3 : IN_VEC;
+    constexpr int NLOOP = (MODE == WSU_MODE_BF16X3) ? Shape<NW>::IN_VEC3 : IN_VEC;
 #pragma unroll
     for (int j = 0; j < NLOOP; ++j) {
         const int i = tid + j * NT;
@@ -140,34 +157,37 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_kernel(const ConvArgs a) {
         ldsoff[j] = sub * PLANE_IN + pix * 16;          // BF16X3: hi plane `sub`, lo plane `2 + sub`
     }
 
-    u32x4 st_in[IN_VEC];
-    u32x4 st_w[W_VEC];
+    u32x4 st_in[Shape<NW>::ST_IN];
+    u32x4 st_w[Shape<NW>::W_VEC];
     // ---- main loop ------------------------------------------------------------------------------------
     const int wv = tid >> 6, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
-    f32x16 acc[2][2];
+    const int rowpair = NW == 4 ? wv : (wv >> 1);                    // output rows 2*rowpair, 2*rowpair + 1
+    const int mbase = NW == 4 ? 0 : (wv & 1) * 32;                   // first output channel of this wave
+    f32x16 acc[MT][2];
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int q = 0; q < 2; ++q)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][q][r] = 0.f;
 
-    const char* ldsA = smem + LDS_IN + l31 * 16;                     // + ((tap*4+g)*64 + mt*32)*16
-    const char* ldsB = smem + ((2 * wv) * IW + l31) * 16;            // + g*PLANE_IN + ((nt+dy)*IW + dx)*16
+    const char* ldsA = smem + LDS_IN + (mbase + l31) * 16;           // + ((tap*4+g)*64 + mt*32)*16
+    const char* ldsB = smem + ((2 * rowpair) * IW + l31) * 16;       // + g*PLANE_IN + ((nt+dy)*IW + dx)*16
 
-    stage_load<MODE>(a, cb, 0, tid, pixidx, st_in, st_w);
+    stage_load<MODE, NW>(a, cb, 0, tid, pixidx, st_in, st_w);
     for (int c = 0; c < a.nch; ++c) {
         __syncthreads();
-        stage_commit<MODE>(smem, tid, pixidx, ldsoff, st_in, st_w);
+        if (!(a.ablate & 2) || c == 0) stage_commit<MODE, NW>(smem, tid, pixidx, ldsoff, st_in, st_w);
         __syncthreads();
-        if (c + 1 < a.nch) stage_load<MODE>(a, cb, c + 1, tid, pixidx, st_in, st_w);
+        if (c + 1 < a.nch && !(a.ablate & 1)) stage_load<MODE, NW>(a, cb, c + 1, tid, pixidx, st_in, st_w);
+        if (a.ablate & 4) continue;                                     // no LDS fragment reads, no MFMA
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int dy = tap / 3, dx = tap % 3;
             if constexpr (MODE == WSU_MODE_BF16X3) {
-                u32x4 ahi[2], alo[2], bhi[2], blo[2];
+                u32x4 ahi[MT], alo[MT], bhi[2], blo[2];
 #pragma unroll
-                for (int m = 0; m < 2; ++m) {
+                for (int m = 0; m < MT; ++m) {
                     ahi[m] = *reinterpret_cast<const u32x4*>(ldsA + ((tap * 4 + hh) * 64 + m * 32) * 16);
                     alo[m] = *reinterpret_cast<const u32x4*>(ldsA + ((tap * 4 + 2 + hh) * 64 + m * 32) * 16);
                 }
@@ -176,27 +196,32 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_kernel(const ConvArgs a) {
                     bhi[q] = *reinterpret_cast<const u32x4*>(ldsB + hh * PLANE_IN + ((q + dy) * IW + dx) * 16);
                     blo[q] = *reinterpret_cast<const u32x4*>(ldsB + (2 + hh) * PLANE_IN + ((q + dy) * IW + dx) * 16);
                 }
+                // term-major: consecutive MFMAs go to different accumulators (same per-accumulator order, so bit-identical)
 #pragma unroll
-                for (int m = 0; m < 2; ++m)
+                for (int m = 0; m < MT; ++m)
 #pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        wsu_mfma_step<MODE>(alo[m], bhi[q], acc[m][q]);     // small terms first
-                        wsu_mfma_step<MODE>(ahi[m], blo[q], acc[m][q]);
-                        wsu_mfma_step<MODE>(ahi[m], bhi[q], acc[m][q]);
-                    }
+                    for (int q = 0; q < 2; ++q) wsu_mfma_step<MODE>(alo[m], bhi[q], acc[m][q]);     // small terms first
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) wsu_mfma_step<MODE>(ahi[m], blo[q], acc[m][q]);
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) wsu_mfma_step<MODE>(ahi[m], bhi[q], acc[m][q]);
             } else {
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     const int g = 2 * ks + hh;
-                    u32x4 av[2], bv[2];
+                    u32x4 av[MT], bv[2];
 #pragma unroll
-                    for (int m = 0; m < 2; ++m)
+                    for (int m = 0; m < MT; ++m)
                         av[m] = *reinterpret_cast<const u32x4*>(ldsA + ((tap * 4) * 64 + m * 32) * 16 + g * (64 * 16));
 #pragma unroll
                     for (int q = 0; q < 2; ++q)
                         bv[q] = *reinterpret_cast<const u32x4*>(ldsB + g * PLANE_IN + ((q + dy) * IW + dx) * 16);
 #pragma unroll
-                    for (int m = 0; m < 2; ++m)
+                    for (int m = 0; m < MT; ++m)
 #pragma unroll
                         for (int q = 0; q < 2; ++q) wsu_mfma_step<MODE>(av[m], bv[q], acc[m][q]);
                 }
@@ -208,10 +233,10 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_kernel(const ConvArgs a) {
     __syncthreads();
     constexpr int STRIDE = Epi<MODE>::STRIDE;
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
+    for (int m = 0; m < MT; ++m) {
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
-            const int co = m * 32 + 8 * g4 + 4 * hh;                  // 4 consecutive channels co..co+3
+            const int co = mbase + m * 32 + 8 * g4 + 4 * hh;          // 4 consecutive channels co..co+3
             f32x4 b4 = mk_f4(0.f, 0.f, 0.f, 0.f);
             if (a.bias) b4 = *reinterpret_cast<const f32x4*>(a.bias + cb * WSU_COB + co);
 #pragma unroll
@@ -219,7 +244,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_kernel(const ConvArgs a) {
                 float v0 = acc[m][q][4 * g4 + 0] + b4.x, v1 = acc[m][q][4 * g4 + 1] + b4.y;
                 float v2 = acc[m][q][4 * g4 + 2] + b4.z, v3 = acc[m][q][4 * g4 + 3] + b4.w;
                 if (a.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
-                const int px = (2 * wv + q) * TW + l31;
+                const int px = (2 * rowpair + q) * TW + l31;
                 if constexpr (ESZ == 4) {
                     *reinterpret_cast<f32x4*>(smem + px * STRIDE + co * 4) = mk_f4(v0, v1, v2, v3);
                 } else {
@@ -319,20 +344,417 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_kernel(const ConvArgs a) {
     }
 }
 
+
+// =====================================================================================================
+// Ping-pong kernel (experimental, WSU_CONV_IMPL=pp).  Why it was written: with two independent workgroups per CU the v1 kernel's matrix phase
+// (MFMA over a staged chunk) and memory phase (global -> LDS staging, epilogue stores) of co-resident
+// workgroups run in lock-step, so its time is the SUM of the two (measured by ablation, DESIGN.md section 5:
+// e12 bf16x3 1966 us = 950 us MFMA-only + 1016 us memory-only).  Here ONE persistent 512-thread workgroup per
+// CU holds two 4-wave groups that are in anti-phase BY CONSTRUCTION: in every barrier interval one group runs
+// the MFMAs of its chunk while the other group (its waves sit on the same four SIMDs) commits the next chunk
+// to LDS, issues the prefetch after that and stores a finished tile -- matrix beside memory on every SIMD.
+//   * each group owns an 8x32-pixel tile (64 co) -> per wave 64 co x 64 px as in v1;
+//   * the two groups work on tile pairs with the SAME output-channel block, so the weight tile is staged
+//     once (by group 0, double-buffered) and read by both: weight traffic (62 % of v1's staged bytes) halves;
+//   * the epilogue goes straight from the accumulators to NHWC (4 consecutive channels = 16 B per lane), the
+//     2x2 max-pool is taken in registers (rows = the wave's two MFMA column tiles, columns = lane pairs);
+//     no LDS round trip, no extra barriers;
+//   * work is walked persistently with an XCD-contiguous order, chunk 0 of the next tile is prefetched during
+//     the last chunk of the current one.
+// Interval i:  group g is in its memory phase when (i - g) is even, in its matrix phase when odd.
+// =====================================================================================================
+constexpr int PP_LDS = 2 * LDS_IN + 2 * LDS_W;           // 118016 B
+
+struct PPItem { int n, y0, x0, cb, valid; };
+
+__device__ __forceinline__ PPItem pp_item(const ConvArgs& a, int pair, int grp) {
+    PPItem it;
+    const int t2 = pair / a.ncb;
+    it.cb = pair - t2 * a.ncb;
+    int tile = 2 * t2 + grp;
+    const int ntiles = a.n * a.tiles_x * a.tiles_y;
+    it.valid = tile < ntiles;
+    tile = min(tile, ntiles - 1);
+    const int tx = tile % a.tiles_x; tile /= a.tiles_x;
+    const int ty = tile % a.tiles_y;
+    it.n = tile / a.tiles_y; it.y0 = ty * TH; it.x0 = tx * TW;
+    return it;
+}
+
 template <int MODE>
-int launch_conv(const ConvArgs& a, hipStream_t s) {
+__device__ __forceinline__ void pp_plan(const ConvArgs& a, const PPItem& it, int gt, int (&pixidx)[Shape<4>::IN_VEC]) {
+    constexpr int NT = 256;
+    constexpr int NITEMS = (MODE == WSU_MODE_BF16X3) ? NPIX_IN * 2 : NPIX_IN * 4;
+    constexpr int NLOOP = (MODE == WSU_MODE_BF16X3) ? Shape<4>::IN_VEC3 : Shape<4>::IN_VEC;
+#pragma unroll
+    for (int j = 0; j < NLOOP; ++j) {
+        const int i = gt + j * NT;
+        const int pix = (MODE == WSU_MODE_BF16X3) ? (i >> 1) : (i >> 2);
+        const int r = pix / IW, c = pix - r * IW;
+        int yy = it.y0 - 1 + r, xx = it.x0 - 1 + c;
+        int p;
+        if (a.pad_zero) {
+            p = (yy >= 0 && yy < a.h && xx >= 0 && xx < a.w) ? (it.n * a.h + yy) * a.w + xx : -1;
+        } else {
+            yy = wsu_reflect(yy, a.h); xx = wsu_reflect(xx, a.w);
+            p = (it.n * a.h + yy) * a.w + xx;
+        }
+        if (!it.valid) p = -1;
+        pixidx[j] = (i < NITEMS) ? p : -2;
+    }
+}
+
+// global -> registers: this group's input-tile items of chunk c; group 0 also takes the shared weight slice
+template <int MODE>
+__device__ __forceinline__ void pp_load(const ConvArgs& a, int c, int gt, const int (&pixidx)[Shape<4>::IN_VEC],
+                                        u32x4 (&st_in)[Shape<4>::ST_IN]) {
+    constexpr int ESZ = Epi<MODE>::ESZ;
+    constexpr int CK = (MODE == WSU_MODE_BF16) ? 32 : 16;
+    constexpr int NT = 256;
+    constexpr int NLOOP = (MODE == WSU_MODE_BF16X3) ? Shape<4>::IN_VEC3 : Shape<4>::IN_VEC;
+    const char* src; int csrc, ch0;
+    if (c < a.nch1) { src = a.x1; csrc = a.c1; ch0 = c * CK; }
+    else            { src = a.x2; csrc = a.c2; ch0 = (c - a.nch1) * CK; }
+#pragma unroll
+    for (int j = 0; j < NLOOP; ++j) {
+        const int p = pixidx[j];
+        if constexpr (MODE == WSU_MODE_BF16X3) {
+            const int sub = (gt + j * NT) & 1;
+            u32x4 v0 = mk_u4(0, 0, 0, 0), v1 = v0;
+            if (p >= 0) {
+                const u32x4* g = reinterpret_cast<const u32x4*>(src + ((size_t)p * csrc + ch0) * 4 + sub * 32);
+                v0 = g[0]; v1 = g[1];
+            }
+            st_in[2 * j] = v0; st_in[2 * j + 1] = v1;
+        } else {
+            const int sub = (gt + j * NT) & 3;
+            u32x4 v = mk_u4(0, 0, 0, 0);
+            if (p >= 0) v = *reinterpret_cast<const u32x4*>(src + ((size_t)p * csrc + ch0) * ESZ + sub * 16);
+            st_in[j] = v;
+        }
+    }
+}
+
+// The shared weight slice of (cb, chunk c) goes global -> LDS by LDS-DMA (global_load_lds_dwordx4): a linear 36 KB
+// copy, 9 wave-instructions per wave of group 0, no staging registers and no ds_write.  LDS destination = wave-uniform
+// base (M0) + lane * 16, global source per lane.
+typedef __attribute__((address_space(3))) void wsu_lds_void;
+typedef __attribute__((address_space(1))) const void wsu_glb_void;
+__device__ __forceinline__ void pp_dma_weights(const ConvArgs& a, int cb, int c, char* w_lds, int gt, int wv4) {
+    const char* wsrc = a.wp + ((size_t)cb * a.nch + c) * LDS_W + (size_t)gt * 16;
+    char* ldst = w_lds + wv4 * 64 * 16;
+#pragma unroll
+    for (int k = 0; k < W_ITEMS / 256; ++k)
+        __builtin_amdgcn_global_load_lds((wsu_glb_void*)(wsrc + (size_t)k * 256 * 16), (wsu_lds_void*)(ldst + k * 256 * 16), 16, 0, 0);
+}
+
+template <int MODE>
+__device__ __forceinline__ void pp_commit(char* in_lds, int gt, const int (&pixidx)[Shape<4>::IN_VEC],
+                                          const u32x4 (&st_in)[Shape<4>::ST_IN]) {
+    constexpr int NT = 256;
+    constexpr int NLOOP = (MODE == WSU_MODE_BF16X3) ? Shape<4>::IN_VEC3 : Shape<4>::IN_VEC;
+#pragma unroll
+    for (int j = 0; j < NLOOP; ++j) {
+        if (pixidx[j] != -2) {
+            const int i = gt + j * NT;
+            if constexpr (MODE == WSU_MODE_BF16X3) {
+                const int off = (i & 1) * PLANE_IN + (i >> 1) * 16;
+                u32x4 hi, lo;
+                wsu_split8(__builtin_bit_cast(f32x4, st_in[2 * j]), __builtin_bit_cast(f32x4, st_in[2 * j + 1]), hi, lo);
+                *reinterpret_cast<u32x4*>(in_lds + off) = hi;
+                *reinterpret_cast<u32x4*>(in_lds + off + 2 * PLANE_IN) = lo;
+            } else {
+                *reinterpret_cast<u32x4*>(in_lds + (i & 3) * PLANE_IN + (i >> 2) * 16) = st_in[j];
+            }
+        }
+    }
+}
+
+// Fragment set of one tap: 8 x 16 B per lane.
+//   BF16X3: {ahi[0], ahi[1], alo[0], alo[1], bhi[0], bhi[1], blo[0], blo[1]}
+//   others: {a[ks0][0], a[ks0][1], b[ks0][0], b[ks0][1], a[ks1][0], a[ks1][1], b[ks1][0], b[ks1][1]}
+template <int MODE, int TAP>
+__device__ __forceinline__ void pp_load_frags(u32x4 (&f)[8], const char* ldsA, const char* ldsB, int hh) {
+    constexpr int dy = TAP / 3, dx = TAP % 3;
+    if constexpr (MODE == WSU_MODE_BF16X3) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            f[m] = *reinterpret_cast<const u32x4*>(ldsA + ((TAP * 4 + hh) * 64 + m * 32) * 16);
+            f[2 + m] = *reinterpret_cast<const u32x4*>(ldsA + ((TAP * 4 + 2 + hh) * 64 + m * 32) * 16);
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            f[4 + q] = *reinterpret_cast<const u32x4*>(ldsB + hh * PLANE_IN + ((q + dy) * IW + dx) * 16);
+            f[6 + q] = *reinterpret_cast<const u32x4*>(ldsB + (2 + hh) * PLANE_IN + ((q + dy) * IW + dx) * 16);
+        }
+    } else {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int g = 2 * ks + hh;
+#pragma unroll
+            for (int m = 0; m < 2; ++m) f[4 * ks + m] = *reinterpret_cast<const u32x4*>(ldsA + ((TAP * 4 + g) * 64 + m * 32) * 16);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) f[4 * ks + 2 + q] = *reinterpret_cast<const u32x4*>(ldsB + g * PLANE_IN + ((q + dy) * IW + dx) * 16);
+        }
+    }
+}
+
+template <int MODE>
+__device__ __forceinline__ void pp_mfma_frags(const u32x4 (&f)[8], f32x16 (&acc)[2][2]) {
+    if constexpr (MODE == WSU_MODE_BF16X3) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) wsu_mfma_step<MODE>(f[2 + m], f[4 + q], acc[m][q]);      // lo * hi   (small terms first)
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) wsu_mfma_step<MODE>(f[m], f[6 + q], acc[m][q]);          // hi * lo
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) wsu_mfma_step<MODE>(f[m], f[4 + q], acc[m][q]);          // hi * hi
+    } else {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) wsu_mfma_step<MODE>(f[4 * ks + m], f[4 * ks + 2 + q], acc[m][q]);
+    }
+}
+
+// One chunk of the matrix phase.  Only ONE wave per SIMD issues MFMAs during an interval, so nothing else hides its
+// LDS latency: the fragments are software-pipelined by a whole tap (two register sets) and the next tap's eight
+// ds_read_b128 are interleaved one by one under the current tap's MFMAs (sched_group_barrier pins the interleave).
+template <int MODE>
+__device__ __forceinline__ void pp_compute(const char* in_lds, const char* w_lds, int wv4, int l31, int hh, f32x16 (&acc)[2][2]) {
+    const char* ldsA = w_lds + l31 * 16;
+    const char* ldsB = in_lds + ((2 * wv4) * IW + l31) * 16;
+    constexpr int NMFMA = MODE == WSU_MODE_BF16X3 ? 12 : (MODE == WSU_MODE_F32 ? 32 : 8);
+    u32x4 fa[8], fb[8];
+    pp_load_frags<MODE, 0>(fa, ldsA, ldsB, hh);
+    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);                              // prologue reads form their own group
+    WSU_STATIC_FOR(9, tap,
+        if constexpr (tap + 1 < 9) {
+            if constexpr (tap % 2 == 0) pp_load_frags<MODE, (tap + 1 < 9 ? tap + 1 : 0)>(fb, ldsA, ldsB, hh);
+            else pp_load_frags<MODE, (tap + 1 < 9 ? tap + 1 : 0)>(fa, ldsA, ldsB, hh);
+        }
+        if constexpr (tap % 2 == 0) pp_mfma_frags<MODE>(fa, acc); else pp_mfma_frags<MODE>(fb, acc);
+        if constexpr (tap + 1 < 9) {
+            _Pragma("unroll") for (int k = 0; k < 8; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                  // DS read
+                __builtin_amdgcn_sched_group_barrier(0x008, NMFMA / 8, 0);          // MFMA
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, NMFMA - 8 * (NMFMA / 8), 0);
+        }
+    );
+}
+
+// accumulators -> NHWC (+bias, ReLU, ReLU mask of the data-gradient pass), fused 2x2 max-pool in registers
+template <int MODE>
+__device__ __forceinline__ void pp_epilogue(const ConvArgs& a, const PPItem& it, int wv4, int l31, int hh, const f32x16 (&acc)[2][2]) {
+    constexpr int ESZ = Epi<MODE>::ESZ;
+    const int cglob = it.cb * WSU_COB;
+    char* ydst = a.y; int ych = a.csplit, ycoff = cglob;
+    const char* msk = a.relu_mask;
+    if (cglob >= a.csplit) { ydst = a.y2; ych = a.cout - a.csplit; ycoff = cglob - a.csplit; msk = a.relu_mask2; }
+    const int col = it.x0 + l31;
+    const int hp = a.h >> 1, wp2 = a.w >> 1;
+    const int gy = (it.y0 >> 1) + wv4, gx = (it.x0 >> 1) + (l31 >> 1);
+    const bool pool_lane = a.ypool && !(l31 & 1) && gy < hp && gx < wp2;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const int co = m * 32 + 8 * g4 + 4 * hh;
+            f32x4 b4 = mk_f4(0.f, 0.f, 0.f, 0.f);
+            if (a.bias) b4 = *reinterpret_cast<const f32x4*>(a.bias + cglob + co);
+            f32x4 v[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                v[q] = mk_f4(acc[m][q][4 * g4 + 0] + b4.x, acc[m][q][4 * g4 + 1] + b4.y,
+                             acc[m][q][4 * g4 + 2] + b4.z, acc[m][q][4 * g4 + 3] + b4.w);
+                if (a.relu) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[q][e] = fmaxf(v[q][e], 0.f);
+                }
+                if constexpr (ESZ == 2) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[q][e] = (float)(__bf16)v[q][e];   // compare / pool on the stored values
+                }
+                const int row = it.y0 + 2 * wv4 + q;
+                if (row < a.h && col < a.w) {
+                    const size_t eoff = ((size_t)(it.n * a.h + row) * a.w + col) * ych + ycoff + co;
+                    if constexpr (ESZ == 4) {
+                        f32x4 val = v[q];
+                        if (msk) {
+                            const f32x4 mk = *reinterpret_cast<const f32x4*>(msk + eoff * 4);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) if (!(mk[e] > 0.f)) val[e] = 0.f;
+                        }
+                        *reinterpret_cast<f32x4*>(ydst + eoff * 4) = val;
+                    } else {
+                        *reinterpret_cast<u32x2*>(ydst + eoff * 2) = mk_u2(wsu_pack_bf16x2(v[q][0], v[q][1]), wsu_pack_bf16x2(v[q][2], v[q][3]));
+                    }
+                }
+            }
+            if (a.ypool) {                                          // wave-uniform: every lane takes part in the shuffles
+                f32x4 best; uint32_t idx = 0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float n0 = __shfl_xor(v[0][e], 1, 64), n1 = __shfl_xor(v[1][e], 1, 64);
+                    float bv = v[0][e]; uint32_t bi = 0;              // window order (0,0) (0,1) (1,0) (1,1), first max wins
+                    if (n0 > bv || n0 != n0) { bv = n0; bi = 1; }
+                    if (v[1][e] > bv || v[1][e] != v[1][e]) { bv = v[1][e]; bi = 2; }
+                    if (n1 > bv || n1 != n1) { bv = n1; bi = 3; }
+                    best[e] = bv; idx |= bi << (8 * e);
+                }
+                if (pool_lane) {
+                    const size_t eoff = ((size_t)(it.n * hp + gy) * wp2 + gx) * a.cout + cglob + co;
+                    if constexpr (ESZ == 4) *reinterpret_cast<f32x4*>(a.ypool + eoff * 4) = best;
+                    else *reinterpret_cast<u32x2*>(a.ypool + eoff * 2) = mk_u2(wsu_pack_bf16x2(best[0], best[1]), wsu_pack_bf16x2(best[2], best[3]));
+                    if (a.pidx) *reinterpret_cast<uint32_t*>(a.pidx + eoff) = idx;
+                }
+            }
+        }
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int grp = __builtin_amdgcn_readfirstlane(tid >> 8);          // wave-uniform: waves 0-3 / 4-7
+    const int gt = tid & 255, wv4 = (tid >> 6) & 3, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+    const bool with_w = grp == 0;
+    char* in_lds = smem + grp * LDS_IN;
+    char* w_base = smem + 2 * LDS_IN;
+
+    const int G = gridDim.x;
+    const int lw = (int)wsu_xcd_remap(blockIdx.x, G);
+    const int ntiles = a.n * a.tiles_x * a.tiles_y;
+    const int npairs = ((ntiles + 1) >> 1) * a.ncb;
+    const int K = npairs > lw ? (npairs - lw + G - 1) / G : 0;         // tile pairs walked by this workgroup
+    const int J = K * a.nch;                                            // chunk steps per group
+
+    int pixidx[Shape<4>::IN_VEC];
+    u32x4 st_in[Shape<4>::ST_IN];
+    f32x16 acc[2][2];
+    PPItem cur = pp_item(a, lw, grp);                                   // item being multiplied / stored
+    if (J > 0) {
+        if (with_w) pp_dma_weights(a, cur.cb, 0, w_base, gt, wv4);      // W(0) -> Wbuf[0]
+        pp_plan<MODE>(a, cur, gt, pixidx);
+        pp_load<MODE>(a, 0, gt, pixidx, st_in);
+    }
+    for (int i = 0; i <= 2 * J + 1; ++i) {
+        const int ph = i - grp;
+        if (ph >= 0) {
+            const int j = ph >> 1;
+            if (!(ph & 1)) {
+                // ---- memory phase: commit chunk j, store the tile finished in the previous interval, prefetch chunk j+1.
+                // Everything this wave issued earlier (input prefetch two intervals ago, weight DMA one interval ago, old
+                // stores) has had at least a full matrix phase to land: draining here is ~free and makes the DMA'd
+                // weights visible at the barrier that ends this interval.  The prefetch issued BELOW stays in flight.
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const int c = j % a.nch;
+                if (j < J) pp_commit<MODE>(in_lds, gt, pixidx, st_in);
+                if (j > 0 && c == 0 && cur.valid && !(a.ablate & 8)) pp_epilogue<MODE>(a, cur, wv4, l31, hh, acc);
+                if (j + 1 < J && !(a.ablate & 1)) {
+                    const int cn = c + 1 == a.nch ? 0 : c + 1;
+                    if (cn == 0) {
+                        const PPItem nxt = pp_item(a, lw + ((j + 1) / a.nch) * G, grp);
+                        pp_plan<MODE>(a, nxt, gt, pixidx);
+                    }
+                    pp_load<MODE>(a, cn, gt, pixidx, st_in);
+                }
+            } else if (j < J) {
+                // ---- matrix phase
+                const int c = j % a.nch;
+                if (with_w && j + 1 < J && !(a.ablate & 1)) {             // W(j+1) -> the buffer nobody reads any more
+                    const int pair = lw + ((j + 1) / a.nch) * G;
+                    pp_dma_weights(a, pair % a.ncb, (j + 1) % a.nch, w_base + ((j + 1) & 1) * LDS_W, gt, wv4);
+                }
+                if (c == 0) {
+                    cur = pp_item(a, lw + (j / a.nch) * G, grp);
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+#pragma unroll
+                        for (int q = 0; q < 2; ++q)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) acc[m][q][r] = 0.f;
+                }
+                // no s_setprio(1) here: a prioritised MFMA wave starves its SIMD partner's VALU (the memory phase is
+                // VALU-heavy: addresses, bf16 split, pooling) and the two phases end up running one after the other
+                if (cur.valid && !(a.ablate & 4)) {
+                    if (a.ablate & 16) __builtin_amdgcn_s_setprio(1);
+                    pp_compute<MODE>(in_lds, w_base + (j & 1) * LDS_W, wv4, l31, hh, acc);
+                    if (a.ablate & 16) __builtin_amdgcn_s_setprio(0);
+                }
+            }
+        }
+        // Interval barrier.  NOT __syncthreads(): its release fence is `s_waitcnt vmcnt(0)`, which would make every
+        // interval wait for the prefetch it has just issued (and for the epilogue stores).  Only LDS traffic has to be
+        // ordered here: drain the LDS queue, then a bare s_barrier; global loads are waited for where their registers
+        // are consumed (the commit two intervals later), stores never.
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+}
+
+template <int MODE>
+int launch_conv_pp(const ConvArgs& a, hipStream_t s) {
+    static int ncu = 0;
+    if (ncu == 0) {
+        int dev = 0; hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+            wsu_set_error("conv3x3: cannot query the device"); return WSU_ERR_HIP;
+        }
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_pp_kernel<MODE>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
+        if (e != hipSuccess) { wsu_set_error("hipFuncSetAttribute(conv3x3_pp): %s", hipGetErrorString(e)); return WSU_ERR_HIP; }
+        ncu = prop.multiProcessorCount;
+    }
+    const long long ntiles = (long long)a.n * a.tiles_x * a.tiles_y;
+    const long long npairs = ((ntiles + 1) / 2) * a.ncb;
+    if (npairs <= 0 || ntiles > 0x3FFFFFFFLL) { wsu_set_error("conv3x3: %lld tiles out of range", ntiles); return WSU_ERR_ARG;}
+    const int grid = (int)(npairs < ncu ? npairs : ncu);
+    hipLaunchKernelGGL(conv3x3_pp_kernel<MODE>, dim3(grid), dim3(512), PP_LDS, s, a);
+    return wsu_check_launch("conv3x3_pp_kernel");
+}
+
+template <int MODE, int NW>
+int launch_conv_nw(const ConvArgs& a, hipStream_t s) {
     const int lds = Epi<MODE>::BYTES > LDS_MAIN ? Epi<MODE>::BYTES : LDS_MAIN;
     static bool attr_done = false;     // benign race: idempotent
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<MODE>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<MODE, NW>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) { wsu_set_error("hipFuncSetAttribute(conv3x3): %s", hipGetErrorString(e)); return WSU_ERR_HIP; }
         attr_done = true;
     }
     const long long nblk = (long long)a.n * a.tiles_x * a.tiles_y * a.ncb;
     if (nblk <= 0 || nblk > 0x7FFFFFFFLL) { wsu_set_error("conv3x3: grid of %lld workgroups out of range", nblk); return WSU_ERR_ARG; }
-    hipLaunchKernelGGL(conv3x3_kernel<MODE>, dim3((unsigned)nblk), dim3(NT), lds, s, a);
+    hipLaunchKernelGGL((conv3x3_kernel<MODE, NW>), dim3((unsigned)nblk), dim3(NW * 64), lds, s, a);
     return wsu_check_launch("conv3x3_kernel");
+}
+
+// WSU_CONV_WAVES=4|8 overrides the workgroup shape (tuning / A-B runs); default chosen per mode by measurement.
+template <int MODE>
+int launch_conv(const ConvArgs& a, hipStream_t s) {
+    // Default = the per-tile kernel (v1): measured faster (bench conv3x3 15.8 ms vs 17.9 ms per batch-32 forward in bf16x3).
+    // WSU_CONV_IMPL=pp selects the ping-pong kernel (kept for the next tuning round; profiles/r01/conv3x3_ablation.md).
+    static int impl = -1;
+    if (impl < 0) { const char* e = getenv("WSU_CONV_IMPL"); impl = (e && e[0] == 'p' && e[1] == 'p') ? 0 : 1; }
+    const bool mask_bf16 = MODE == WSU_MODE_BF16 && (a.relu_mask || a.relu_mask2);
+    if (impl == 0 && !mask_bf16) return launch_conv_pp<MODE>(a, s);
+    static int nw = 0;
+    if (nw == 0) {
+        const char* e = getenv("WSU_CONV_WAVES");
+        nw = (e && atoi(e) == 4) ? 4 : ((e && atoi(e) == 8) ? 8 : (MODE == WSU_MODE_F32 ? 4 : 8));
+    }
+    return nw == 4 ? launch_conv_nw<MODE, 4>(a, s) : launch_conv_nw<MODE, 8>(a, s);
 }
 
 // ---- weight packing: OIHW fp32 -> [cob][chunk][tap][granule][co 64][16 B] -----------------------------
@@ -429,6 +851,9 @@ int wsu_conv3x3_launch_ex(const void* x1, const void* x2, const void* w_packed, 
     a.tiles_x = (w + TW - 1) / TW; a.tiles_y = (h + TH - 1) / TH; a.ncb = cout / WSU_COB;
     a.nch1 = c1 / ck; a.nch = (c1 + c2) / ck;
     a.relu = relu; a.pad_zero = pad_zero;
+    static int ablate = -1;
+    if (ablate < 0) { const char* e = getenv("WSU_CONV_ABLATE"); ablate = e ? atoi(e) : 0; }
+    a.ablate = ablate;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (mode == WSU_MODE_F32) return launch_conv<WSU_MODE_F32>(a, s);
     if (mode == WSU_MODE_BF16X3) return launch_conv<WSU_MODE_BF16X3>(a, s);
