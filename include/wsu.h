@@ -74,6 +74,13 @@ int wsu_conv3x3_fwd(const void* x1, const void* x2, const void* w_packed, const 
                     int n, int h, int w, int c1, int c2, int cout,
                     int mode, int relu, int pad_zero, void* stream);
 
+/* ---- K1 + K5 fused (last layer): out[n,co,y,x] = sigmoid(head_b[co] + sum_c head_w[co,c] * relu(conv3x3(cat[x1,x2]) + bias)[n,y,x,c]).
+ *      Replaces d42 + outconv + F.sigmoid (unet.py:186,189) in one launch; cout must be 64, head_cout 1..4.
+ *      out / logit (optional): NCHW fp32.  y (optional): also store the 64-channel conv output (NHWC). */
+int wsu_conv3x3_head_fwd(const void* x1, const void* x2, const void* w_packed, const float* bias, void* y,
+                         const float* head_w, const float* head_b, float* out, float* logit,
+                         int n, int h, int w, int c1, int c2, int cout, int head_cout, int mode, void* stream);
+
 /* ---- first layer: conv3x3 reflect on a few input planes given as NCHW fp32 (the model input).
  *      Replaces e11 (unet.py:82,141).  cin <= 8, cout multiple of 8.  w is plain OIHW fp32. */
 int wsu_conv3x3_first_fwd(const float* x_nchw, const float* w_oihw, const float* bias, void* y,

@@ -253,3 +253,33 @@ def test_cpu_tensors_are_refused():
         gpu_model(2, "he", "f32")(torch.zeros(1, 1, 30, 32, device=DEV))       # not divisible by 4
     with pytest.raises(ValueError):
         gpu_model(2, "he", "f32")(torch.zeros(1, 1, 4, 4, device=DEV))         # bottom level would be 1x1
+
+
+@pytest.mark.parametrize("mode", MODE_NAMES)
+def test_fused_head_matches_unfused(mode):
+    """d42 + outconv + sigmoid in one launch (wsu_conv3x3_head_fwd) vs the two separate kernels."""
+    m = ops.mode_id(mode)
+    n, h, w, c1, c2 = 2, 24, 40, 64, 64
+    x1, x2 = rand_act((n, c1, h, w), "fh/x1"), rand_act((n, c2, h, w), "fh/x2")
+    wt = torch.from_numpy(formula.formula_tensor("fh/w", (64, c1 + c2, 3, 3), (6.0 / (9 * (c1 + c2))) ** 0.5)).to(DEV)
+    b = torch.from_numpy(formula.formula_tensor("fh/b", (64,), 0.1)).to(DEV)
+    for hc in (1, 3):
+        hw_ = torch.from_numpy(formula.formula_tensor(f"fh/hw{hc}", (hc, 64, 1, 1), 0.4)).to(DEV)
+        hb = torch.from_numpy(formula.formula_tensor(f"fh/hb{hc}", (hc,), 0.1)).to(DEV)
+        wp = ops.pack_conv3x3(wt, m)
+        y = ops.conv3x3(to_nhwc(x1, mode), to_nhwc(x2, mode), wp, b, 64, m)
+        ref_out, ref_logit = ops.conv1x1_sigmoid(y, hw_, hb, m, want_logit=True)
+        out, logit, y2 = ops.conv3x3_head(to_nhwc(x1, mode), to_nhwc(x2, mode), wp, b, hw_, hb, m, want_logit=True, want_y=True)
+        assert torch.equal(y2, y)                                             # the conv tile itself is bit-identical
+        np.testing.assert_allclose(logit.cpu().numpy(), ref_logit.cpu().numpy(), atol=3e-6, rtol=0)
+        np.testing.assert_allclose(out.cpu().numpy(), ref_out.cpu().numpy(), atol=1e-6, rtol=0)
+        out_only = ops.conv3x3_head(to_nhwc(x1, mode), to_nhwc(x2, mode), wp, b, hw_, hb, m)
+        assert torch.equal(out_only, out)
+    # whole model: the fused default equals the unfused path
+    model = gpu_model(2, "he", mode)
+    _, x = images01(2, 64, 64, seed=8)
+    with torch.no_grad():
+        y_f = model(x.to(DEV))
+        model.fuse_head = False
+        y_u = model(x.to(DEV))
+    np.testing.assert_allclose(y_f.cpu().numpy(), y_u.cpu().numpy(), atol=1e-6, rtol=0)

@@ -50,6 +50,8 @@ struct ConvArgs {
     int tiles_x, tiles_y, ncb, nch1, nch;
     int relu, pad_zero;
     int ablate;        // timing-only experiment mask (WSU_CONV_ABLATE), 0 in production
+    // fused 1x1 head + sigmoid (outconv, unet.py:189) on this layer's 64 output channels; y may then be null
+    const float* head_w; const float* head_b; float* head_out; float* head_logit; int head_cout;
 };
 
 template <int MODE> struct Epi {
@@ -261,6 +263,40 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv3x3_kernel(const ConvArgs
     char* ydst = a.y; int ych = a.csplit, ycoff = cglob;
     const char* msk = a.relu_mask;
     if (cglob >= a.csplit) { ydst = a.y2; ych = a.cout - a.csplit; ycoff = cglob - a.csplit; msk = a.relu_mask2; }
+    if (a.head_w && tid < TH * TW) {
+        // fused head: one thread per pixel, 64-wide dot per output plane from the LDS tile, sigmoid, NCHW fp32 store
+        const int r = tid / TW, c = tid % TW;
+        if (y0 + r < a.h && x0 + c < a.w) {
+            float z[4];
+#pragma unroll
+            for (int co = 0; co < 4; ++co) z[co] = (co < a.head_cout && a.head_b) ? a.head_b[co] : 0.f;
+#pragma unroll
+            for (int v = 0; v < VPP; ++v) {
+                const u32x4 raw = *reinterpret_cast<const u32x4*>(smem + tid * STRIDE + v * 16);
+                float xv[16 / ESZ];
+                if constexpr (ESZ == 4) { const f32x4 f = __builtin_bit_cast(f32x4, raw); xv[0] = f.x; xv[1] = f.y; xv[2] = f.z; xv[3] = f.w; }
+                else {
+                    const uint32_t u[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) xv[e] = wsu_bf16_to_f32((u[e >> 1] >> ((e & 1) * 16)) & 0xFFFF);
+                }
+#pragma unroll
+                for (int co = 0; co < 4; ++co)
+                    if (co < a.head_cout)
+#pragma unroll
+                        for (int e = 0; e < 16 / ESZ; ++e) z[co] = fmaf(xv[e], a.head_w[co * WSU_COB + v * (16 / ESZ) + e], z[co]);
+            }
+            const size_t hw = (size_t)a.h * a.w, pix = (size_t)(y0 + r) * a.w + x0 + c;
+#pragma unroll
+            for (int co = 0; co < 4; ++co)
+                if (co < a.head_cout) {
+                    const size_t o = ((size_t)n * a.head_cout + co) * hw + pix;
+                    if (a.head_logit) a.head_logit[o] = z[co];
+                    a.head_out[o] = 1.f / (1.f + expf(-z[co]));
+                }
+        }
+    }
+    if (ydst)
 #pragma unroll
     for (int k = 0; k < TH * TW * VPP / NT; ++k) {
         const int i = tid + k * NT;
@@ -684,13 +720,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const ConvArgs a) {
 #pragma unroll
                             for (int r = 0; r < 16; ++r) acc[m][q][r] = 0.f;
                 }
-                // no s_setprio(1) here: a prioritised MFMA wave starves its SIMD partner's VALU (the memory phase is
-                // VALU-heavy: addresses, bf16 split, pooling) and the two phases end up running one after the other
-                if (cur.valid && !(a.ablate & 4)) {
-                    if (a.ablate & 16) __builtin_amdgcn_s_setprio(1);
-                    pp_compute<MODE>(in_lds, w_base + (j & 1) * LDS_W, wv4, l31, hh, acc);
-                    if (a.ablate & 16) __builtin_amdgcn_s_setprio(0);
-                }
+                // (s_setprio on either phase was measured to make no difference: profiles/r01/conv3x3_ablation.md)
+                if (cur.valid && !(a.ablate & 4)) pp_compute<MODE>(in_lds, w_base + (j & 1) * LDS_W, wv4, l31, hh, acc);
             }
         }
         // Interval barrier.  NOT __syncthreads(): its release fence is `s_waitcnt vmcnt(0)`, which would make every
@@ -748,7 +779,7 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
     static int impl = -1;
     if (impl < 0) { const char* e = getenv("WSU_CONV_IMPL"); impl = (e && e[0] == 'p' && e[1] == 'p') ? 0 : 1; }
     const bool mask_bf16 = MODE == WSU_MODE_BF16 && (a.relu_mask || a.relu_mask2);
-    if (impl == 0 && !mask_bf16) return launch_conv_pp<MODE>(a, s);
+    if (impl == 0 && !mask_bf16 && !a.head_w) return launch_conv_pp<MODE>(a, s);
     static int nw = 0;
     if (nw == 0) {
         const char* e = getenv("WSU_CONV_WAVES");
@@ -827,14 +858,17 @@ int wsu_conv3x3_pack_dgrad(const float* w_oihw, void* w_packed, int cin, int cou
 }
 
 // Extended launcher shared by the forward op and the data-gradient op (wsu_conv3x3_bwd_data in conv3x3_bwd.hip).
-int wsu_conv3x3_launch_ex(const void* x1, const void* x2, const void* w_packed, const float* bias,
+static int conv3x3_launch_full(const void* x1, const void* x2, const void* w_packed, const float* bias,
                           void* y, void* y2, int csplit, void* y_pool, uint8_t* pool_idx,
                           const void* relu_mask, const void* relu_mask2,
+                          const float* head_w, const float* head_b, float* head_out, float* head_logit, int head_cout,
                           int n, int h, int w, int c1, int c2, int cout,
                           int mode, int relu, int pad_zero, void* stream) {
     WSU_REQUIRE(mode >= 0 && mode <= 2, "conv3x3: bad mode %d", mode);
     const int ck = wsu_chunk_channels(mode);
-    WSU_REQUIRE(x1 && w_packed && y, "conv3x3: null pointer");
+    WSU_REQUIRE(x1 && w_packed && (y || head_w), "conv3x3: null pointer");
+    WSU_REQUIRE(!head_w || (head_out && cout == WSU_COB && head_cout >= 1 && head_cout <= 4 && !y2),
+                "conv3x3: fused head needs cout == %d, 1..4 head planes and an output pointer", WSU_COB);
     WSU_REQUIRE(n > 0 && h >= 2 && w >= 2, "conv3x3: bad shape n=%d h=%d w=%d (reflect pad 1 needs h,w >= 2)", n, h, w);
     WSU_REQUIRE(c1 > 0 && c1 % ck == 0, "conv3x3: c1=%d must be a positive multiple of %d in mode %d", c1, ck, mode);
     WSU_REQUIRE(c2 >= 0 && c2 % ck == 0 && (c2 == 0) == (x2 == nullptr), "conv3x3: c2=%d inconsistent with x2 / not a multiple of %d", c2, ck);
@@ -851,6 +885,7 @@ int wsu_conv3x3_launch_ex(const void* x1, const void* x2, const void* w_packed, 
     a.tiles_x = (w + TW - 1) / TW; a.tiles_y = (h + TH - 1) / TH; a.ncb = cout / WSU_COB;
     a.nch1 = c1 / ck; a.nch = (c1 + c2) / ck;
     a.relu = relu; a.pad_zero = pad_zero;
+    a.head_w = head_w; a.head_b = head_b; a.head_out = head_out; a.head_logit = head_logit; a.head_cout = head_cout;
     static int ablate = -1;
     if (ablate < 0) { const char* e = getenv("WSU_CONV_ABLATE"); ablate = e ? atoi(e) : 0; }
     a.ablate = ablate;
@@ -858,6 +893,25 @@ int wsu_conv3x3_launch_ex(const void* x1, const void* x2, const void* w_packed, 
     if (mode == WSU_MODE_F32) return launch_conv<WSU_MODE_F32>(a, s);
     if (mode == WSU_MODE_BF16X3) return launch_conv<WSU_MODE_BF16X3>(a, s);
     return launch_conv<WSU_MODE_BF16>(a, s);
+}
+
+int wsu_conv3x3_launch_ex(const void* x1, const void* x2, const void* w_packed, const float* bias,
+                          void* y, void* y2, int csplit, void* y_pool, uint8_t* pool_idx,
+                          const void* relu_mask, const void* relu_mask2,
+                          int n, int h, int w, int c1, int c2, int cout,
+                          int mode, int relu, int pad_zero, void* stream) {
+    return conv3x3_launch_full(x1, x2, w_packed, bias, y, y2, csplit, y_pool, pool_idx, relu_mask, relu_mask2,
+                               nullptr, nullptr, nullptr, nullptr, 0, n, h, w, c1, c2, cout, mode, relu, pad_zero, stream);
+}
+
+// K1 + K5 fused: out = sigmoid(head_w . relu(conv3x3(cat[x1,x2]) + bias) + head_b), NCHW fp32; the 64-channel conv output is
+// stored only if y != NULL.  Replaces d42 + outconv + sigmoid (unet.py:186,189) in one launch.
+int wsu_conv3x3_head_fwd(const void* x1, const void* x2, const void* w_packed, const float* bias, void* y,
+                         const float* head_w, const float* head_b, float* out, float* logit,
+                         int n, int h, int w, int c1, int c2, int cout, int head_cout, int mode, void* stream) {
+    WSU_REQUIRE(head_w && out, "conv3x3_head: null pointer");
+    return conv3x3_launch_full(x1, x2, w_packed, bias, y, nullptr, cout, nullptr, nullptr, nullptr, nullptr,
+                               head_w, head_b, out, logit, head_cout, n, h, w, c1, c2, cout, mode, 1, 0, stream);
 }
 
 int wsu_conv3x3_fwd(const void* x1, const void* x2, const void* w_packed, const float* bias,

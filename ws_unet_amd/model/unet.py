@@ -75,6 +75,7 @@ class UNet(nn.Module):
             raise NotImplementedError("the reference defines at most 4 pooling steps (unet.py:85-132)")
         self.nsteps = nsteps
         self.mode = mode or os.environ.get("WSU_MODE", "bf16x3")
+        self.fuse_head = os.environ.get("WSU_FUSE_HEAD", "1") != "0"  # fold outconv + sigmoid into the last 3x3 conv
         self.train_mode = os.environ.get("WSU_TRAIN_MODE", "f32")      # arithmetic of the autograd path ('f32' | 'bf16x3')
         ops.mode_id(self.mode)                                    # validate early
         conv_kw = {"kernel_size": 3, "padding": 1, "padding_mode": "reflect"}
@@ -146,6 +147,7 @@ class UNet(nn.Module):
         if save:
             t["xe11"] = cur
         skips: List[torch.Tensor] = []
+        oc_fusable = self.fuse_head and self.outconv.out_channels <= 4
         for lvl in range(self.nsteps + 1):
             a, b = ENC[lvl]
             if lvl >= 1:
@@ -173,6 +175,10 @@ class UNet(nn.Module):
             if save:
                 t["xu" + up[-1]] = xu
                 t["x" + c1] = cur
+            if depth == 1 and not save and oc_fusable:
+                # last layer: d42 + outconv + sigmoid in one launch, xd42 never touches HBM
+                return ops.conv3x3_head(cur, None, self._packed(c2, m, "conv"), l2.bias.detach(),
+                                        self.outconv.weight.detach(), self.outconv.bias.detach(), m, want_logit=want_logit)
             cur = ops.conv3x3(cur, None, self._packed(c2, m, "conv"), l2.bias.detach(), l2.out_channels, m)
             if save:
                 t["x" + c2] = cur

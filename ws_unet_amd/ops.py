@@ -142,6 +142,33 @@ def conv3x3(x1: torch.Tensor, x2: Optional[torch.Tensor], w_packed: torch.Tensor
     return (y, yp, idx) if pool_idx else (y, yp)
 
 
+def conv3x3_head(x1: torch.Tensor, x2: Optional[torch.Tensor], w_packed: torch.Tensor, bias: Optional[torch.Tensor],
+                 head_w: torch.Tensor, head_b: Optional[torch.Tensor], mode: int, want_logit: bool = False, want_y: bool = False):
+    """Last 3x3 conv (64 output channels) + ReLU fused with the 1x1 head + sigmoid.  Returns out (N,co,H,W) fp32
+    [, logit][, y NHWC]."""
+    lib = _lib.load()
+    hw2 = head_w.detach().reshape(head_w.shape[0], -1)
+    _dev_check(x1, x2, w_packed, bias, hw2, head_b)
+    n, h, w, c1 = x1.shape
+    c2 = 0 if x2 is None else x2.shape[3]
+    cout, hc = hw2.shape[1], hw2.shape[0]
+    out = torch.empty((n, hc, h, w), dtype=torch.float32, device=x1.device)
+    logit = torch.empty_like(out) if want_logit else None
+    y = torch.empty((n, h, w, cout), dtype=act_dtype(mode), device=x1.device) if want_y else None
+    esz = 2 if mode == MODE_BF16 else 4
+    meta = {"flops": 2.0 * 9 * (c1 + c2) * cout * n * h * w,
+            "bytes": float(n * h * w * ((c1 + c2) * esz + hc * 4) + 9 * (c1 + c2) * cout * esz)}
+    check(_launch("conv3x3", meta, lambda: lib.wsu_conv3x3_head_fwd(
+        x1.data_ptr(), _ptr(x2), w_packed.data_ptr(), _ptr(bias), _ptr(y), hw2.data_ptr(), _ptr(head_b), out.data_ptr(), _ptr(logit),
+        n, h, w, c1, c2, cout, hc, mode, _stream())), "wsu_conv3x3_head_fwd")
+    res = [out]
+    if want_logit:
+        res.append(logit)
+    if want_y:
+        res.append(y)
+    return res[0] if len(res) == 1 else tuple(res)
+
+
 def conv3x3_first(x_nchw: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], mode: int, relu: bool = True) -> torch.Tensor:
     lib = _lib.load()
     _dev_check(x_nchw, w, bias)
