@@ -44,14 +44,14 @@ def build_model(mode, dev):
     return m.to(dev)
 
 
-def timed_steps(model, x, steps, warmup, world, timer=None):
+def timed_steps(model, x, steps, warmup, use_dist, timer=None):
     from ws_unet_amd import ops
     import torch.distributed as dist
     with torch.no_grad():
         for _ in range(warmup):
             model(x)
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         ops.set_timer(timer)
@@ -59,12 +59,12 @@ def timed_steps(model, x, steps, warmup, world, timer=None):
         for _ in range(steps):
             y = model(x)
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         ops.set_timer(None)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=x.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
@@ -119,7 +119,10 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback for the product path)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # Under torch.distributed.run (RANK set) the RCCL process group is always created, also for one rank, so the
+    # barrier / max-reduce code below is the same code at every N.
+    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -131,7 +134,7 @@ def main():
 
     model = build_model(args.mode, dev)
     timer = ops.KernelTimer()
-    dt, y = timed_steps(model, x, args.steps, args.warmup, world, timer)
+    dt, y = timed_steps(model, x, args.steps, args.warmup, use_dist, timer)
     imgs = world * args.batch * args.steps
     value = imgs / dt
 
@@ -169,7 +172,7 @@ def main():
         for md in [m for m in ("bf16", "f32", "bf16x3") if m != args.mode]:
             mm = build_model(md, dev)
             st = max(2, args.steps // 3)
-            d2, y2 = timed_steps(mm, x, st, 1, 1)
+            d2, y2 = timed_steps(mm, x, st, 1, False)
             other[md] = {"images_per_s": args.batch * st / d2, "ms_per_step": d2 / st * 1e3, "_y": y2[:4].cpu()}
             del mm
         result["other_modes"] = other
@@ -193,7 +196,7 @@ def main():
         for o in result.get("other_modes", {}).values():
             o.pop("_y", None)
         print(json.dumps(result))
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
         dist.destroy_process_group()
 

@@ -126,7 +126,7 @@ int wsu_u8_to_unit_f32(const uint8_t* x, float* y, size_t count, void* stream);
  * g: (N,H,W,Cout) fp32.  dx1: (N,H,W,csplit), dx2: (N,H,W,cin-csplit) or NULL (the two inputs of a fused concat).
  * relu_mask1/2 (optional, shapes of dx1/dx2): saved post-ReLU activations; where they are <= 0 the gradient is zeroed,
  * which makes dx the pre-activation gradient of the producing layers.  mode: WSU_MODE_F32 or WSU_MODE_BF16X3. */
-int wsu_conv3x3_bwd_data(const void* g, const void* w_packed_dgrad, const float* w_oihw,
+int wsu_conv3x3_bwd_data(const void* g, const void* w_packed_dgrad, const float* w_oihw, float* w_scratch /* 9*cin*cout floats */,
                          void* dx1, void* dx2, int csplit, const void* relu_mask1, const void* relu_mask2,
                          int n, int h, int w, int cin, int cout, int mode, void* stream);
 
@@ -140,6 +140,9 @@ int wsu_conv3x3_bwd_weight(const float* g, const float* x1, const float* x2, flo
 size_t wsu_first_bwd_workspace_bytes(int n, int h, int w, int cin, int cout);
 int wsu_conv3x3_first_bwd_weight(const float* g, const float* x_nchw, float* dw, float* db,
                                  float* workspace, size_t workspace_bytes, int n, int h, int w, int cin, int cout, void* stream);
+
+/* first layer: dx (N,cin,H,W) NCHW fp32 -- the input saliency gradient (src/saliency.py:159-174). */
+int wsu_conv3x3_first_bwd_data(const float* g, const float* w_oihw, float* dx_nchw, int n, int h, int w, int cin, int cout, void* stream);
 
 /* transposed conv: dW (Cin x Cout x 2 x 2), db (Cout, optional) from x (N,h,w,Cin) and dy (N,2h,2w,Cout) ... */
 int wsu_convt2x2_bwd_weight(const float* x, const float* dy, float* dw, float* db,

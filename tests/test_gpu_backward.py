@@ -144,7 +144,7 @@ def test_unet_gradients_golden(golden, ns):
     cov_u8 = formula.synthetic_images(2, 64, 64, seed=11)
     st_u8 = cov_u8.copy(); st_u8[0] = formula.lsbr_embed(cov_u8[0], 0.4, seed=5)
     covers = torch.from_numpy(cov_u8.astype(np.float32) / np.float32(255.))[:, None].to(DEV)
-    inputs = torch.from_numpy(st_u8.astype(np.float32) / np.float32(255.))[:, None].to(DEV)
+    inputs = torch.from_numpy(st_u8.astype(np.float32) / np.float32(255.))[:, None].to(DEV).requires_grad_(True)
     alphas = torch.tensor([0.4, 0.0], device=DEV)
     out = model(inputs)
     assert out.requires_grad
@@ -166,9 +166,14 @@ def test_unet_gradients_golden(golden, ns):
         s = g[f"grad{ns}_{k}_sum"]
         full = p.grad.detach().double().cpu().numpy()
         assert math.isclose(float(np.sqrt((full ** 2).sum())), s[2], rel_tol=1e-3), k
+    # inputs.requires_grad exercises the input-gradient kernel here, but the golden grad{ns}_dx is not comparable: the
+    # reference's WS term depends on `inputs` directly (losses.py:59-62) and autograd adds that path, while the fused loss
+    # treats inputs as data (as the training loop does).  The input gradient is checked in test_saliency_style_input_gradient.
+    assert inputs.grad is not None and torch.isfinite(inputs.grad).all()
     # gradients are deterministic (no float atomics): bitwise equal on a repeat
     first = {k: p.grad.clone() for k, p in model.named_parameters()}
     model.zero_grad()
+    inputs.grad = None
     losses.L1WSLoss()(model(inputs), (covers, alphas), inputs).backward()
     for k, p in model.named_parameters():
         assert torch.equal(p.grad, first[k]), k
@@ -221,3 +226,27 @@ def test_training_reduces_loss_and_checkpoints(tmp_path):
     assert set(ck) == {"epoch", "state_dict", "best_val_loss", "patience", "optimizer", "scheduler"}
     assert list(ck["state_dict"]) == list(model.state_dict())
     assert (tmp_path / "run" / "config.json").exists() and (tmp_path / "run" / "log" / "scalars.csv").exists()
+
+
+def test_saliency_style_input_gradient():
+    """src/saliency.py:133-174: parameters frozen, input requires grad, backward from ONE output pixel; the gradient
+    is confined to the receptive field and matches the CPU oracle."""
+    model = gpu_model(2, "he", "f32")
+    model.input_dropout = None
+    for p in model.parameters():
+        p.requires_grad = False
+    _, x = images01(1, 64, 64, seed=13)
+    xd = x.to(DEV).requires_grad_(True)
+    out = model(xd)
+    out[0, 0, 30, 33].backward()
+    gx = xd.grad.cpu()
+    ref_m = unet_ref.build_ref(2, formula.formula_state_dict(2, "he"))
+    xr = x.clone().requires_grad_(True)
+    ref_m(xr)[0, 0, 30, 33].backward()
+    scale = xr.grad.abs().max().item()
+    assert scale > 0
+    np.testing.assert_allclose(gx.numpy(), xr.grad.numpy(), rtol=0, atol=2e-4 * scale)
+    nz = (xr.grad[0, 0] != 0).nonzero()
+    assert nz[:, 0].min() >= 30 - 24 and nz[:, 0].max() <= 30 + 24           # receptive field of unet_2 ~ +-22
+    with torch.no_grad():
+        assert model(torch.zeros(0, 1, 64, 64, device=DEV)).shape == (0, 1, 64, 64)     # empty batch

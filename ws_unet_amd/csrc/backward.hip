@@ -25,7 +25,7 @@ namespace {
 // columns 1, W-2 receive anything.  One workgroup per destination pixel, one thread per input channel,
 // fixed summation order; the ReLU mask of the producing layer is applied to the addend.
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void dgrad_border_kernel(const float* __restrict__ g, const float* __restrict__ w_oihw,
+__global__ __launch_bounds__(256) void dgrad_border_kernel(const float* __restrict__ g, const float* __restrict__ w_t,
                                                            float* __restrict__ dx1, float* __restrict__ dx2,
                                                            const float* __restrict__ mask1, const float* __restrict__ mask2,
                                                            int n, int h, int w, int cin, int csplit, int cout) {
@@ -62,9 +62,9 @@ __global__ __launch_bounds__(256) void dgrad_border_kernel(const float* __restri
                         const int sx = xp - v + 1;
                         if (sx < 0 || sx >= w) continue;
                         const float* gp = g + ((size_t)(img * h + sy) * w + sx) * cout;
-                        const float* wp = w_oihw + ((size_t)ci * 9 + u * 3 + v);
+                        const float* wp = w_t + ((size_t)(u * 3 + v) * cout) * cin + ci;      // [tap][co][ci]: lanes read consecutive ci
                         float s = 0.f;
-                        for (int co = 0; co < cout; ++co) s = fmaf(gp[co], wp[(size_t)co * cin * 9], s);
+                        for (int co = 0; co < cout; ++co) s = fmaf(gp[co], wp[(size_t)co * cin], s);
                         acc += s;
                     }
                 }
@@ -75,6 +75,15 @@ __global__ __launch_bounds__(256) void dgrad_border_kernel(const float* __restri
         const size_t o = ((size_t)(img * h + y) * w + x) * c + cc;
         if (mk && !(mk[o] > 0.f)) acc = 0.f;
         dst[o] += acc;
+    }
+}
+
+// OIHW -> [tap][co][ci] so that the border kernel's lanes (one per ci) read consecutive floats
+__global__ void border_weight_transpose_kernel(const float* __restrict__ w, float* __restrict__ wt, int cin, int cout) {
+    const int total = 9 * cout * cin;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int ci = i % cin, co = (i / cin) % cout, tap = i / (cin * cout);
+        wt[i] = w[((size_t)co * cin + ci) * 9 + tap];
     }
 }
 
@@ -380,18 +389,74 @@ __global__ void first_wgrad_reduce_kernel(const float* __restrict__ part, float*
     if (r < cin * 9) dw[(size_t)co * cin * 9 + r] = s; else if (db) db[co] = s;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// First-layer data gradient (input saliency, src/saliency.py:159-174): dx[n,ci,y,x] = sum over the padded positions that
+// reflect onto (y,x) of sum_{u,v,co} W[co,ci,u,v] * g[n, yp-u+1, xp-v+1, co]  (g zero outside the image).
+// One thread per input element; weights transposed to [ci][tap][co] in LDS so the 64-wide dot reads are contiguous.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void first_dgrad_kernel(const float* __restrict__ g, const float* __restrict__ w,
+                                                          float* __restrict__ dx, int n, int h, int wd, int cin, int cout) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* wl = reinterpret_cast<float*>(smem);                 // [ci][tap][co]
+    for (int i = threadIdx.x; i < cin * 9 * cout; i += blockDim.x) {
+        const int co = i % cout, tap = (i / cout) % 9, ci = i / (9 * cout);
+        wl[i] = w[((size_t)co * cin + ci) * 9 + tap];
+    }
+    __syncthreads();
+    const long long total = (long long)n * cin * h * wd;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % wd); long long t = i / wd;
+        const int y = (int)(t % h); t /= h;
+        const int ci = (int)(t % cin); const int img = (int)(t / cin);
+        int ys[3], xs[3]; int ny = 0, nx = 0;
+        ys[ny++] = y; if (y == 1) ys[ny++] = -1; if (y == h - 2) ys[ny++] = h;
+        xs[nx++] = x; if (x == 1) xs[nx++] = -1; if (x == wd - 2) xs[nx++] = wd;
+        float acc = 0.f;
+        for (int iy = 0; iy < ny; ++iy)
+            for (int ix = 0; ix < nx; ++ix)
+                for (int u = 0; u < 3; ++u) {
+                    const int sy = ys[iy] - u + 1;
+                    if (sy < 0 || sy >= h) continue;
+                    for (int v = 0; v < 3; ++v) {
+                        const int sx = xs[ix] - v + 1;
+                        if (sx < 0 || sx >= wd) continue;
+                        const f32x4* gp = reinterpret_cast<const f32x4*>(g + ((size_t)(img * h + sy) * wd + sx) * cout);
+                        const f32x4* wp = reinterpret_cast<const f32x4*>(wl + (ci * 9 + u * 3 + v) * cout);
+                        float s = 0.f;
+                        for (int c4 = 0; c4 < cout / 4; ++c4) {
+                            const f32x4 a = gp[c4], b = wp[c4];
+                            s = fmaf(a.x, b.x, s); s = fmaf(a.y, b.y, s); s = fmaf(a.z, b.z, s); s = fmaf(a.w, b.w, s);
+                        }
+                        acc += s;
+                    }
+                }
+        dx[i] = acc;
+    }
+}
+
 }  // namespace
 
 extern "C" {
 
+// dx (N, cin, H, W) NCHW fp32 of the first layer from its pre-activation gradient g (N,H,W,cout).
+int wsu_conv3x3_first_bwd_data(const float* g, const float* w_oihw, float* dx_nchw, int n, int h, int w, int cin, int cout, void* stream) {
+    WSU_REQUIRE(g && w_oihw && dx_nchw, "conv3x3_first_bwd_data: null pointer");
+    WSU_REQUIRE(n > 0 && h >= 2 && w >= 2 && cin >= 1 && cin <= 8 && cout % 4 == 0 && cout > 0, "conv3x3_first_bwd_data: bad shape");
+    const long long total = (long long)n * cin * h * w;
+    const unsigned nblk = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(first_dgrad_kernel, dim3(nblk), dim3(256), (size_t)cin * 9 * cout * sizeof(float), static_cast<hipStream_t>(stream),
+                       g, w_oihw, dx_nchw, n, h, w, cin, cout);
+    return wsu_check_launch("first_dgrad_kernel");
+}
+
 // dx (= pre-activation gradient of the producing layer when relu_mask is given) of the 3x3 reflect conv.
 //   g: (N,H,W,Cout) fp32;  w_packed_dgrad: wsu_conv3x3_pack_dgrad output;  w_oihw: the plain weight (border fold).
 //   dx1: (N,H,W,csplit), dx2: (N,H,W,cin-csplit) or NULL (csplit == cin);  relu_mask*: tensors of the dx shapes or NULL.
-int wsu_conv3x3_bwd_data(const void* g, const void* w_packed_dgrad, const float* w_oihw,
+int wsu_conv3x3_bwd_data(const void* g, const void* w_packed_dgrad, const float* w_oihw, float* w_scratch,
                          void* dx1, void* dx2, int csplit, const void* relu_mask1, const void* relu_mask2,
                          int n, int h, int w, int cin, int cout, int mode, void* stream) {
     WSU_REQUIRE(mode == WSU_MODE_F32 || mode == WSU_MODE_BF16X3, "conv3x3_bwd_data: fp32-storage modes only (got %d)", mode);
-    WSU_REQUIRE(w_oihw, "conv3x3_bwd_data: null weight");
+    WSU_REQUIRE(w_oihw && w_scratch, "conv3x3_bwd_data: null weight / scratch (scratch: 9*cin*cout floats)");
     WSU_REQUIRE(cin % WSU_COB == 0, "conv3x3_bwd_data: cin=%d must be a multiple of %d", cin, WSU_COB);
     int rc = wsu_conv3x3_launch_ex(g, nullptr, w_packed_dgrad, nullptr, dx1, dx2, csplit, nullptr, nullptr,
                                    relu_mask1, relu_mask2, n, h, w, cout, 0, cin, mode, 0, 1, stream);
@@ -399,8 +464,11 @@ int wsu_conv3x3_bwd_data(const void* g, const void* w_packed_dgrad, const float*
     const int nrows = (h - 2 != 1) ? 2 : 1, ncols = (w - 2 != 1) ? 2 : 1;
     const long long nblk = (long long)n * (nrows * w + ncols * (h - nrows));
     WSU_REQUIRE(nblk < 0x7FFFFFFFLL, "conv3x3_bwd_data: border grid too large");
+    hipLaunchKernelGGL(border_weight_transpose_kernel, dim3(64), dim3(256), 0, static_cast<hipStream_t>(stream), w_oihw, w_scratch, cin, cout);
+    rc = wsu_check_launch("border_weight_transpose_kernel");
+    if (rc) return rc;
     hipLaunchKernelGGL(dgrad_border_kernel, dim3((unsigned)nblk), dim3(cin < 256 ? cin : 256), 0, static_cast<hipStream_t>(stream),
-                       (const float*)g, w_oihw, (float*)dx1, (float*)dx2, (const float*)relu_mask1, (const float*)relu_mask2,
+                       (const float*)g, (const float*)w_scratch, (float*)dx1, (float*)dx2, (const float*)relu_mask1, (const float*)relu_mask2,
                        n, h, w, cin, csplit, cout);
     return wsu_check_launch("dgrad_border_kernel");
 }

@@ -5,6 +5,7 @@ src/unet/model/unet.py:137-189.  Here the whole network is ONE autograd node: fo
 activations (and 2-bit pool argmax), backward walks the layers in reverse calling the K7 kernels
 (include/wsu.h).  All activations stay fp32; `model.train_mode` picks the arithmetic of the forward /
 data-gradient GEMMs ('f32' exact, default, or 'bf16x3'); weight gradients are always exact fp32 MFMA.
+The gradient w.r.t. the network input (saliency, src/saliency.py:159-174) is produced when `x.requires_grad`.
 
 Conventions inside backward: `g` is the PRE-activation gradient of the layer being processed; every kernel
 that produces the gradient w.r.t. a post-ReLU activation applies that activation's ReLU mask itself
@@ -56,9 +57,6 @@ def _forward_train(model, x: torch.Tensor, m: int) -> Dict[str, torch.Tensor]:
 class _UNetFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, x, *params):
-        if x.requires_grad:
-            raise NotImplementedError("gradient w.r.t. the network input (saliency, src/saliency.py:159-174) is a "
-                                      "'next' item (SURVEY.md 8f-3); only parameter gradients are implemented")
         m = ops.mode_id(getattr(model, "train_mode", "f32"))
         if m == ops.MODE_BF16:
             raise ValueError("train_mode must be 'f32' or 'bf16x3' (activations are kept in fp32 for the backward pass)")
@@ -70,6 +68,7 @@ class _UNetFn(torch.autograd.Function):
     def backward(ctx, dout):
         model, t, x, m = ctx.model, ctx.t, ctx.x, ctx.m
         grads: Dict[str, torch.Tensor] = {}
+        dx = None
         dout = dout.contiguous().float()
 
         def conv_bwd(name, g, x1, x2, mask1, mask2, need_dx=True):
@@ -100,10 +99,12 @@ class _UNetFn(torch.autograd.Function):
             g, _ = conv_bwd(b, g, xa, None, xa, None)                            # -> pre-activation grad of conv a
             if lvl == 0:
                 grads[a + ".weight"], grads[a + ".bias"] = ops.conv3x3_first_bwd_weight(g, x)
+                if ctx.needs_input_grad[1]:                                      # saliency: src/saliency.py:159-174
+                    dx = ops.conv3x3_first_bwd_data(g, getattr(model, a).weight)
             else:
                 g, _ = conv_bwd(a, g, t[f"xp{lvl}"], None, None, None)           # pooled tensor: no ReLU of its own
         ctx.t = None
-        out = [None, None]
+        out = [None, dx if ctx.needs_input_grad[1] else None]
         for name, p in model.named_parameters():
             out.append(grads[name] if p.requires_grad else None)
         return tuple(out)

@@ -193,6 +193,8 @@ class UNet(nn.Module):
 
     def forward(self, x_in: torch.Tensor) -> torch.Tensor:
         x_in = self._check_input(x_in)
+        if x_in.shape[0] == 0:                                     # empty batch: nothing to launch (torch returns an empty tensor too)
+            return x_in.new_zeros((0, self.outconv.out_channels) + tuple(x_in.shape[2:]), dtype=torch.float32)
         if self.input_dropout is not None:
             x_in = self.input_dropout(x_in)
         x = x_in if (x_in.dtype == torch.float32 and x_in.is_contiguous()) else x_in.float().contiguous()

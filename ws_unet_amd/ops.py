@@ -295,8 +295,9 @@ def conv3x3_bwd_data(g: torch.Tensor, w_packed_dgrad: torch.Tensor, w_oihw: torc
     dx1 = torch.empty((n, h, w, csplit), dtype=torch.float32, device=g.device)
     dx2 = torch.empty((n, h, w, cin - csplit), dtype=torch.float32, device=g.device) if csplit < cin else None
     meta = {"flops": 2.0 * 9 * cin * cout * n * h * w}
+    scratch = torch.empty(9 * cin * cout, dtype=torch.float32, device=g.device)
     check(_launch("conv3x3_bwd_data", meta, lambda: lib.wsu_conv3x3_bwd_data(
-        g.data_ptr(), w_packed_dgrad.data_ptr(), w_oihw.data_ptr(), dx1.data_ptr(), _ptr(dx2), csplit, _ptr(mask1), _ptr(mask2),
+        g.data_ptr(), w_packed_dgrad.data_ptr(), w_oihw.data_ptr(), scratch.data_ptr(), dx1.data_ptr(), _ptr(dx2), csplit, _ptr(mask1), _ptr(mask2),
         n, h, w, cin, cout, mode, _stream())), "wsu_conv3x3_bwd_data")
     return dx1, dx2
 
@@ -330,6 +331,19 @@ def conv3x3_first_bwd_weight(g: torch.Tensor, x_nchw: torch.Tensor, want_bias: b
         g.data_ptr(), x_nchw.data_ptr(), dw.data_ptr(), _ptr(db), ws.data_ptr(), ws.numel() * 4, n, h, w, cin, cout, _stream())),
         "wsu_conv3x3_first_bwd_weight")
     return dw, db
+
+
+def conv3x3_first_bwd_data(g: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    """g: (N,H,W,cout) pre-activation gradient of the first layer -> dx (N,cin,H,W)."""
+    lib = _lib.load()
+    w = w.detach()
+    _dev_check(g, w)
+    n, h, wd, cout = g.shape
+    cin = w.shape[1]
+    dx = torch.empty((n, cin, h, wd), dtype=torch.float32, device=g.device)
+    check(lib.wsu_conv3x3_first_bwd_data(g.data_ptr(), w.data_ptr(), dx.data_ptr(), n, h, wd, cin, cout, _stream()),
+          "wsu_conv3x3_first_bwd_data")
+    return dx
 
 
 def convt2x2_bwd_weight(x: torch.Tensor, dy: torch.Tensor, want_bias: bool = True):
