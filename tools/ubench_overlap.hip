@@ -12,7 +12,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
 template <int VIA_LDS>
 __global__ __launch_bounds__(512, 2) void k(const u32x4* __restrict__ src, u32x4* __restrict__ dst, size_t vec_per_block,
-                                            int mfma_iters, int mode, float* sink, int split, int duty, int valu, int prio) {
+                                            int mfma_iters, int mode, float* sink, int split, int duty, int valu, int prio, int ldsfrag) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, grp = tid >> 8, gt = tid & 255;
     // split = 1: even workgroups (CUs) only do the MFMA part with 2x the iterations, odd ones only the copy with 2x the bytes
@@ -27,6 +27,23 @@ __global__ __launch_bounds__(512, 2) void k(const u32x4* __restrict__ src, u32x4
         for (int i = 0; i < 4; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
         u32x4 ra = {0x3f803f80u + tid, 0x3f803f80u, 0x3f003f80u, 0x3f803f00u}, rb = {0x3f803f80u, 0x3f003f00u + tid, 0x3f803f80u, 0x3f803f80u};
         const bf16x8 a = __builtin_bit_cast(bf16x8, ra), b = __builtin_bit_cast(bf16x8, rb);
+        if (ldsfrag) {
+            // conv-like matrix phase: per 12 MFMAs the wave re-reads 8 x 16 B fragments per lane from LDS (conflict free)
+            u32x4* l = reinterpret_cast<u32x4*>(smem) + 1024;           // beyond the copy group's 16 KB
+            for (int i = gt; i < 2048; i += 256) l[i] = ra;
+            __builtin_amdgcn_s_barrier();
+            for (int it = 0; it < mfma_iters / 3; ++it) {
+                u32x4 f[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) f[q] = l[((it + q) & 7) * 256 + gt];
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f[(i & 1) + 2 * (t & 1)]),
+                                                                           __builtin_bit_cast(bf16x8, f[4 + (i >> 1) + 2 * (t >> 1)]), acc[i], 0, 0, 0);
+            }
+        } else
         for (int it = 0; it < mfma_iters; ++it) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i], 0, 0, 0);
@@ -36,6 +53,7 @@ __global__ __launch_bounds__(512, 2) void k(const u32x4* __restrict__ src, u32x4
         for (int i = 0; i < 4; ++i) for (int r = 0; r < 16; ++r) s += acc[i][r];
         if (s == 12345.678f) sink[tid] = s;
     } else {
+        if (ldsfrag && (mode & 1)) __builtin_amdgcn_s_barrier();
         if (!(mode & 2)) return;
         if (prio == 1) __builtin_amdgcn_s_setprio(3);
         const size_t bidx = split ? (blockIdx.x >> 1) : blockIdx.x;
@@ -68,16 +86,17 @@ int main(int argc, char** argv) {
     hipMemset(src, 1, bytes);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const char* names[] = {"thin partner, dense MFMA", "even/odd CUs", "thin partner, MFMA 50% duty", "VALU x8 partner", "VALU x8 partner, partner prio 3",
-                           "VALU x8 partner, MFMA prio 3", "VALU x32 partner", "VALU x32 partner, partner prio 3"};
-    for (int cfg = 0; cfg < 8; ++cfg)
+                           "VALU x8 partner, MFMA prio 3", "VALU x32 partner", "VALU x32 partner, partner prio 3", "MFMA reads LDS frags, thin partner", "MFMA reads LDS frags, partner via LDS"};
+    for (int cfg = 0; cfg < 10; ++cfg)
         for (int mode = 1; mode <= 3; ++mode) {
-            const int via = 0, split = cfg == 1, duty = cfg == 2;
-            const int valu = cfg >= 6 ? 32 : (cfg >= 3 ? 8 : 0), prio = (cfg == 4 || cfg == 7) ? 1 : (cfg == 5 ? 2 : 0);
-            if (mode == 1 && cfg >= 3 && cfg != 5) continue;
+            const int via = cfg == 9, split = cfg == 1, duty = cfg == 2, ldsfrag = cfg >= 8;
+            const int valu = cfg >= 8 ? 0 : cfg >= 6 ? 32 : (cfg >= 3 ? 8 : 0), prio = (cfg == 4 || cfg == 7) ? 1 : (cfg == 5 ? 2 : 0);
+            if (mode == 1 && cfg >= 3 && cfg != 5 && cfg != 8) continue;
             float best = 1e30f;
             for (int rep = 0; rep < 4; ++rep) {
                 hipEventRecord(e0);
-                hipLaunchKernelGGL(k<0>, dim3(ncu), dim3(512), 16384, 0, src, dst, vec_per_block, iters, mode, sink, split, duty, valu, prio);
+                if (via) hipLaunchKernelGGL(k<1>, dim3(ncu), dim3(512), 65536, 0, src, dst, vec_per_block, iters, mode, sink, split, duty, valu, prio, ldsfrag);
+                else     hipLaunchKernelGGL(k<0>, dim3(ncu), dim3(512), 65536, 0, src, dst, vec_per_block, iters, mode, sink, split, duty, valu, prio, ldsfrag);
                 hipEventRecord(e1); hipEventSynchronize(e1);
                 float ms; hipEventElapsedTime(&ms, e0, e1);
                 if (rep && ms < best) best = ms;

@@ -43,6 +43,13 @@ template <int NW> struct Shape {
     static constexpr int ST_IN = IN_VEC > 2 * IN_VEC3 ? IN_VEC : 2 * IN_VEC3;
 };
 
+// Diagnostic in-kernel stamps (WSU_CONV_ABLATE bit 512; never in production): s_memtime per phase of the first 2048
+// workgroups, read back with wsu_debug_read_stamps().  Values go to a buffer nothing else reads.
+#define WSU_NSTAMP 32
+__device__ unsigned long long g_stamps[2048 * WSU_NSTAMP];
+#define WSU_STAMP(k) do { if ((a.ablate & 512) && blockIdx.x < 2048 && threadIdx.x == 0) \
+        g_stamps[blockIdx.x * WSU_NSTAMP + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+
 struct ConvArgs {
     const char* x1; const char* x2; const char* wp; const float* bias;
     char* y; char* y2; char* ypool; uint8_t* pidx; const char* relu_mask; const char* relu_mask2;
@@ -176,12 +183,17 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv3x3_kernel(const ConvArgs
     const char* ldsA = smem + LDS_IN + (mbase + l31) * 16;           // + ((tap*4+g)*64 + mt*32)*16
     const char* ldsB = smem + ((2 * rowpair) * IW + l31) * 16;       // + g*PLANE_IN + ((nt+dy)*IW + dx)*16
 
+    WSU_STAMP(0);
     stage_load<MODE, NW>(a, cb, 0, tid, pixidx, st_in, st_w);
+    WSU_STAMP(1);
     for (int c = 0; c < a.nch; ++c) {
         __syncthreads();
+        if (c < 6) WSU_STAMP(2 + 4 * c);
         if (!(a.ablate & 2) || c == 0) stage_commit<MODE, NW>(smem, tid, pixidx, ldsoff, st_in, st_w);
         __syncthreads();
+        if (c < 6) WSU_STAMP(3 + 4 * c);
         if (c + 1 < a.nch && !(a.ablate & 1)) stage_load<MODE, NW>(a, cb, c + 1, tid, pixidx, st_in, st_w);
+        if (c < 6) WSU_STAMP(4 + 4 * c);
         if (a.ablate & 4) continue;                                     // no LDS fragment reads, no MFMA
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
@@ -229,10 +241,12 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv3x3_kernel(const ConvArgs
                 }
             }
         }
+        if (c < 6) WSU_STAMP(5 + 4 * c);
     }
 
     // ---- epilogue: accumulators -> [pixel][channel] LDS tile ---------------------------------------
     __syncthreads();
+    WSU_STAMP(26);
     constexpr int STRIDE = Epi<MODE>::STRIDE;
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
@@ -326,6 +340,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv3x3_kernel(const ConvArgs
         }
     }
 
+    WSU_STAMP(27);
     // ---- fused 2x2/2 max-pool with first-max-wins argmax ------------------------------------------------
     if (a.ypool) {
         const int hp = a.h >> 1, wp2 = a.w >> 1;
@@ -683,8 +698,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const ConvArgs a) {
         pp_plan<MODE>(a, cur, gt, pixidx);
         pp_load<MODE>(a, 0, gt, pixidx, st_in);
     }
+    const int lag = (a.ablate & 256) ? 0 : grp;          // experiment: 256 = both groups in phase
     for (int i = 0; i <= 2 * J + 1; ++i) {
-        const int ph = i - grp;
+        const int ph = i - lag;
         if (ph >= 0) {
             const int j = ph >> 1;
             if (!(ph & 1)) {
@@ -842,6 +858,12 @@ int pack_impl(const float* w, void* dst, int cin, int cout, int mode, int tf, vo
 }  // namespace
 
 extern "C" {
+
+// diagnostic only (not part of include/wsu.h): copy the in-kernel stamps of the last conv3x3 v1 launch to the host
+int wsu_debug_read_stamps(unsigned long long* host_dst, int nblocks) {
+    if (nblocks > 2048) nblocks = 2048;
+    return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_stamps), (size_t)nblocks * WSU_NSTAMP * sizeof(unsigned long long)) == hipSuccess ? 0 : -2;
+}
 
 size_t wsu_conv3x3_packed_bytes(int cin, int cout, int mode) {
     if (cin <= 0 || cout <= 0 || mode < 0 || mode > 2) return 0;
