@@ -35,3 +35,8 @@ last = 5 + 4 * (min(nch, 6) - 1)
 print(f"epilogue: acc->LDS+barrier {med(rel[:,26]-rel[:,last]):8.0f}  stores {med(rel[:,27]-rel[:,26]):8.0f}   total/block {med(rel[:,27]):8.0f}")
 # concurrency: blocks sorted by start; how many blocks start within the first block's lifetime
 print("block lifetimes: median", med(rel[:, 27]), " p10", float(np.percentile(rel[:, 27], 10)), " p90", float(np.percentile(rel[:, 27], 90)))
+
+real = (st[:, 31] - st[:, 30]).astype(np.float64)          # 100 MHz ticks
+cyc = (st[:, 27] - st[:, 0]).astype(np.float64)
+ok = real > 0
+print(f"in-kernel clock (s_memtime / s_memrealtime x 100 MHz): median {np.median(cyc[ok] / real[ok]) * 0.1:.3f} GHz")

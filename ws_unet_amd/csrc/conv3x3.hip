@@ -184,6 +184,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv3x3_kernel(const ConvArgs
     const char* ldsB = smem + ((2 * rowpair) * IW + l31) * 16;       // + g*PLANE_IN + ((nt+dy)*IW + dx)*16
 
     WSU_STAMP(0);
+    if ((a.ablate & 512) && blockIdx.x < 2048 && threadIdx.x == 0) g_stamps[blockIdx.x * WSU_NSTAMP + 30] = __builtin_amdgcn_s_memrealtime();
     stage_load<MODE, NW>(a, cb, 0, tid, pixidx, st_in, st_w);
     WSU_STAMP(1);
     for (int c = 0; c < a.nch; ++c) {
@@ -341,6 +342,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv3x3_kernel(const ConvArgs
     }
 
     WSU_STAMP(27);
+    if ((a.ablate & 512) && blockIdx.x < 2048 && threadIdx.x == 0) g_stamps[blockIdx.x * WSU_NSTAMP + 31] = __builtin_amdgcn_s_memrealtime();
     // ---- fused 2x2/2 max-pool with first-max-wins argmax ------------------------------------------------
     if (a.ypool) {
         const int hp = a.h >> 1, wp2 = a.w >> 1;
