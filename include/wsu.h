@@ -130,11 +130,12 @@ int wsu_conv3x3_bwd_data(const void* g, const void* w_packed_dgrad, const float*
                          void* dx1, void* dx2, int csplit, const void* relu_mask1, const void* relu_mask2,
                          int n, int h, int w, int cin, int cout, int mode, void* stream);
 
-/* dW (OIHW, Cout x (c1+c2) x 3 x 3) and db (Cout, optional) of conv3x3-reflect on cat[x1, x2]; exact fp32 MFMA. */
+/* dW (OIHW, Cout x (c1+c2) x 3 x 3) and db (Cout, optional) of conv3x3-reflect on cat[x1, x2]: exact fp32 MFMA (mode F32) or
+ * split-bf16 MFMA fed by transposing LDS reads (mode BF16X3); db is always an exact fp32 sum. */
 size_t wsu_wgrad_workspace_bytes(int cm, int cn, int ntaps);
 int wsu_conv3x3_bwd_weight(const float* g, const float* x1, const float* x2, float* dw, float* db,
                            float* workspace, size_t workspace_bytes,
-                           int n, int h, int w, int c1, int c2, int cout, void* stream);
+                           int n, int h, int w, int c1, int c2, int cout, int mode /* F32 exact | BF16X3 */, void* stream);
 
 /* first layer: dW (Cout x cin x 3 x 3), db from g (N,H,W,Cout) and the NCHW fp32 input planes. */
 size_t wsu_first_bwd_workspace_bytes(int n, int h, int w, int cin, int cout);
@@ -147,7 +148,7 @@ int wsu_conv3x3_first_bwd_data(const float* g, const float* w_oihw, float* dx_nc
 /* transposed conv: dW (Cin x Cout x 2 x 2), db (Cout, optional) from x (N,h,w,Cin) and dy (N,2h,2w,Cout) ... */
 int wsu_convt2x2_bwd_weight(const float* x, const float* dy, float* dw, float* db,
                             float* workspace, size_t workspace_bytes,
-                            int n, int h, int w, int cin, int cout, void* stream);
+                            int n, int h, int w, int cin, int cout, int mode, void* stream);
 /* ... and dx (N,h,w,Cin), optionally masked by the saved post-ReLU activation of the producing layer. */
 size_t wsu_convt2x2_packed_dgrad_bytes(int cin, int cout, int mode);
 int wsu_convt2x2_pack_dgrad(const float* w_iohw, void* w_packed, int cin, int cout, int mode, void* stream);

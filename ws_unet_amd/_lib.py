@@ -51,11 +51,11 @@ SIGNATURES = {
     # ---- backward / train step
     "wsu_conv3x3_bwd_data": (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, _P] + [c_int] * 6 + [_P]),
     "wsu_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
-    "wsu_conv3x3_bwd_weight": (c_int, [_P, _P, _P, _P, _P, _P, c_size_t] + [c_int] * 6 + [_P]),
+    "wsu_conv3x3_bwd_weight": (c_int, [_P, _P, _P, _P, _P, _P, c_size_t] + [c_int] * 7 + [_P]),
     "wsu_first_bwd_workspace_bytes": (c_size_t, [c_int] * 5),
     "wsu_conv3x3_first_bwd_weight": (c_int, [_P, _P, _P, _P, _P, c_size_t] + [c_int] * 5 + [_P]),
     "wsu_conv3x3_first_bwd_data": (c_int, [_P, _P, _P] + [c_int] * 5 + [_P]),
-    "wsu_convt2x2_bwd_weight": (c_int, [_P, _P, _P, _P, _P, c_size_t] + [c_int] * 5 + [_P]),
+    "wsu_convt2x2_bwd_weight": (c_int, [_P, _P, _P, _P, _P, c_size_t] + [c_int] * 6 + [_P]),
     "wsu_convt2x2_packed_dgrad_bytes": (c_size_t, [c_int, c_int, c_int]),
     "wsu_convt2x2_pack_dgrad": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "wsu_convt2x2_bwd_data": (c_int, [_P, _P, _P, _P] + [c_int] * 6 + [_P]),

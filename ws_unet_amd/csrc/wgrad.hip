@@ -136,6 +136,130 @@ __global__ __launch_bounds__(NT, 2) void wgrad_kernel(const WgArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Split-bf16 variant (train_mode 'bf16x3'): same GEMM, operands split hi + lo bf16 while staging, 3 bf16 MFMAs per
+// product (lo*hi, hi*lo, hi*hi), fp32 accumulate -- ~3x the fp32-MFMA rate at ~2^-17 relative error.
+// The reduction index is the PIXEL, so each lane of v_mfma_f32_32x32x16_bf16 needs 8 consecutive pixels of ONE channel.
+// The LDS tiles stay row-major [pixel][64 ch] (coalesced 16-byte staging writes); the transposition is done by the
+// hardware: ds_read_b64_tr_b16 hands lane i of a 16-lane group column i of the 4 rows whose addresses the group's lanes
+// supplied (lane 4q+p -> row q, columns 4p..4p+3; semantics probed on the device: tools/probe_tr16.hip).  Two such reads
+// give the 8 k-values of a fragment.  Rows may be any pixels, so the stride-2 gather of the transposed conv is free.
+// ---------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+constexpr int X3_ROW = 144;                       // bytes per pixel row: 64 bf16 + 16 pad (16-byte aligned rows)
+
+template <int KIND> struct GeoX3 {
+    static constexpr int NTAPS = Geo<KIND>::NTAPS, TH = Geo<KIND>::TH, VH = Geo<KIND>::VH, VW = Geo<KIND>::VW;
+    static constexpr int U_PIX = TH * TW, V_PIX = VH * VW;
+    static constexpr int U_BYTES = U_PIX * X3_ROW, V_BYTES = V_PIX * X3_ROW;      // per hi / lo image
+    static constexpr int LDS = 2 * U_BYTES + 2 * V_BYTES;
+};
+
+// 8 k-values (pixels row0.., row step `rstep` pixels) of channel column `col0 + lane&15 (+16 for odd groups)`
+__device__ __forceinline__ u32x4 x3_frag(const char* img, int row0, int rstep, int colbyte) {
+    const int lane = threadIdx.x & 63, li = lane & 15, q = li >> 2, pp = li & 3;
+    const char* a0 = img + (row0 + q * rstep) * X3_ROW + colbyte + pp * 8;
+    const s16x4 r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a0);
+    const s16x4 r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 4 * rstep * X3_ROW));
+    const u32x2 lo = __builtin_bit_cast(u32x2, r0), hi = __builtin_bit_cast(u32x2, r1);
+    return mk_u4(lo.x, lo.y, hi.x, hi.y);
+}
+
+template <int KIND>
+__global__ __launch_bounds__(NT, 2) void wgrad_x3_kernel(const WgArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using G = GeoX3<KIND>;
+    constexpr int NTAPS = G::NTAPS, TH = G::TH, VH = G::VH, VW = G::VW;
+    char* u_hi = smem;
+    char* u_lo = smem + G::U_BYTES;
+    char* v_hi = smem + 2 * G::U_BYTES;
+    char* v_lo = v_hi + G::V_BYTES;
+
+    const int tid = threadIdx.x;
+    int b = blockIdx.x;
+    const int nb = b % a.nnb; b /= a.nnb;
+    const int mb = b % a.nmb;
+    const int split = b / a.nmb;
+    const int hv = KIND == 0 ? a.hu : 2 * a.hu, wv = KIND == 0 ? a.wu : 2 * a.wu;
+    const float* vsrc; int cv, vch0;
+    if (nb * 64 < a.cv1) { vsrc = a.v1; cv = a.cv1; vch0 = nb * 64; }
+    else                 { vsrc = a.v2; cv = a.cv2; vch0 = nb * 64 - a.cv1; }
+
+    const int wv_ = tid >> 6, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+    const int wm = wv_ >> 1, wn = wv_ & 1;
+    const int colA = (wm * 32 + ((lane >> 4) & 1) * 16) * 2;         // byte offset of this 16-lane group's channel block
+    const int colB = (wn * 32 + ((lane >> 4) & 1) * 16) * 2;
+    f32x16 acc[NTAPS];
+#pragma unroll
+    for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    const int t0 = split * a.tiles_per_split;
+    const int t1 = min(t0 + a.tiles_per_split, a.ntiles);
+    for (int tile = t0; tile < t1; ++tile) {
+        int tt = tile;
+        const int tx = tt % a.tiles_x; tt /= a.tiles_x;
+        const int ty = tt % a.tiles_y;
+        const int n = tt / a.tiles_y;
+        const int y0 = ty * TH, x0 = tx * TW;
+        __syncthreads();
+        // ---- stage: 8 fp32 channels per item -> bf16 hi row piece + bf16 lo row piece (16 B each)
+        for (int i = tid; i < G::U_PIX * 8; i += NT) {
+            const int p = i >> 3, cg = i & 7;
+            const int r = p / TW, c = p % TW;
+            u32x4 hi = mk_u4(0, 0, 0, 0), lo = hi;
+            if (y0 + r < a.hu && x0 + c < a.wu) {
+                const f32x4* src = reinterpret_cast<const f32x4*>(a.u + ((size_t)(n * a.hu + y0 + r) * a.wu + x0 + c) * a.cu + mb * 64 + cg * 8);
+                wsu_split8(src[0], src[1], hi, lo);
+            }
+            *reinterpret_cast<u32x4*>(u_hi + p * X3_ROW + cg * 16) = hi;
+            *reinterpret_cast<u32x4*>(u_lo + p * X3_ROW + cg * 16) = lo;
+        }
+        for (int i = tid; i < G::V_PIX * 8; i += NT) {
+            const int p = i >> 3, cg = i & 7;
+            const int r = p / VW, c = p % VW;
+            int yy, xx;
+            if (KIND == 0) { yy = wsu_reflect(y0 - 1 + r, hv); xx = wsu_reflect(x0 - 1 + c, wv); }
+            else           { yy = min(2 * y0 + r, hv - 1);     xx = min(2 * x0 + c, wv - 1); }
+            const f32x4* src = reinterpret_cast<const f32x4*>(vsrc + ((size_t)(n * hv + yy) * wv + xx) * cv + vch0 + cg * 8);
+            u32x4 hi, lo;
+            wsu_split8(src[0], src[1], hi, lo);
+            *reinterpret_cast<u32x4*>(v_hi + p * X3_ROW + cg * 16) = hi;
+            *reinterpret_cast<u32x4*>(v_lo + p * X3_ROW + cg * 16) = lo;
+        }
+        __syncthreads();
+        // ---- MFMA: k-steps of 16 pixels along a tile row
+#pragma unroll
+        for (int r = 0; r < TH; ++r) {
+#pragma unroll
+            for (int c0 = 0; c0 < TW; c0 += 16) {
+                const int up = r * TW + c0 + 8 * hh;                                    // first U pixel of this lane half
+                const u32x4 ahi = x3_frag(u_hi, up, 1, colA), alo = x3_frag(u_lo, up, 1, colA);
+#pragma unroll
+                for (int t = 0; t < NTAPS; ++t) {
+                    int vp, vstep;
+                    if (KIND == 0) { vp = (r + t / 3) * VW + c0 + 8 * hh + t % 3; vstep = 1; }
+                    else           { vp = (2 * r + (t >> 1)) * VW + 2 * (c0 + 8 * hh) + (t & 1); vstep = 2; }
+                    const u32x4 bhi = x3_frag(v_hi, vp, vstep, colB), blo = x3_frag(v_lo, vp, vstep, colB);
+                    wsu_mfma_step<WSU_MODE_BF16X3>(alo, bhi, acc[t]);
+                    wsu_mfma_step<WSU_MODE_BF16X3>(ahi, blo, acc[t]);
+                    wsu_mfma_step<WSU_MODE_BF16X3>(ahi, bhi, acc[t]);
+                }
+            }
+        }
+    }
+    float* dst = a.part + ((size_t)((split * a.nmb + mb) * a.nnb + nb) * NTAPS) * 4096;
+#pragma unroll
+    for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            dst[(size_t)t * 4096 + m * 64 + wn * 32 + l31] = acc[t][r];
+        }
+}
+
 // dW (conv: OIHW [M = co][Ntot = ci][3][3]; convT: IOHW [M = ci][Ntot = co][2][2]) = sum over splits, fixed order
 template <int KIND>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bpart,
@@ -187,7 +311,7 @@ __global__ void colsum_final_kernel(const float* __restrict__ part, float* __res
 }
 
 template <int KIND>
-int run_wgrad(WgArgs a, float* dw, float* db, float* workspace, size_t workspace_bytes, hipStream_t s) {
+int run_wgrad(WgArgs a, float* dw, float* db, float* workspace, size_t workspace_bytes, hipStream_t s, bool x3 = false) {
     using G = Geo<KIND>;
     a.tiles_x = (a.wu + TW - 1) / TW; a.tiles_y = (a.hu + G::TH - 1) / G::TH;
     a.ntiles = a.n * a.tiles_x * a.tiles_y;
@@ -205,7 +329,20 @@ int run_wgrad(WgArgs a, float* dw, float* db, float* workspace, size_t workspace
     a.nsplit = nsplit;
     a.tiles_per_split = (a.ntiles + nsplit - 1) / nsplit;
     a.part = workspace;
-    a.bpart = db ? workspace + (size_t)nsplit * slab / sizeof(float) : nullptr;
+    a.bpart = (db && !x3) ? workspace + (size_t)nsplit * slab / sizeof(float) : nullptr;
+    if (x3) {
+        static bool attr_x3 = false;
+        if (!attr_x3) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_x3_kernel<KIND>), hipFuncAttributeMaxDynamicSharedMemorySize, GeoX3<KIND>::LDS);
+            if (e != hipSuccess) { wsu_set_error("hipFuncSetAttribute(wgrad_x3): %s", hipGetErrorString(e)); return WSU_ERR_HIP; }
+            attr_x3 = true;
+        }
+        hipLaunchKernelGGL(wgrad_x3_kernel<KIND>, dim3(nsplit * a.nmb * a.nnb), dim3(NT), GeoX3<KIND>::LDS, s, a);
+        int rc = wsu_check_launch("wgrad_x3_kernel");
+        if (rc) return rc;
+        hipLaunchKernelGGL(wgrad_reduce_kernel<KIND>, dim3(512), dim3(256), 0, s, a.part, (const float*)nullptr, dw, (float*)nullptr, nsplit, a.nmb, a.nnb);
+        return wsu_check_launch("wgrad_reduce_kernel");
+    }
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<KIND>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
@@ -231,39 +368,47 @@ size_t wsu_wgrad_workspace_bytes(int cm, int cn, int ntaps) {
     return nsplit * (nmb * nnb * ntaps * 4096 + nmb * 64) * sizeof(float);
 }
 
+static int colsum_channels(const float* x, float* out, float* workspace, size_t workspace_bytes, long long npix, int c, hipStream_t s) {
+    const int chunk = 4096;
+    const int nchunks = (int)((npix + chunk - 1) / chunk);
+    WSU_REQUIRE((size_t)nchunks * c * sizeof(float) <= workspace_bytes, "bias reduction: workspace too small");
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nchunks, c / 64), dim3(256), 0, s, x, workspace, npix, c, chunk);
+    int rc = wsu_check_launch("colsum_partial_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((c + 63) / 64), dim3(64), 0, s, workspace, out, nchunks, c);
+    return wsu_check_launch("colsum_final_kernel");
+}
+
 int wsu_conv3x3_bwd_weight(const float* g, const float* x1, const float* x2, float* dw, float* db,
                            float* workspace, size_t workspace_bytes,
-                           int n, int h, int w, int c1, int c2, int cout, void* stream) {
+                           int n, int h, int w, int c1, int c2, int cout, int mode, void* stream) {
+    WSU_REQUIRE(mode == WSU_MODE_F32 || mode == WSU_MODE_BF16X3, "conv3x3_bwd_weight: mode must be f32 or bf16x3");
     WSU_REQUIRE(g && x1 && dw && workspace, "conv3x3_bwd_weight: null pointer");
     WSU_REQUIRE(n > 0 && h >= 2 && w >= 2, "conv3x3_bwd_weight: bad shape");
     WSU_REQUIRE(c1 > 0 && c1 % 64 == 0 && c2 >= 0 && c2 % 64 == 0 && (c2 == 0) == (x2 == nullptr), "conv3x3_bwd_weight: c1=%d c2=%d must be multiples of 64", c1, c2);
     WSU_REQUIRE(cout > 0 && cout % 64 == 0, "conv3x3_bwd_weight: cout=%d must be a multiple of 64", cout);
     WgArgs a{};
     a.u = g; a.v1 = x1; a.v2 = x2; a.n = n; a.hu = h; a.wu = w; a.cu = cout; a.cv1 = c1; a.cv2 = c2;
-    return run_wgrad<0>(a, dw, db, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (mode == WSU_MODE_F32) return run_wgrad<0>(a, dw, db, workspace, workspace_bytes, s);
+    int rc = run_wgrad<0>(a, dw, nullptr, workspace, workspace_bytes, s, true);
+    if (rc || !db) return rc;
+    return colsum_channels(g, db, workspace, workspace_bytes, (long long)n * h * w, cout, s);     // exact fp32 bias gradient
 }
 
 int wsu_convt2x2_bwd_weight(const float* x, const float* dy, float* dw, float* db,
                             float* workspace, size_t workspace_bytes,
-                            int n, int h, int w, int cin, int cout, void* stream) {
+                            int n, int h, int w, int cin, int cout, int mode, void* stream) {
+    WSU_REQUIRE(mode == WSU_MODE_F32 || mode == WSU_MODE_BF16X3, "convt2x2_bwd_weight: mode must be f32 or bf16x3");
     WSU_REQUIRE(x && dy && dw && workspace, "convt2x2_bwd_weight: null pointer");
     WSU_REQUIRE(n > 0 && h > 0 && w > 0, "convt2x2_bwd_weight: bad shape");
     WSU_REQUIRE(cin > 0 && cin % 64 == 0 && cout > 0 && cout % 64 == 0, "convt2x2_bwd_weight: cin=%d cout=%d must be multiples of 64", cin, cout);
     WgArgs a{};
     a.u = x; a.v1 = dy; a.v2 = nullptr; a.n = n; a.hu = h; a.wu = w; a.cu = cin; a.cv1 = cout; a.cv2 = 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    int rc = run_wgrad<1>(a, dw, nullptr, workspace, workspace_bytes, s);
+    int rc = run_wgrad<1>(a, dw, nullptr, workspace, workspace_bytes, s, mode == WSU_MODE_BF16X3);
     if (rc || !db) return rc;
-    // db[co] = sum over all output pixels of dy (two-stage, fixed order)
-    const long long npix = (long long)n * h * w * 4;
-    const int chunk = 4096;
-    int nchunks = (int)((npix + chunk - 1) / chunk);
-    WSU_REQUIRE((size_t)nchunks * cout * sizeof(float) <= workspace_bytes, "convt2x2_bwd_weight: workspace too small for the bias reduction");
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nchunks, cout / 64), dim3(256), 0, s, dy, workspace, npix, cout, chunk);
-    rc = wsu_check_launch("colsum_partial_kernel");
-    if (rc) return rc;
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((cout + 63) / 64), dim3(64), 0, s, workspace, db, nchunks, cout);
-    return wsu_check_launch("colsum_final_kernel");
+    return colsum_channels(dy, db, workspace, workspace_bytes, (long long)n * h * w * 4, cout, s);   // db[co] = sum of dy
 }
 
 }  // extern "C"

@@ -4,7 +4,7 @@ The reference has no hand-written backward -- it relies on autograd through
 src/unet/model/unet.py:137-189.  Here the whole network is ONE autograd node: forward saves the NHWC
 activations (and 2-bit pool argmax), backward walks the layers in reverse calling the K7 kernels
 (include/wsu.h).  All activations stay fp32; `model.train_mode` picks the arithmetic of the forward /
-data-gradient GEMMs ('f32' exact, default, or 'bf16x3'); weight gradients are always exact fp32 MFMA.
+data-gradient / weight-gradient GEMMs ('f32' exact, default, or 'bf16x3' split-bf16); bias gradients are exact fp32 sums.
 The gradient w.r.t. the network input (saliency, src/saliency.py:159-174) is produced when `x.requires_grad`.
 
 Conventions inside backward: `g` is the PRE-activation gradient of the layer being processed; every kernel
@@ -73,7 +73,7 @@ class _UNetFn(torch.autograd.Function):
 
         def conv_bwd(name, g, x1, x2, mask1, mask2, need_dx=True):
             layer = getattr(model, name)
-            grads[name + ".weight"], grads[name + ".bias"] = ops.conv3x3_bwd_weight(g, x1, x2)
+            grads[name + ".weight"], grads[name + ".bias"] = ops.conv3x3_bwd_weight(g, x1, x2, mode=m)
             if not need_dx:
                 return None, None
             csplit = x1.shape[3]
@@ -88,7 +88,7 @@ class _UNetFn(torch.autograd.Function):
             dxu, skip_g[depth] = conv_bwd(c1, g, xu, skip, None, skip)           # upconv output has no ReLU; skip is masked
             below = t["x" + (dec_names(depth + 1)[2] if depth < model.nsteps else ENC[model.nsteps][1])]
             lu = getattr(model, up)
-            grads[up + ".weight"], grads[up + ".bias"] = ops.convt2x2_bwd_weight(below, dxu)
+            grads[up + ".weight"], grads[up + ".bias"] = ops.convt2x2_bwd_weight(below, dxu, mode=m)
             g = ops.convt2x2_bwd_data(dxu, model._packed(up, m, "convt_dgrad"), lu.in_channels, below, m)
         for lvl in range(model.nsteps, -1, -1):
             a, b = ENC[lvl]

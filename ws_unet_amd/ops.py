@@ -302,7 +302,7 @@ def conv3x3_bwd_data(g: torch.Tensor, w_packed_dgrad: torch.Tensor, w_oihw: torc
     return dx1, dx2
 
 
-def conv3x3_bwd_weight(g: torch.Tensor, x1: torch.Tensor, x2: Optional[torch.Tensor], want_bias: bool = True):
+def conv3x3_bwd_weight(g: torch.Tensor, x1: torch.Tensor, x2: Optional[torch.Tensor], want_bias: bool = True, mode: int = 0):
     lib = _lib.load()
     _dev_check(g, x1, x2)
     n, h, w, cout = g.shape
@@ -310,12 +310,12 @@ def conv3x3_bwd_weight(g: torch.Tensor, x1: torch.Tensor, x2: Optional[torch.Ten
     c2 = 0 if x2 is None else x2.shape[3]
     dw = torch.empty((cout, c1 + c2, 3, 3), dtype=torch.float32, device=g.device)
     db = torch.empty(cout, dtype=torch.float32, device=g.device) if want_bias else None
-    nbytes = lib.wsu_wgrad_workspace_bytes(cout, c1 + c2, 9)
+    nbytes = max(lib.wsu_wgrad_workspace_bytes(cout, c1 + c2, 9), (n * h * w + 4095) // 4096 * cout * 4)
     ws = workspace(nbytes, g.device)
     meta = {"flops": 2.0 * 9 * (c1 + c2) * cout * n * h * w}
     check(_launch("conv3x3_bwd_weight", meta, lambda: lib.wsu_conv3x3_bwd_weight(
         g.data_ptr(), x1.data_ptr(), _ptr(x2), dw.data_ptr(), _ptr(db), ws.data_ptr(), ws.numel() * 4,
-        n, h, w, c1, c2, cout, _stream())), "wsu_conv3x3_bwd_weight")
+        n, h, w, c1, c2, cout, mode, _stream())), "wsu_conv3x3_bwd_weight")
     return dw, db
 
 
@@ -346,7 +346,7 @@ def conv3x3_first_bwd_data(g: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
     return dx
 
 
-def convt2x2_bwd_weight(x: torch.Tensor, dy: torch.Tensor, want_bias: bool = True):
+def convt2x2_bwd_weight(x: torch.Tensor, dy: torch.Tensor, want_bias: bool = True, mode: int = 0):
     lib = _lib.load()
     _dev_check(x, dy)
     n, h, w, cin = x.shape
@@ -358,7 +358,7 @@ def convt2x2_bwd_weight(x: torch.Tensor, dy: torch.Tensor, want_bias: bool = Tru
     ws = workspace(nbytes, x.device)
     meta = {"flops": 2.0 * 4 * cin * cout * n * h * w}
     check(_launch("convt2x2_bwd_weight", meta, lambda: lib.wsu_convt2x2_bwd_weight(
-        x.data_ptr(), dy.data_ptr(), dw.data_ptr(), _ptr(db), ws.data_ptr(), ws.numel() * 4, n, h, w, cin, cout, _stream())),
+        x.data_ptr(), dy.data_ptr(), dw.data_ptr(), _ptr(db), ws.data_ptr(), ws.numel() * 4, n, h, w, cin, cout, mode, _stream())),
         "wsu_convt2x2_bwd_weight")
     return dw, db
 
