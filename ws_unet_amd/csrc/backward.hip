@@ -538,9 +538,15 @@ int wsu_convt2x2_bwd_data(const void* dy, const void* w_packed_dgrad, void* dx, 
     return wsu_check_launch("convt2x2_bwd_data_kernel");
 }
 
+static int first_bwd_chunk(long long npix) {                  // ~1024 chunks whatever the batch, at least 2048 pixels each
+    const long long c = (npix + 1023) / 1024;
+    return (int)(c < 2048 ? 2048 : c);
+}
+
 size_t wsu_first_bwd_workspace_bytes(int n, int h, int w, int cin, int cout) {
     const long long npix = (long long)n * h * w;
-    const long long nchunks = (npix + 2047) / 2048;
+    const int chunk = first_bwd_chunk(npix);
+    const long long nchunks = (npix + chunk - 1) / chunk;
     return (size_t)nchunks * (cin * 9 + 1) * cout * sizeof(float);
 }
 
@@ -549,7 +555,7 @@ int wsu_conv3x3_first_bwd_weight(const float* g, const float* x_nchw, float* dw,
     WSU_REQUIRE(g && x_nchw && dw && workspace, "conv3x3_first_bwd_weight: null pointer");
     WSU_REQUIRE(n > 0 && h >= 2 && w >= 2 && cin >= 1 && cin <= 8 && cout % 64 == 0, "conv3x3_first_bwd_weight: bad shape");
     const long long npix = (long long)n * h * w;
-    const int chunk = 2048;
+    const int chunk = first_bwd_chunk(npix);
     const int nchunks = (int)((npix + chunk - 1) / chunk);
     WSU_REQUIRE(wsu_first_bwd_workspace_bytes(n, h, w, cin, cout) <= workspace_bytes, "conv3x3_first_bwd_weight: workspace too small");
     hipStream_t s = static_cast<hipStream_t>(stream);

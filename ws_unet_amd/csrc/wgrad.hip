@@ -369,7 +369,9 @@ size_t wsu_wgrad_workspace_bytes(int cm, int cn, int ntaps) {
 }
 
 static int colsum_channels(const float* x, float* out, float* workspace, size_t workspace_bytes, long long npix, int c, hipStream_t s) {
-    const int chunk = 4096;
+    // ~1024 pixel chunks whatever the batch: the final kernel walks them serially per channel
+    long long chunk_ll = (npix + 1023) / 1024;
+    const int chunk = (int)(chunk_ll < 4096 ? 4096 : chunk_ll);
     const int nchunks = (int)((npix + chunk - 1) / chunk);
     WSU_REQUIRE((size_t)nchunks * c * sizeof(float) <= workspace_bytes, "bias reduction: workspace too small");
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(nchunks, c / 64), dim3(256), 0, s, x, workspace, npix, c, chunk);
