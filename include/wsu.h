@@ -112,6 +112,28 @@ int wsu_uniform_dropout_fwd(const float* x, float* y, const float* mask, float* 
 int wsu_ws_residual_stats(const uint8_t* x_u8, const float* y01, float* beta_hat, float* l1,
                           int n, int h, int w, void* stream);
 
+/* ---- K11: weighted-stego payload estimate of the predictor's caller, src/ws/estimate.py:55-136 `attack`, batched.
+ *      x_u8: (N,H,W) DEVICE pixels of the analysed plane.  The pixel prediction is either
+ *        x_hat (DEVICE fp32): hat_full=1 -> (N,H,W), interior read at [r][c] (a network output; hat_scale = 255),
+ *                             hat_full=0 -> (N,H-2,W-2) (what `pixel_estimator(x)` returns; hat_scale = 1), or
+ *        pixel_filter (HOST, 9 floats K[a][b] of the reference's (3,3,1) kernel array, filters/evaluate.py:30-50,136-141):
+ *                             x_hat = convolve(x/255, K, 'valid')*255 evaluated inside the kernel.
+ *      mean_filter (HOST, 9 floats, same layout; NAMED_FILTERS['AVG'] by default, estimate.py:60,93-95) feeds the local
+ *      variance for weighted = 1 (1/(5+var)) or -1 (5+var); weighted = 0 -> uniform weights (:97-110).
+ *      correct_bias (:126-128) needs x_bias = pixel_estimator(x_bar - x) in x_hat's layout (not with pixel_filter).
+ *      beta_hat: (N) fp32, clipped at 0 (:121); sums: optional (N,3) fp64 {sum w, sum w*s*(x-x_hat), sum w*s*x_bias}. */
+size_t wsu_ws_attack_workspace_bytes(int n);
+int wsu_ws_attack(const uint8_t* x_u8, const float* x_hat, const float* x_bias, const float* pixel_filter, const float* mean_filter,
+                  int hat_full, float hat_scale, int weighted, int correct_bias, float* beta_hat, double* sums,
+                  void* workspace, size_t workspace_bytes, int n, int h, int w, void* stream);
+
+/* Linear pixel predictor on its own (filters/evaluate.py:136-141): y (N,H-2,W-2) = convolve(x/255., K, 'valid')*255.
+ * x: DEVICE (N,H,W) fp32; filter: HOST 9 floats K[a][b]. */
+int wsu_filter3x3_valid_f32(const float* x, const float* filter, float* y, int n, int h, int w, void* stream);
+
+/* (x ^ 1 - x) / 255. as fp32: the network input of the bias term `pixel_estimator(x_bar - x)` (estimate.py:127, evaluate.py:45) */
+int wsu_lsb_delta_unit_f32(const uint8_t* x, float* y, size_t count, void* stream);
+
 /* ---- u8 -> [0,1] fp32, numpy float32 division semantics of evaluate.py:45 (x / 255.) */
 int wsu_u8_to_unit_f32(const uint8_t* x, float* y, size_t count, void* stream);
 
@@ -166,7 +188,8 @@ int wsu_conv1x1_sigmoid_bwd(const float* x, const float* w, const float* out, co
                             float* gx, float* dw, float* db, float* workspace, size_t workspace_bytes,
                             int n, int h, int w_, int c, int cout, int apply_relu_mask, void* stream);
 
-/* K8: L1 + WS loss and dLoss/dout in one call (losses.py:33-36,47-89,99-116). */
+/* K8: L1 + WS loss and dLoss/dout in one call (losses.py:33-36,47-89,99-116).
+ * use_l1: 0 = off, 1 = mean |covers - out| (L1Loss), 2 = mean (covers - out)^2 (L2Loss, losses.py:39-42). */
 size_t wsu_l1ws_loss_workspace_bytes(int n);
 int wsu_l1ws_loss_fwd_bwd(const float* out, const float* covers, const float* inputs, const float* alphas,
                           float* loss, float* loss_parts, float* dout, float* beta_hat, void* workspace, size_t workspace_bytes,

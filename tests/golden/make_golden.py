@@ -10,6 +10,8 @@ What is imported from the reference:
   * src/_defs/losses.py       -> L1Loss / WSLoss / L1WSLoss          (by file path; a dummy `timm` module is
   * src/_defs/metrics.py      -> MAEMeter / WSMeter                   registered because losses.py:2 imports it unused)
   * src/fabrika.py            -> precovers / stego_spatial iterate
+  * src/ws/estimate.py        -> attack, NAMED_FILTERS;  src/filters/evaluate.py -> get_filter_estimator;
+    src/_defs/filters.py      -> get_processor_2d                    (placeholders for seaborn/conseal/_defs/unet, see gen_ws_attack)
 Everything written is DATA (inputs are formula-generated, see ws_unet_amd/formula.py;
 outputs are arrays / JSON).  No reference source text is stored.
 """
@@ -316,6 +318,74 @@ def gen_png_kat():
     os.chmod(HERE / "cover_10.png", 0o644)
 
 
+def cross_mean(x):
+    """Host pixel predictor used for the 'arbitrary callable' WS cases (repeated in tests/test_gpu_ws_attack.py)."""
+    return ((x[:-2, 1:-1] + x[2:, 1:-1] + x[1:-1, :-2] + x[1:-1, 2:]) * np.float32(0.25))[..., :1]
+
+
+def gen_ws_attack(out):
+    """Run the reference's own `attack` (src/ws/estimate.py:55-136) and linear predictors (src/filters/evaluate.py).
+    Modules those files import at the top but do not use in these functions, and that are absent here (seaborn, conseal)
+    or pull in cv2/torchvision (_defs, unet), are registered as empty placeholders for the duration of the import."""
+    saved = {k: sys.modules.get(k) for k in ("seaborn", "conseal", "_defs", "filters", "unet")}
+    try:
+        for k in ("seaborn", "conseal", "filters", "unet"):
+            sys.modules[k] = types.ModuleType(k)
+        ref_defs_filters = load_by_path("ref_defs_filters", REF / "src" / "_defs" / "filters.py")
+        d = types.ModuleType("_defs")
+        d.imread4_u8 = d.imread4_f32 = None                      # only default-argument values at def time
+        d.get_processor_2d = ref_defs_filters.get_processor_2d
+        sys.modules["_defs"] = d
+        ref_filters = load_by_path("ref_filters_evaluate", REF / "src" / "filters" / "evaluate.py")
+        ref_ws = load_by_path("ref_ws_estimate", REF / "src" / "ws" / "estimate.py")
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    process = ref_defs_filters.get_processor_2d(channels=(3,))
+
+    def run_attack(plane_u8, est, **kw):
+        img4 = np.repeat(plane_u8[..., None], 4, axis=-1)        # what imread4_u8 returns for a gray PNG
+        r = ref_ws.attack("mem", channels=(3,), pixel_estimator=est, imread=lambda f: img4, process_image=process, **kw)
+        return np.float64(r["beta_hat"])
+
+    # --- 64x64: linear predictors of the reference + an arbitrary host callable
+    cov = formula.synthetic_images(3, 64, 64, seed=51)
+    planes = [cov[0], formula.lsbr_embed(cov[1], 0.4, seed=3), formula.lsbr_embed(cov[2], 1.0, seed=4)]
+    ests = {"KB": ref_filters.get_filter_estimator(filter_name="KB", flatten=False),
+            "AVG": ref_filters.get_filter_estimator(filter_name="AVG", flatten=False),
+            "cross": cross_mean}
+    cfgs = [(w, cb) for w in (1, 0, -1) for cb in (False, True)]
+    out["cfgs"] = np.array([[w, int(cb)] for w, cb in cfgs])
+    for name, est in ests.items():
+        out[f"beta64_{name}"] = np.array([[run_attack(p, est, weighted=w, correct_bias=cb) for w, cb in cfgs] for p in planes])
+    out["beta64_KB_meanAVG9"] = np.array([run_attack(p, ests["KB"], weighted=1, mean_estimator=ref_ws.NAMED_FILTERS["AVG9"])
+                                          for p in planes])
+    out["filter64_KB"] = ests["KB"](process(np.repeat(planes[1][..., None], 4, axis=-1)))[..., 0]
+    for k in ("KB", "AVG", "AVG9", "1"):
+        out[f"named_{k}"] = ref_ws.NAMED_FILTERS[k]
+        out[f"named2d_{k}"] = ref_filters.NAMED_FILTERS_2D[k]
+    # --- 512x512: the UNet predictor (formula 'he' weights), x/255 -> net -> *255 -> crop as in unet/evaluate.py:45-51
+    m = ref_model(2, "he"); m.input_dropout = None
+    memo = {}
+
+    def unet_est(x):
+        key = x.tobytes()
+        if key not in memo:
+            with torch.no_grad():
+                y = m(torch.from_numpy(np.ascontiguousarray((x / 255.).transpose(2, 0, 1)))[None])
+            memo[key] = (y.numpy()[0, 0, 1:-1, 1:-1] * 255.)[..., None]
+        return memo[key]
+
+    c512 = formula.synthetic_images(1, 512, 512, seed=7)[0]
+    p512 = [c512, formula.lsbr_embed(c512, 0.4, seed=5)]
+    cfg512 = [(1, False), (0, False), (1, True), (0, True)]
+    out["cfg512"] = np.array([[w, int(cb)] for w, cb in cfg512])
+    out["beta512_unet"] = np.array([[run_attack(p, unet_est, weighted=w, correct_bias=cb) for w, cb in cfg512] for p in p512])
+
+
 def main():
     sys.modules.setdefault("timm", types.ModuleType("timm"))
     losses = load_by_path("ref_losses", REF / "src" / "_defs" / "losses.py")
@@ -330,6 +400,7 @@ def main():
         "micro": lambda o: gen_micro(o),
         "losses": lambda o: gen_losses(o, losses, metrics),
         "adamw": lambda o: gen_adamw(o, losses),
+        "ws_attack": lambda o: gen_ws_attack(o),
     }
     only = sys.argv[1:]
     for name, fn in groups.items():

@@ -124,12 +124,12 @@ def _loss_inputs():
 def test_losses_golden(golden):
     g = golden["losses"]
     covers, inputs, alphas = _loss_inputs()
-    for i, (name, cls) in enumerate([("l1", losses.L1Loss), ("ws", losses.WSLoss), ("l1ws", losses.L1WSLoss)]):
+    for i, (name, cls) in enumerate([("l1", losses.L1Loss), ("l2", losses.L2Loss), ("ws", losses.WSLoss), ("l1ws", losses.L1WSLoss)]):
         outputs = torch.from_numpy(g["loss_outputs"]).to(DEV).requires_grad_(True)
         crit = cls()
         v = crit(outputs, (covers.to(DEV), alphas.to(DEV)), inputs.to(DEV))
         v.backward()
-        ref = float(g["loss_values"][{"l1": 0, "ws": 2, "l1ws": 3}[name]])
+        ref = float(g["loss_values"][{"l1": 0, "l2": 1, "ws": 2, "l1ws": 3}[name]])
         assert math.isclose(v.item(), ref, rel_tol=2e-6), name
         np.testing.assert_allclose(outputs.grad.cpu().numpy(), g[f"loss_{name}_dout"], rtol=1e-5, atol=1e-10, err_msg=name)
     with pytest.raises(NotImplementedError):

@@ -233,3 +233,39 @@ def test_ws_stats_and_png_kat():
     assert beta == 0.0 and l1 == 0.0
     beta, l1 = np_ops.ws_stats(x[1:-1, 1:-1], (x[1:-1, 1:-1] ^ 1).astype(np.float32))
     assert beta == 1.0 and l1 == 1.0
+
+
+# ---- WS payload estimator: oracle vs the reference's own attack() ------------------------------
+
+def _ws_planes64():
+    cov = formula.synthetic_images(3, 64, 64, seed=51)
+    return [cov[0], formula.lsbr_embed(cov[1], 0.4, seed=3), formula.lsbr_embed(cov[2], 1.0, seed=4)]
+
+
+def _cross_mean(x):
+    return ((x[:-2, 1:-1] + x[2:, 1:-1] + x[1:-1, :-2] + x[1:-1, 2:]) * np.float32(0.25))[..., :1]
+
+
+def test_ws_attack_oracle_vs_reference(golden):
+    """The reference evaluates its 3x3 convolutions through scipy's float32 FFT branch, so agreement is to FFT round-off
+    (rel 2e-4 / abs 2e-5), not bitwise; see oracle/ws_ref.py."""
+    from oracle import ws_ref
+    from ws_unet_amd import filters
+    g = golden["ws_attack"]
+    for k in ("KB", "AVG", "AVG9", "1"):
+        np.testing.assert_array_equal(filters.NAMED_FILTERS_2D[k], g[f"named2d_{k}"])
+        np.testing.assert_array_equal(filters.NAMED_FILTERS_2D[k], g[f"named_{k}"])
+    planes = _ws_planes64()
+    np.testing.assert_allclose(ws_ref.filter_infere_single(planes[1].astype(np.float32)[..., None], filters.NAMED_FILTERS_2D["KB"])[..., 0],
+                               g["filter64_KB"], atol=2e-4)
+    ests = {"KB": lambda x: ws_ref.filter_infere_single(x, filters.NAMED_FILTERS_2D["KB"]),
+            "AVG": lambda x: ws_ref.filter_infere_single(x, filters.NAMED_FILTERS_2D["AVG"]),
+            "cross": _cross_mean}
+    for name, est in ests.items():
+        for i, p in enumerate(planes):
+            for j, (w, cb) in enumerate(g["cfgs"]):
+                got = ws_ref.attack_array(p, est, filters.NAMED_FILTERS_2D["AVG"], correct_bias=bool(cb), weighted=int(w))
+                assert math.isclose(got, g[f"beta64_{name}"][i, j], rel_tol=2e-4, abs_tol=2e-5), (name, i, w, cb, got)
+    for i, p in enumerate(planes):
+        got = ws_ref.attack_array(p, ests["KB"], filters.NAMED_FILTERS_2D["AVG9"], weighted=1)
+        assert math.isclose(got, g["beta64_KB_meanAVG9"][i], rel_tol=2e-4, abs_tol=2e-5)

@@ -25,20 +25,16 @@ def __getattr__(name):
     if name in _LAZY:
         mod, attr = _LAZY[name]
         return getattr(importlib.import_module(mod), attr)
-    if name in ("data", "evaluate", "model", "fabrika", "ops", "formula", "losses", "metrics", "imread", "parallel", "trainer"):
+    if name in ("data", "evaluate", "model", "fabrika", "ops", "formula", "losses", "metrics", "imread", "parallel", "trainer", "filters", "ws"):
         return importlib.import_module(f"ws_unet_amd.{name}")
     raise AttributeError(name)
 
 
 def get_unet_estimator(*args, **kw):
-    """Closure `predict(x: (H,W,1) float32 0..255) -> (H-2,W-2,1)` over a pretrained model
-    (reference src/unet/__init__.py:110-121).  The closure holds GPU state: it cannot be pickled into
-    joblib/loky workers (the reference's ws/estimate.py:139 does that with its CPU model) -- call it from
-    the process that owns the GPU, e.g. with fabrika iterator='python' or 'batched'."""
-    from .evaluate import get_pretrained, infere_single
-    model = get_pretrained(*args, **kw)
-
-    def predict(x):
-        return infere_single(x, model=model)
-
-    return predict
+    """`predict(x: (H,W,1) float32 0..255) -> (H-2,W-2,1)` over a pretrained model (reference
+    src/unet/__init__.py:110-121), returned as a callable `ws.estimate.UNetEstimator` whose `.model` lets the WS
+    estimator keep predictions on the device.  It holds GPU state: it cannot be pickled into joblib/loky workers
+    (the reference's ws/estimate.py:139 does that with its CPU model) -- use fabrika iterator='python' or 'batched'."""
+    from .evaluate import get_pretrained
+    from .ws.estimate import UNetEstimator
+    return UNetEstimator(get_pretrained(*args, **kw))

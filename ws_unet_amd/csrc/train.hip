@@ -1,7 +1,7 @@
 // K8 loss (+ its gradient) and K9 optimiser of the reconstructed UNet train step.
 //
 // Loss: src/_defs/losses.py -- L1Loss :28-36, WSLoss :45-90, L1WSLoss :93-121 (sum of the two, loss_lambda unused):
-//   L1  = mean |covers - out|
+//   L1  = mean |covers - out|            (use_l1 = 1)      L2 = mean (covers - out)^2   (use_l1 = 2, L2Loss :39-42)
 //   WS  = mean_n | relu(beta_hat_n) - alpha_n / 2 |,
 //         beta_hat_n = sum_p (1/(C*H*W)) * (in255 - flip(in255)) * (in255 - out255),  in255 = in*255, out255 = out*255,
 //         flip(v) = float(int(rint(v)) ^ 1)                       (integer LSB flip, bit-exact)
@@ -15,7 +15,7 @@ namespace {
 // one workgroup per image: s1 = sum |cov - out|, beta = sum w * s * (in255 - out255)
 __global__ __launch_bounds__(1024) void loss_reduce_kernel(const float* __restrict__ out, const float* __restrict__ cov,
                                                            const float* __restrict__ inp, double* __restrict__ s1,
-                                                           double* __restrict__ beta, long long per_img) {
+                                                           double* __restrict__ beta, long long per_img, int squared) {
     __shared__ double ra[1024];
     __shared__ double rb[1024];
     const int n = blockIdx.x, tid = threadIdx.x;
@@ -24,7 +24,8 @@ __global__ __launch_bounds__(1024) void loss_reduce_kernel(const float* __restri
     double a = 0.0, b = 0.0;
     for (long long i = tid; i < per_img; i += 1024) {
         const float o = out[base + i];
-        a += (double)fabsf(cov[base + i] - o);
+        const float d = cov[base + i] - o;
+        a += (double)(squared ? d * d : fabsf(d));                  // L2Loss (losses.py:39-42) reuses the L1 slot
         const float in255 = inp[base + i] * 255.0f;
         const float bar = (float)(((int)rintf(in255)) ^ 1);
         b += (double)(wgt * (in255 - bar) * (in255 - o * 255.0f));  // float32 products like the reference
@@ -69,7 +70,8 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(const float* __restrict_
         float g = 0.f;
         if (use_l1) {
             const float d = cov[i] - out[i];
-            g += (d > 0.f ? -inv : (d < 0.f ? inv : 0.f));          // d|cov - out|/dout = -sign(cov - out)
+            if (use_l1 == 2) g += -2.f * d * inv;                    // d(cov - out)^2/dout
+            else g += (d > 0.f ? -inv : (d < 0.f ? inv : 0.f));     // d|cov - out|/dout = -sign(cov - out)
         }
         if (use_ws) {
             const float in255 = inp[i] * 255.0f;
@@ -123,7 +125,7 @@ int wsu_l1ws_loss_fwd_bwd(const float* out, const float* covers, const float* in
     double* beta = s1 + n;
     float* coef = reinterpret_cast<float*>(beta + n);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(loss_reduce_kernel, dim3(n), dim3(1024), 0, s, out, covers, inputs, s1, beta, per_image);
+    hipLaunchKernelGGL(loss_reduce_kernel, dim3(n), dim3(1024), 0, s, out, covers, inputs, s1, beta, per_image, use_l1 == 2 ? 1 : 0);
     int rc = wsu_check_launch("loss_reduce_kernel");
     if (rc) return rc;
     hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(64), 0, s, s1, beta, alphas, loss, loss_parts, coef, beta_hat, n, per_image, use_l1, use_ws);

@@ -7,7 +7,7 @@ The value and dLoss/doutputs come from ONE fused libwsu call (wsu_l1ws_loss_fwd_
 fp64 reductions, the integer LSB flip `round(x*255) ^ 1` done in integer arithmetic (bit-exact), the
 gradient written in the same pass structure.  `loss.backward()` just scales that stored gradient.
 L1WSLoss = L1 + WS unweighted (the configs' `loss_lambda` is unused by the reference, losses.py:114-116).
-L2Loss (losses.py:39-42) is not used by any published run and is not provided.
+L2Loss (losses.py:39-42, unused by the published runs) rides the same kernel with the squared error in the L1 slot.
 """
 import torch
 
@@ -58,6 +58,10 @@ class L1Loss(_Base):
     use_l1, use_ws = True, False
 
 
+class L2Loss(_Base):
+    use_l1, use_ws = 2, False
+
+
 class WSLoss(_Base):
     use_l1, use_ws = False, True
 
@@ -69,6 +73,6 @@ class L1WSLoss(_Base):
 def get_loss(name: str):
     """Config key `loss` of models/unet/*/config.json: 'l1' (dropout run) or 'l1ws' (LSBR / HILLR runs)."""
     try:
-        return {"l1": L1Loss, "ws": WSLoss, "l1ws": L1WSLoss}[name]()
+        return {"l1": L1Loss, "l2": L2Loss, "ws": WSLoss, "l1ws": L1WSLoss}[name]()
     except KeyError:
         raise NotImplementedError(f"loss {name} not implemented")

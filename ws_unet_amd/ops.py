@@ -8,6 +8,7 @@ from __future__ import annotations
 
 from typing import Optional, Tuple
 
+import numpy as np
 import torch
 
 from . import _lib
@@ -250,6 +251,72 @@ def ws_residual_stats(x_u8: torch.Tensor, y01: torch.Tensor) -> Tuple[torch.Tens
     return beta, l1
 
 
+def _taps(k) -> Optional[np.ndarray]:
+    """(3,3) / (3,3,1) kernel array -> 9 contiguous host floats K[a][b] (layout of the reference's NAMED_FILTERS)."""
+    if k is None:
+        return None
+    k = np.asarray(k, dtype=np.float32)
+    if k.ndim == 3 and k.shape[2] == 1:
+        k = k[..., 0]
+    if k.shape != (3, 3):
+        raise ValueError(f"3x3 single-channel kernel expected, got shape {k.shape}")
+    return np.ascontiguousarray(k)
+
+
+def ws_attack(x_u8: torch.Tensor, x_hat: Optional[torch.Tensor] = None, *, x_bias: Optional[torch.Tensor] = None,
+              pixel_filter=None, mean_filter=None, hat_scale: float = 255.0, weighted: int = 1, correct_bias: bool = False,
+              return_sums: bool = False):
+    """Batched WS payload estimate (wsu_ws_attack, src/ws/estimate.py:55-136).  x_u8: (N,H,W) uint8.
+    x_hat: (N,H,W)/(N,1,H,W) full-frame prediction or (N,H-2,W-2) interior prediction, multiplied by `hat_scale`;
+    or `pixel_filter` (3,3[,1]) for an in-kernel linear predictor.  Returns beta_hat[N] (and the (N,3) fp64 sums)."""
+    lib = _lib.load()
+    _dev_check(x_u8, *[t for t in (x_hat, x_bias) if t is not None])
+    n, h, w = x_u8.shape
+    assert x_u8.dtype == torch.uint8
+    hat_full = 1
+    if x_hat is not None:
+        assert x_hat.dtype == torch.float32 and x_hat.is_contiguous()
+        if x_hat.numel() == n * h * w:
+            hat_full = 1
+        elif x_hat.numel() == n * (h - 2) * (w - 2):
+            hat_full = 0
+        else:
+            raise ValueError(f"prediction of {tuple(x_hat.shape)} does not match pixels {tuple(x_u8.shape)}")
+        if x_bias is not None:
+            assert x_bias.dtype == torch.float32 and x_bias.is_contiguous() and x_bias.numel() == x_hat.numel()
+    pt, mt = _taps(pixel_filter), _taps(mean_filter)
+    beta = torch.empty(n, dtype=torch.float32, device=x_u8.device)
+    sums = torch.empty((n, 3), dtype=torch.float64, device=x_u8.device) if return_sums else None
+    ws = torch.empty(lib.wsu_ws_attack_workspace_bytes(n) // 8, dtype=torch.float64, device=x_u8.device)
+    check(_launch("ws_attack", {}, lambda: lib.wsu_ws_attack(
+        x_u8.data_ptr(), x_hat.data_ptr() if x_hat is not None else None, x_bias.data_ptr() if x_bias is not None else None,
+        pt.ctypes.data if pt is not None else None, mt.ctypes.data if mt is not None else None,
+        hat_full, float(hat_scale), int(weighted), int(bool(correct_bias)), beta.data_ptr(),
+        sums.data_ptr() if sums is not None else None, ws.data_ptr(), ws.numel() * 8, n, h, w, _stream())), "wsu_ws_attack")
+    return (beta, sums) if return_sums else beta
+
+
+def filter3x3_valid(x: torch.Tensor, kernel) -> torch.Tensor:
+    """x: (N,H,W) fp32 -> (N,H-2,W-2) fp32 = convolve(x/255., K, 'valid')*255. (wsu_filter3x3_valid_f32)."""
+    lib = _lib.load()
+    _dev_check(x)
+    assert x.dtype == torch.float32 and x.dim() == 3
+    n, h, w = x.shape
+    k = _taps(kernel)
+    y = torch.empty((n, h - 2, w - 2), dtype=torch.float32, device=x.device)
+    check(lib.wsu_filter3x3_valid_f32(x.data_ptr(), k.ctypes.data, y.data_ptr(), n, h, w, _stream()), "wsu_filter3x3_valid_f32")
+    return y
+
+
+def lsb_delta_unit(x_u8: torch.Tensor) -> torch.Tensor:
+    """((x ^ 1) - x) / 255. as fp32, same shape."""
+    lib = _lib.load()
+    _dev_check(x_u8)
+    y = torch.empty(x_u8.shape, dtype=torch.float32, device=x_u8.device)
+    check(lib.wsu_lsb_delta_unit_f32(x_u8.data_ptr(), y.data_ptr(), x_u8.numel(), _stream()), "wsu_lsb_delta_unit_f32")
+    return y
+
+
 def u8_to_unit(x_u8: torch.Tensor) -> torch.Tensor:
     lib = _lib.load()
     _dev_check(x_u8)
@@ -409,7 +476,7 @@ def conv1x1_sigmoid_bwd(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, dou
 
 
 def l1ws_loss_fwd_bwd(out: torch.Tensor, covers: torch.Tensor, inputs: torch.Tensor, alphas: torch.Tensor,
-                      use_l1: bool = True, use_ws: bool = True):
+                      use_l1: int = 1, use_ws: bool = True):
     """Returns (loss scalar tensor, dLoss/dout, parts[l1, ws], beta_hat[N])."""
     lib = _lib.load()
     _dev_check(out, covers, inputs, alphas)
