@@ -14,6 +14,9 @@
 //   input tile   [4 granule planes][10 x 34 pixels][16 B]   halo resolved (reflect / zero) while staging
 //   weight tile  [9 taps][4 granule planes][64 co][16 B]    straight copy of the packed weights
 //   both granule-planar, so every fragment read is a contiguous 512-byte ds_read_b128 (conflict free).
+// MFMA tile: v_mfma_f32_32x32x16_bf16 (v_mfma_f32_32x32x2_f32 for mode f32); template flag S16 selects
+// v_mfma_f32_16x16x32_bf16 (lane = k-group x 16 rows; C/D: 4 consecutive channels of one pixel per lane), the default for
+// bf16 storage (profiles/r01/conv3x3_ablation.md, second pass).
 // Staging is register-double-buffered: chunk c+1's global loads are in flight while chunk c is multiplied.
 // The epilogue re-uses the LDS as a [pixel][channel] tile: bias + ReLU (+ReLU-mask for the data-gradient
 // pass), coalesced 16-byte NHWC stores, and the fused 2x2 max-pool with first-max-wins argmax.
@@ -129,7 +132,7 @@ __device__ __forceinline__ void stage_commit(char* smem, int tid, const int (&pi
         if (W_ITEMS % NT == 0 || tid + k * NT < W_ITEMS) wdst[tid + k * NT] = st_w[k];
 }
 
-template <int MODE, int NW>
+template <int MODE, int NW, bool S16 = false>
 __global__ __launch_bounds__(NW * 64, NW / 2) void conv3x3_kernel(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int ESZ = Epi<MODE>::ESZ;
@@ -182,6 +185,16 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv3x3_kernel(const ConvArgs
 
     const char* ldsA = smem + LDS_IN + (mbase + l31) * 16;           // + ((tap*4+g)*64 + mt*32)*16
     const char* ldsB = smem + ((2 * rowpair) * IW + l31) * 16;       // + g*PLANE_IN + ((nt+dy)*IW + dx)*16
+    // 16x16x32 variant (S16): lane = (k-group kg = lane>>4 -> granule plane, row/column l15 = lane&15); per wave MT*2 channel
+    // tiles x 4 pixel tiles (output row q = pt>>1, column half pt&1) of 16x16, 4 accumulator registers each.
+    const int l15 = lane & 15, kg = lane >> 4;
+    f32x4 acc16[MT * 2][4];
+#pragma unroll
+    for (int m = 0; m < MT * 2; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc16[m][q] = mk_f4(0.f, 0.f, 0.f, 0.f);
+    const char* ldsA16 = smem + LDS_IN + (mbase + l15) * 16;         // + ((tap*4+plane)*64 + ct*16)*16
+    const char* ldsB16 = smem + ((2 * rowpair) * IW + l15) * 16;     // + plane*PLANE_IN + ((q+dy)*IW + dx + half*16)*16
 
     WSU_STAMP(0);
     if ((a.ablate & 512) && blockIdx.x < 2048 && threadIdx.x == 0) g_stamps[blockIdx.x * WSU_NSTAMP + 30] = __builtin_amdgcn_s_memrealtime();
@@ -196,52 +209,104 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv3x3_kernel(const ConvArgs
         if (c + 1 < a.nch && !(a.ablate & 1)) stage_load<MODE, NW>(a, cb, c + 1, tid, pixidx, st_in, st_w);
         if (c < 6) WSU_STAMP(4 + 4 * c);
         if (a.ablate & 4) continue;                                     // no LDS fragment reads, no MFMA
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int dy = tap / 3, dx = tap % 3;
+        if constexpr (S16 && MODE == WSU_MODE_BF16) {
+            // one v_mfma_f32_16x16x32_bf16 covers a whole 32-channel chunk of one tap: k-group kg = granule plane kg
+            WSU_STATIC_FOR(9, tap, {
+                constexpr int dy = tap / 3, dx = tap % 3;
+                u32x4 av[MT * 2], bv[4];
+                WSU_STATIC_FOR(MT * 2, m, { av[m] = *reinterpret_cast<const u32x4*>(ldsA16 + ((tap * 4) * 64 + m * 16) * 16 + kg * (64 * 16)); });
+                WSU_STATIC_FOR(4, pt, { bv[pt] = *reinterpret_cast<const u32x4*>(ldsB16 + kg * PLANE_IN + (((pt >> 1) + dy) * IW + dx + (pt & 1) * 16) * 16); });
+                WSU_STATIC_FOR(MT * 2, m, { WSU_STATIC_FOR(4, pt, {
+                    acc16[m][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av[m]), __builtin_bit_cast(bf16x8, bv[pt]), acc16[m][pt], 0, 0, 0);
+                }); });
+            });
+        } else if constexpr (S16 && MODE == WSU_MODE_BF16X3) {
+            // K = 32 per instruction = two 16-channel operand halves:
+            //   type 1 (per tap):       A = [w_hi | w_lo] (planes 0..3 in k-group order), B = [x_hi | x_hi]   -> w_hi*x_hi + w_lo*x_hi
+            //   type 2 (per tap pair):  A = [w_hi(t) | w_hi(t+1)],                        B = [x_lo(t) | x_lo(t+1)]
+            // tap 8 has no partner: its type-2 instruction carries zeros in the upper half (1 of 27 instructions half empty).
+            const int khalf = kg >> 1, kp = kg & 1;
+            auto type1 = [&](auto tap_c) __attribute__((always_inline)) {
+                constexpr int tap = decltype(tap_c)::value;
+                constexpr int dy = tap / 3, dx = tap % 3;
+                u32x4 av[MT * 2], bv[4];
+                WSU_STATIC_FOR(MT * 2, m, { av[m] = *reinterpret_cast<const u32x4*>(ldsA16 + ((tap * 4) * 64 + m * 16) * 16 + kg * (64 * 16)); });
+                WSU_STATIC_FOR(4, pt, { bv[pt] = *reinterpret_cast<const u32x4*>(ldsB16 + kp * PLANE_IN + (((pt >> 1) + dy) * IW + dx + (pt & 1) * 16) * 16); });
+                WSU_STATIC_FOR(MT * 2, m, { WSU_STATIC_FOR(4, pt, {
+                    acc16[m][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av[m]), __builtin_bit_cast(bf16x8, bv[pt]), acc16[m][pt], 0, 0, 0);
+                }); });
+            };
+            auto type2 = [&](auto tap_c) __attribute__((always_inline)) {
+                constexpr int t0 = decltype(tap_c)::value;
+                constexpr int t1 = t0 + 1 < 9 ? t0 + 1 : t0;
+                constexpr bool single = t0 + 1 >= 9;
+                const int aoff = (khalf ? t1 : t0) * 4 * 64 * 16 + kp * (64 * 16);
+                const int boff = (2 + kp) * PLANE_IN + (khalf ? ((t1 / 3) * IW + t1 % 3) : ((t0 / 3) * IW + t0 % 3)) * 16;
+                u32x4 av[MT * 2], bv[4];
+                WSU_STATIC_FOR(MT * 2, m, {
+                    av[m] = *reinterpret_cast<const u32x4*>(ldsA16 + aoff + m * 16 * 16);
+                    if (single && khalf) av[m] = mk_u4(0, 0, 0, 0);
+                });
+                WSU_STATIC_FOR(4, pt, {
+                    bv[pt] = *reinterpret_cast<const u32x4*>(ldsB16 + boff + ((pt >> 1) * IW + (pt & 1) * 16) * 16);
+                    if (single && khalf) bv[pt] = mk_u4(0, 0, 0, 0);
+                });
+                WSU_STATIC_FOR(MT * 2, m, { WSU_STATIC_FOR(4, pt, {
+                    acc16[m][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av[m]), __builtin_bit_cast(bf16x8, bv[pt]), acc16[m][pt], 0, 0, 0);
+                }); });
+            };
+            WSU_STATIC_FOR(5, tp, {
+                type2(std::integral_constant<int, 2 * tp>{});
+                type1(std::integral_constant<int, 2 * tp>{});
+                if constexpr (2 * tp + 1 < 9) type1(std::integral_constant<int, 2 * tp + 1>{});
+            });
+        } else
+        WSU_STATIC_FOR(9, tap, {
+            constexpr int dy = tap / 3, dx = tap % 3;
+            if ((a.ablate & 16) && tap >= 6) return;                   // timing probe: 2/3 of the matrix work (results wrong)
             if constexpr (MODE == WSU_MODE_BF16X3) {
                 u32x4 ahi[MT], alo[MT], bhi[2], blo[2];
-#pragma unroll
+_Pragma("unroll")
                 for (int m = 0; m < MT; ++m) {
                     ahi[m] = *reinterpret_cast<const u32x4*>(ldsA + ((tap * 4 + hh) * 64 + m * 32) * 16);
                     alo[m] = *reinterpret_cast<const u32x4*>(ldsA + ((tap * 4 + 2 + hh) * 64 + m * 32) * 16);
                 }
-#pragma unroll
+_Pragma("unroll")
                 for (int q = 0; q < 2; ++q) {
                     bhi[q] = *reinterpret_cast<const u32x4*>(ldsB + hh * PLANE_IN + ((q + dy) * IW + dx) * 16);
                     blo[q] = *reinterpret_cast<const u32x4*>(ldsB + (2 + hh) * PLANE_IN + ((q + dy) * IW + dx) * 16);
                 }
                 // term-major: consecutive MFMAs go to different accumulators (same per-accumulator order, so bit-identical)
-#pragma unroll
+_Pragma("unroll")
                 for (int m = 0; m < MT; ++m)
-#pragma unroll
+_Pragma("unroll")
                     for (int q = 0; q < 2; ++q) wsu_mfma_step<MODE>(alo[m], bhi[q], acc[m][q]);     // small terms first
-#pragma unroll
+_Pragma("unroll")
                 for (int m = 0; m < MT; ++m)
-#pragma unroll
+_Pragma("unroll")
                     for (int q = 0; q < 2; ++q) wsu_mfma_step<MODE>(ahi[m], blo[q], acc[m][q]);
-#pragma unroll
+_Pragma("unroll")
                 for (int m = 0; m < MT; ++m)
-#pragma unroll
+_Pragma("unroll")
                     for (int q = 0; q < 2; ++q) wsu_mfma_step<MODE>(ahi[m], bhi[q], acc[m][q]);
             } else {
-#pragma unroll
+_Pragma("unroll")
                 for (int ks = 0; ks < 2; ++ks) {
                     const int g = 2 * ks + hh;
                     u32x4 av[MT], bv[2];
-#pragma unroll
+_Pragma("unroll")
                     for (int m = 0; m < MT; ++m)
                         av[m] = *reinterpret_cast<const u32x4*>(ldsA + ((tap * 4) * 64 + m * 32) * 16 + g * (64 * 16));
-#pragma unroll
+_Pragma("unroll")
                     for (int q = 0; q < 2; ++q)
                         bv[q] = *reinterpret_cast<const u32x4*>(ldsB + g * PLANE_IN + ((q + dy) * IW + dx) * 16);
-#pragma unroll
+_Pragma("unroll")
                     for (int m = 0; m < MT; ++m)
-#pragma unroll
+_Pragma("unroll")
                         for (int q = 0; q < 2; ++q) wsu_mfma_step<MODE>(av[m], bv[q], acc[m][q]);
                 }
             }
-        }
+        });
         if (c < 6) WSU_STAMP(5 + 4 * c);
     }
 
@@ -249,6 +314,26 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv3x3_kernel(const ConvArgs
     __syncthreads();
     WSU_STAMP(26);
     constexpr int STRIDE = Epi<MODE>::STRIDE;
+    if constexpr (S16 && MODE != WSU_MODE_F32) {
+        // 16x16 C/D map: column = lane&15 -> pixel, row = 4*(lane>>4) + r -> 4 consecutive channels per lane
+#pragma unroll
+        for (int m = 0; m < MT * 2; ++m) {
+            const int co = mbase + m * 16 + 4 * kg;
+            f32x4 b4 = mk_f4(0.f, 0.f, 0.f, 0.f);
+            if (a.bias) b4 = *reinterpret_cast<const f32x4*>(a.bias + cb * WSU_COB + co);
+#pragma unroll
+            for (int pt = 0; pt < 4; ++pt) {
+                float v0 = acc16[m][pt][0] + b4.x, v1 = acc16[m][pt][1] + b4.y, v2 = acc16[m][pt][2] + b4.z, v3 = acc16[m][pt][3] + b4.w;
+                if (a.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+                const int px = (2 * rowpair + (pt >> 1)) * TW + (pt & 1) * 16 + l15;
+                if constexpr (ESZ == 4) {
+                    *reinterpret_cast<f32x4*>(smem + px * STRIDE + co * 4) = mk_f4(v0, v1, v2, v3);
+                } else {
+                    *reinterpret_cast<u32x2*>(smem + px * STRIDE + co * 2) = mk_u2(wsu_pack_bf16x2(v0, v1), wsu_pack_bf16x2(v2, v3));
+                }
+            }
+        }
+    } else
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
 #pragma unroll
@@ -773,19 +858,19 @@ int launch_conv_pp(const ConvArgs& a, hipStream_t s) {
     return wsu_check_launch("conv3x3_pp_kernel");
 }
 
-template <int MODE, int NW>
+template <int MODE, int NW, bool S16 = false>
 int launch_conv_nw(const ConvArgs& a, hipStream_t s) {
     const int lds = Epi<MODE>::BYTES > LDS_MAIN ? Epi<MODE>::BYTES : LDS_MAIN;
     static bool attr_done = false;     // benign race: idempotent
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<MODE, NW>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<MODE, NW, S16>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) { wsu_set_error("hipFuncSetAttribute(conv3x3): %s", hipGetErrorString(e)); return WSU_ERR_HIP; }
         attr_done = true;
     }
     const long long nblk = (long long)a.n * a.tiles_x * a.tiles_y * a.ncb;
     if (nblk <= 0 || nblk > 0x7FFFFFFFLL) { wsu_set_error("conv3x3: grid of %lld workgroups out of range", nblk); return WSU_ERR_ARG; }
-    hipLaunchKernelGGL((conv3x3_kernel<MODE, NW>), dim3((unsigned)nblk), dim3(NW * 64), lds, s, a);
+    hipLaunchKernelGGL((conv3x3_kernel<MODE, NW, S16>), dim3((unsigned)nblk), dim3(NW * 64), lds, s, a);
     return wsu_check_launch("conv3x3_kernel");
 }
 
@@ -802,6 +887,14 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
     if (nw == 0) {
         const char* e = getenv("WSU_CONV_WAVES");
         nw = (e && atoi(e) == 4) ? 4 : ((e && atoi(e) == 8) ? 8 : (MODE == WSU_MODE_F32 ? 4 : 8));
+    }
+    if constexpr (MODE != WSU_MODE_F32) {
+        // MFMA tile shape: v_mfma_f32_16x16x32_bf16 is the default for bf16 storage (measured +3-5 % over 32x32x16 at 8 waves,
+        // a higher sustained clock at equal cycles); for bf16x3 the two shapes time the same and 32x32x16 stays.
+        // WSU_CONV_MFMA=16|32 overrides.
+        static int s16 = -1;
+        if (s16 < 0) { const char* e = getenv("WSU_CONV_MFMA"); s16 = e ? (atoi(e) == 16) : (MODE == WSU_MODE_BF16 ? 1 : 0); }
+        if (s16) return nw == 4 ? launch_conv_nw<MODE, 4, true>(a, s) : launch_conv_nw<MODE, 8, true>(a, s);
     }
     return nw == 4 ? launch_conv_nw<MODE, 4>(a, s) : launch_conv_nw<MODE, 8>(a, s);
 }
