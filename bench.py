@@ -19,6 +19,7 @@ launch time vs the dense bf16 MFMA peak) and `cpu_baseline` (the CPU oracle = to
 reference, batch 1 with autograd on exactly like infere_single, on a bounded sample of the same images).
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -99,6 +100,25 @@ def cpu_baseline(sample_u8, budget_s=25.0):
     return torch.cat(outs), float(np.median(times)), len(times), torch.get_num_threads()
 
 
+def pmc_traffic(args, algorithmic_bytes_per_launch):
+    """HBM bytes per conv3x3 launch from the PMC counters.  They cannot be read from inside this process (rocprofv3 has to
+    wrap it), so the number comes from the committed summary of two `rocprofv3 --pmc` passes of THIS command (FETCH_SIZE and
+    WRITE_SIZE separately, FETCH_SIZE doubled on gfx950; tools/pmc_traffic.py), and only when workload and mode match."""
+    out = {"traffic": None, "algorithmic_bytes_per_launch": algorithmic_bytes_per_launch}
+    if (args.mode, args.batch, args.size) != ("bf16x3", 32, 512):
+        return out
+    here = os.path.dirname(os.path.abspath(__file__))
+    cands = sorted(glob.glob(os.path.join(here, "profiles", "r*", "pmc_conv3x3_traffic.json")))
+    if not cands:
+        return out
+    with open(cands[-1]) as f:
+        pmc = json.load(f)
+    out["traffic"] = pmc["traffic_bytes_per_launch"]
+    out["traffic_unit"] = "HBM bytes per launch (PMC: 2 x FETCH_SIZE + WRITE_SIZE)"
+    out["traffic_source"] = os.path.relpath(cands[-1], here)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -152,6 +172,7 @@ def main():
             "note": "algorithmic FLOPs = 2*9*Cin*Cout*N*H*W summed over the 9 conv3x3 launches of a forward "
                     "(split-bf16 issues 3 MFMAs per product; they are not counted)",
         }
+        roofline.update(pmc_traffic(args, conv["bytes"] / conv["launches"]))
         gpu_ms = {k: round(v["total_ms"] / args.steps, 3) for k, v in ks.items()}
         result = {
             "metric": "512x512 grayscale images/sec (UNet predict)", "value": value, "unit": "images/s",
