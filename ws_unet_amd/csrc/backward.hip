@@ -22,9 +22,11 @@ namespace {
 // zero-padded conv computed by conv3x3_kernel with transposed weights; this kernel adds what the padded
 // border ring folds back:  dx[y, x] += sum over (yp, xp) in preimage(y, x) \ {(y, x)} of dxpad[yp, xp],
 // preimage rows of y = {y} U {-1 if y == 1} U {H if y == H-2}, same for columns.  Only rows 1, H-2 and
-// columns 1, W-2 receive anything.  One workgroup per destination pixel, one thread per input channel,
+// columns 1, W-2 receive anything.  One workgroup per 16 destination pixels, 16 lanes x 4 input channels per pixel,
 // fixed summation order; the ReLU mask of the producing layer is applied to the addend.
 // ---------------------------------------------------------------------------------------------------
+constexpr int BORDER_PXB = 16;        // destination pixels per workgroup; 16 lanes x 4 channels cover 64 input channels per pixel
+
 __global__ __launch_bounds__(256) void dgrad_border_kernel(const float* __restrict__ g, const float* __restrict__ w_t,
                                                            float* __restrict__ dx1, float* __restrict__ dx2,
                                                            const float* __restrict__ mask1, const float* __restrict__ mask2,
@@ -33,14 +35,16 @@ __global__ __launch_bounds__(256) void dgrad_border_kernel(const float* __restri
     const int nrows = (h - 2 != 1) ? 2 : 1;
     const int ncols = (w - 2 != 1) ? 2 : 1;
     const int per_img = nrows * w + ncols * (h - nrows);
-    int b = blockIdx.x;
-    const int img = b / per_img; b -= img * per_img;
+    const int blocks_per_img = (per_img + BORDER_PXB - 1) / BORDER_PXB;
+    const int img = blockIdx.x / blocks_per_img;
+    int b = (blockIdx.x - img * blocks_per_img) * BORDER_PXB + (threadIdx.x >> 4);
+    const int cg = threadIdx.x & 15;
+    if (b >= per_img) return;
     int y, x;
     if (b < nrows * w) { y = (b / w == 0) ? 1 : h - 2; x = b % w; }
     else {
         b -= nrows * w;
         const int k = b / ncols, which = b % ncols;       // k-th row that is not a border-destination row
-        // rows other than {1, h-2} in ascending order
         int row = k;
         if (row >= 1) ++row;                              // skip row 1
         if (nrows == 2 && row >= h - 2) ++row;            // skip row h-2
@@ -49,8 +53,9 @@ __global__ __launch_bounds__(256) void dgrad_border_kernel(const float* __restri
     int ys[3], xs[3]; int ny = 0, nx = 0;
     ys[ny++] = y; if (y == 1) ys[ny++] = -1; if (y == h - 2) ys[ny++] = h;
     xs[nx++] = x; if (x == 1) xs[nx++] = -1; if (x == w - 2) xs[nx++] = w;
-    for (int ci = threadIdx.x; ci < cin; ci += blockDim.x) {
-        float acc = 0.f;
+    // (source pixel, tap) pairs of this destination, in a fixed order (at most 8 x 9)
+    for (int ci = 4 * cg; ci < cin; ci += 64) {
+        f32x4 acc = mk_f4(0.f, 0.f, 0.f, 0.f);
         for (int iy = 0; iy < ny; ++iy)
             for (int ix = 0; ix < nx; ++ix) {
                 if (iy == 0 && ix == 0) continue;         // (y, x) itself is the interior part
@@ -61,11 +66,18 @@ __global__ __launch_bounds__(256) void dgrad_border_kernel(const float* __restri
                     for (int v = 0; v < 3; ++v) {
                         const int sx = xp - v + 1;
                         if (sx < 0 || sx >= w) continue;
-                        const float* gp = g + ((size_t)(img * h + sy) * w + sx) * cout;
-                        const float* wp = w_t + ((size_t)(u * 3 + v) * cout) * cin + ci;      // [tap][co][ci]: lanes read consecutive ci
-                        float s = 0.f;
-                        for (int co = 0; co < cout; ++co) s = fmaf(gp[co], wp[(size_t)co * cin], s);
-                        acc += s;
+                        const f32x4* gp = reinterpret_cast<const f32x4*>(g + ((size_t)(img * h + sy) * w + sx) * cout);
+                        const float* wp = w_t + ((size_t)(u * 3 + v) * cout) * cin + ci;      // [tap][co][ci]: 4 consecutive ci per lane
+                        f32x4 s4 = mk_f4(0.f, 0.f, 0.f, 0.f);
+                        for (int co = 0; co < cout; co += 4) {
+                            const f32x4 gv = gp[co >> 2];
+                            const f32x4 w0 = *reinterpret_cast<const f32x4*>(wp + (size_t)(co + 0) * cin);
+                            const f32x4 w1 = *reinterpret_cast<const f32x4*>(wp + (size_t)(co + 1) * cin);
+                            const f32x4 w2 = *reinterpret_cast<const f32x4*>(wp + (size_t)(co + 2) * cin);
+                            const f32x4 w3 = *reinterpret_cast<const f32x4*>(wp + (size_t)(co + 3) * cin);
+                            s4 = s4 + gv.x * w0; s4 = s4 + gv.y * w1; s4 = s4 + gv.z * w2; s4 = s4 + gv.w * w3;
+                        }
+                        acc = acc + s4;
                     }
                 }
             }
@@ -73,8 +85,13 @@ __global__ __launch_bounds__(256) void dgrad_border_kernel(const float* __restri
         if (ci < csplit) { dst = dx1; mk = mask1; c = csplit; cc = ci; }
         else             { dst = dx2; mk = mask2; c = cin - csplit; cc = ci - csplit; }
         const size_t o = ((size_t)(img * h + y) * w + x) * c + cc;
-        if (mk && !(mk[o] > 0.f)) acc = 0.f;
-        dst[o] += acc;
+        f32x4 cur = *reinterpret_cast<f32x4*>(dst + o);
+        if (mk) {
+            const f32x4 m = *reinterpret_cast<const f32x4*>(mk + o);
+            if (!(m.x > 0.f)) acc.x = 0.f; if (!(m.y > 0.f)) acc.y = 0.f;
+            if (!(m.z > 0.f)) acc.z = 0.f; if (!(m.w > 0.f)) acc.w = 0.f;
+        }
+        *reinterpret_cast<f32x4*>(dst + o) = cur + acc;
     }
 }
 
@@ -354,13 +371,14 @@ __global__ __launch_bounds__(256) void first_wgrad_partial_kernel(const float* _
     const long long p0 = (long long)blockIdx.x * chunk, p1 = min(p0 + chunk, npix);
     __shared__ float red[256];
     float* dst = part + (size_t)blockIdx.x * (cin * 9 + 1) * cout;
-    for (int ci = 0; ci <= cin; ++ci) {                     // ci == cin: the bias pass
-        float acc[9];
+    for (int ci = 0; ci < cin; ++ci) {                      // the bias sum rides on the ci == 0 pass
+        float acc[9], accb = 0.f;
 #pragma unroll
         for (int t = 0; t < 9; ++t) acc[t] = 0.f;
+#pragma unroll 4
         for (long long p = p0 + grp; p < p1; p += 4) {
             const float gv = g[(size_t)p * cout + ch];
-            if (ci == cin) { acc[0] += gv; continue; }
+            accb += gv;
             const int xx = (int)(p % w); const long long t2 = p / w;
             const int yy = (int)(t2 % h); const int nn = (int)(t2 / h);
             const float* xp = x + ((size_t)nn * cin + ci) * h * w;
@@ -368,13 +386,16 @@ __global__ __launch_bounds__(256) void first_wgrad_partial_kernel(const float* _
             for (int t = 0; t < 9; ++t)
                 acc[t] = fmaf(gv, xp[(size_t)wsu_reflect(yy + t / 3 - 1, h) * w + wsu_reflect(xx + t % 3 - 1, w)], acc[t]);
         }
-        const int nt = (ci == cin) ? 1 : 9;
-        for (int t = 0; t < nt; ++t) {
+#pragma unroll
+        for (int t = 0; t < 10; ++t) {                      // compile-time t: acc[] stays in registers
+            if (t == 9 && ci != 0) break;
             __syncthreads();
-            red[threadIdx.x] = acc[t];
+            red[threadIdx.x] = t < 9 ? acc[t < 9 ? t : 0] : accb;
             __syncthreads();
-            if (threadIdx.x < 64)
-                dst[(size_t)(ci * 9 + t) * cout + ch] = (red[threadIdx.x] + red[threadIdx.x + 64]) + (red[threadIdx.x + 128] + red[threadIdx.x + 192]);
+            if (threadIdx.x < 64) {
+                const int row = t < 9 ? ci * 9 + t : cin * 9;
+                dst[(size_t)row * cout + ch] = (red[threadIdx.x] + red[threadIdx.x + 64]) + (red[threadIdx.x + 128] + red[threadIdx.x + 192]);
+            }
         }
     }
 }
@@ -462,12 +483,14 @@ int wsu_conv3x3_bwd_data(const void* g, const void* w_packed_dgrad, const float*
                                    relu_mask1, relu_mask2, n, h, w, cout, 0, cin, mode, 0, 1, stream);
     if (rc) return rc;
     const int nrows = (h - 2 != 1) ? 2 : 1, ncols = (w - 2 != 1) ? 2 : 1;
-    const long long nblk = (long long)n * (nrows * w + ncols * (h - nrows));
+    const int per_img = nrows * w + ncols * (h - nrows);
+    const long long nblk = (long long)n * ((per_img + BORDER_PXB - 1) / BORDER_PXB);
     WSU_REQUIRE(nblk < 0x7FFFFFFFLL, "conv3x3_bwd_data: border grid too large");
+    WSU_REQUIRE(csplit % 4 == 0 && cout % 4 == 0, "conv3x3_bwd_data: csplit=%d / cout=%d must be multiples of 4", csplit, cout);
     hipLaunchKernelGGL(border_weight_transpose_kernel, dim3(64), dim3(256), 0, static_cast<hipStream_t>(stream), w_oihw, w_scratch, cin, cout);
     rc = wsu_check_launch("border_weight_transpose_kernel");
     if (rc) return rc;
-    hipLaunchKernelGGL(dgrad_border_kernel, dim3((unsigned)nblk), dim3(cin < 256 ? cin : 256), 0, static_cast<hipStream_t>(stream),
+    hipLaunchKernelGGL(dgrad_border_kernel, dim3((unsigned)nblk), dim3(256), 0, static_cast<hipStream_t>(stream),
                        (const float*)g, (const float*)w_scratch, (float*)dx1, (float*)dx2, (const float*)relu_mask1, (const float*)relu_mask2,
                        n, h, w, cin, csplit, cout);
     return wsu_check_launch("dgrad_border_kernel");

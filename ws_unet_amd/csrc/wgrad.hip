@@ -196,6 +196,11 @@ __global__ __launch_bounds__(NT, 2) void wgrad_x3_kernel(const WgArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
+    // bias gradient (exact fp32 column sums of U = g) rides on the staging loop of the workgroups with nb == 0: a thread always
+    // stages the same 8-channel group (NT is a multiple of 8), so it keeps 8 running sums and the 32 threads of a group meet in LDS.
+    const bool bias_on = KIND == 0 && a.bpart != nullptr && nb == 0;
+    f32x4 bs0 = mk_f4(0.f, 0.f, 0.f, 0.f), bs1 = bs0;
+
     const int t0 = split * a.tiles_per_split;
     const int t1 = min(t0 + a.tiles_per_split, a.ntiles);
     for (int tile = t0; tile < t1; ++tile) {
@@ -212,7 +217,9 @@ __global__ __launch_bounds__(NT, 2) void wgrad_x3_kernel(const WgArgs a) {
             u32x4 hi = mk_u4(0, 0, 0, 0), lo = hi;
             if (y0 + r < a.hu && x0 + c < a.wu) {
                 const f32x4* src = reinterpret_cast<const f32x4*>(a.u + ((size_t)(n * a.hu + y0 + r) * a.wu + x0 + c) * a.cu + mb * 64 + cg * 8);
-                wsu_split8(src[0], src[1], hi, lo);
+                const f32x4 s0 = src[0], s1 = src[1];
+                if (bias_on) { bs0 = bs0 + s0; bs1 = bs1 + s1; }
+                wsu_split8(s0, s1, hi, lo);
             }
             *reinterpret_cast<u32x4*>(u_hi + p * X3_ROW + cg * 16) = hi;
             *reinterpret_cast<u32x4*>(u_lo + p * X3_ROW + cg * 16) = lo;
@@ -258,6 +265,19 @@ __global__ __launch_bounds__(NT, 2) void wgrad_x3_kernel(const WgArgs a) {
             const int m = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
             dst[(size_t)t * 4096 + m * 64 + wn * 32 + l31] = acc[t][r];
         }
+    if (bias_on) {                                                     // uniform per workgroup
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);                   // [32 threads of a group][64 channels]
+        const int cg = tid & 7, k = tid >> 3;
+        *reinterpret_cast<f32x4*>(red + k * 64 + cg * 8) = bs0;
+        *reinterpret_cast<f32x4*>(red + k * 64 + cg * 8 + 4) = bs1;
+        __syncthreads();
+        if (tid < 64) {
+            float sum = 0.f;
+            for (int j = 0; j < NT / 8; ++j) sum += red[j * 64 + tid];
+            a.bpart[(size_t)split * (a.nmb * 64) + mb * 64 + tid] = sum;
+        }
+    }
 }
 
 // dW (conv: OIHW [M = co][Ntot = ci][3][3]; convT: IOHW [M = ci][Ntot = co][2][2]) = sum over splits, fixed order
@@ -329,7 +349,7 @@ int run_wgrad(WgArgs a, float* dw, float* db, float* workspace, size_t workspace
     a.nsplit = nsplit;
     a.tiles_per_split = (a.ntiles + nsplit - 1) / nsplit;
     a.part = workspace;
-    a.bpart = (db && !x3) ? workspace + (size_t)nsplit * slab / sizeof(float) : nullptr;
+    a.bpart = (db && (!x3 || KIND == 0)) ? workspace + (size_t)nsplit * slab / sizeof(float) : nullptr;
     if (x3) {
         static bool attr_x3 = false;
         if (!attr_x3) {
@@ -340,7 +360,7 @@ int run_wgrad(WgArgs a, float* dw, float* db, float* workspace, size_t workspace
         hipLaunchKernelGGL(wgrad_x3_kernel<KIND>, dim3(nsplit * a.nmb * a.nnb), dim3(NT), GeoX3<KIND>::LDS, s, a);
         int rc = wsu_check_launch("wgrad_x3_kernel");
         if (rc) return rc;
-        hipLaunchKernelGGL(wgrad_reduce_kernel<KIND>, dim3(512), dim3(256), 0, s, a.part, (const float*)nullptr, dw, (float*)nullptr, nsplit, a.nmb, a.nnb);
+        hipLaunchKernelGGL(wgrad_reduce_kernel<KIND>, dim3(512), dim3(256), 0, s, a.part, (const float*)a.bpart, dw, a.bpart ? db : (float*)nullptr, nsplit, a.nmb, a.nnb);
         return wsu_check_launch("wgrad_reduce_kernel");
     }
     static bool attr_done = false;
@@ -393,9 +413,7 @@ int wsu_conv3x3_bwd_weight(const float* g, const float* x1, const float* x2, flo
     a.u = g; a.v1 = x1; a.v2 = x2; a.n = n; a.hu = h; a.wu = w; a.cu = cout; a.cv1 = c1; a.cv2 = c2;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (mode == WSU_MODE_F32) return run_wgrad<0>(a, dw, db, workspace, workspace_bytes, s);
-    int rc = run_wgrad<0>(a, dw, nullptr, workspace, workspace_bytes, s, true);
-    if (rc || !db) return rc;
-    return colsum_channels(g, db, workspace, workspace_bytes, (long long)n * h * w, cout, s);     // exact fp32 bias gradient
+    return run_wgrad<0>(a, dw, db, workspace, workspace_bytes, s, true);      // exact fp32 bias gradient from the staging loop
 }
 
 int wsu_convt2x2_bwd_weight(const float* x, const float* dy, float* dw, float* db,
