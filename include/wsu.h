@@ -81,6 +81,17 @@ int wsu_conv3x3_head_fwd(const void* x1, const void* x2, const void* w_packed, c
                          const float* head_w, const float* head_b, float* out, float* logit,
                          int n, int h, int w, int c1, int c2, int cout, int head_cout, int mode, void* stream);
 
+/* ---- K1w: the same forward conv (mode bf16x3 only: fp32 NHWC activations) through a Winograd F(2,3) kernel along x:
+ *      1.5x fewer MFMAs, results equal to the direct kernel up to fp32 re-association.  Weights from wsu_conv3x3_wino_pack
+ *      ([cob][chunk][12 taps][4 planes][64 co][16 B], row taps pre-multiplied by G).  Same fusions: x2 = second concat source,
+ *      y_pool / pool_idx = fused 2x2 max-pool (+argmax), head_* = fused 1x1 head + sigmoid (y may then be NULL). */
+size_t wsu_conv3x3_wino_packed_bytes(int cin, int cout);
+int wsu_conv3x3_wino_pack(const float* w_oihw, void* w_packed, int cin, int cout, void* stream);
+int wsu_conv3x3_wino_fwd(const void* x1, const void* x2, const void* w_packed, const float* bias, void* y,
+                         void* y_pool, uint8_t* pool_idx,
+                         const float* head_w, const float* head_b, float* head_out, float* head_logit, int head_cout,
+                         int n, int h, int w, int c1, int c2, int cout, int relu, void* stream);
+
 /* ---- first layer: conv3x3 reflect on a few input planes given as NCHW fp32 (the model input).
  *      Replaces e11 (unet.py:82,141).  cin <= 8, cout multiple of 8.  w is plain OIHW fp32. */
 int wsu_conv3x3_first_fwd(const float* x_nchw, const float* w_oihw, const float* bias, void* y,

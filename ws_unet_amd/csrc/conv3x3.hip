@@ -142,6 +142,137 @@ __device__ __forceinline__ void stage_commit(char* smem, int tid, const int (&pi
         if (W_ITEMS % NT == 0 || tid + k * NT < W_ITEMS) wdst[tid + k * NT] = st_w[k];
 }
 
+// Everything behind the [pixel][channel] LDS tile (TH x 32 pixels, Epi<MODE>::STRIDE bytes per pixel): fused 1x1 head, coalesced
+// NHWC stores with the optional ReLU mask, fused 2x2 max-pool with first-max-wins argmax.  Shared by the direct and the Winograd kernel.
+template <int MODE, int NT, int TH>
+__device__ __forceinline__ void tile_epilogue(const ConvArgs& a, char* smem, int tid, int n, int y0, int x0, int cb) {
+    constexpr int ESZ = Epi<MODE>::ESZ;
+    constexpr int STRIDE = Epi<MODE>::STRIDE;
+    // ---- coalesced NHWC store (16 B per thread), optional ReLU mask of the data-gradient pass --------
+    constexpr int VPP = Epi<MODE>::VPP;
+    const int cglob = cb * WSU_COB;                                   // first output channel of this block
+    char* ydst = a.y; int ych = a.csplit, ycoff = cglob;
+    const char* msk = a.relu_mask;
+    if (cglob >= a.csplit) { ydst = a.y2; ych = a.cout - a.csplit; ycoff = cglob - a.csplit; msk = a.relu_mask2; }
+    if (a.head_w && tid < TH * TW) {
+        // fused head: one thread per pixel, 64-wide dot per output plane from the LDS tile, sigmoid, NCHW fp32 store
+        const int r = tid / TW, c = tid % TW;
+        if (y0 + r < a.h && x0 + c < a.w) {
+            float z[4];
+#pragma unroll
+            for (int co = 0; co < 4; ++co) z[co] = (co < a.head_cout && a.head_b) ? a.head_b[co] : 0.f;
+#pragma unroll
+            for (int v = 0; v < VPP; ++v) {
+                const u32x4 raw = *reinterpret_cast<const u32x4*>(smem + tid * STRIDE + v * 16);
+                float xv[16 / ESZ];
+                if constexpr (ESZ == 4) { const f32x4 f = __builtin_bit_cast(f32x4, raw); xv[0] = f.x; xv[1] = f.y; xv[2] = f.z; xv[3] = f.w; }
+                else {
+                    const uint32_t u[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) xv[e] = wsu_bf16_to_f32((u[e >> 1] >> ((e & 1) * 16)) & 0xFFFF);
+                }
+#pragma unroll
+                for (int co = 0; co < 4; ++co)
+                    if (co < a.head_cout)
+#pragma unroll
+                        for (int e = 0; e < 16 / ESZ; ++e) z[co] = fmaf(xv[e], a.head_w[co * WSU_COB + v * (16 / ESZ) + e], z[co]);
+            }
+            const size_t hw = (size_t)a.h * a.w, pix = (size_t)(y0 + r) * a.w + x0 + c;
+#pragma unroll
+            for (int co = 0; co < 4; ++co)
+                if (co < a.head_cout) {
+                    const size_t o = ((size_t)n * a.head_cout + co) * hw + pix;
+                    if (a.head_logit) a.head_logit[o] = z[co];
+                    a.head_out[o] = 1.f / (1.f + expf(-z[co]));
+                }
+        }
+    }
+    if (ydst)
+#pragma unroll
+    for (int k = 0; k < TH * TW * VPP / NT; ++k) {
+        const int i = tid + k * NT;
+        const int px = i / VPP, v = i % VPP;
+        const int r = px / TW, c = px % TW;
+        if (y0 + r < a.h && x0 + c < a.w) {
+            u32x4 val = *reinterpret_cast<const u32x4*>(smem + px * STRIDE + v * 16);
+            const size_t off = (((size_t)(n * a.h + y0 + r) * a.w + x0 + c) * ych + ycoff) * ESZ + v * 16;
+            if (msk) {
+                const u32x4 mk = *reinterpret_cast<const u32x4*>(msk + off);
+                if constexpr (ESZ == 4) {
+                    const f32x4 mf = __builtin_bit_cast(f32x4, mk);
+                    if (!(mf.x > 0.f)) val.x = 0; if (!(mf.y > 0.f)) val.y = 0;
+                    if (!(mf.z > 0.f)) val.z = 0; if (!(mf.w > 0.f)) val.w = 0;
+                } else {
+                    const uint32_t mm[4] = {mk.x, mk.y, mk.z, mk.w};
+                    uint32_t vv[4] = {val.x, val.y, val.z, val.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (!(wsu_bf16_to_f32(mm[e] & 0xFFFF) > 0.f)) vv[e] &= 0xFFFF0000u;
+                        if (!(wsu_bf16_to_f32(mm[e] >> 16) > 0.f)) vv[e] &= 0x0000FFFFu;
+                    }
+                    val = mk_u4(vv[0], vv[1], vv[2], vv[3]);
+                }
+            }
+            *reinterpret_cast<u32x4*>(ydst + off) = val;
+        }
+    }
+
+    WSU_STAMP(27);
+    if ((a.ablate & 512) && blockIdx.x < 2048 && threadIdx.x == 0) g_stamps[blockIdx.x * WSU_NSTAMP + 31] = __builtin_amdgcn_s_memrealtime();
+    // ---- fused 2x2/2 max-pool with first-max-wins argmax ------------------------------------------------
+    if (a.ypool) {
+        const int hp = a.h >> 1, wp2 = a.w >> 1;
+#pragma unroll
+        for (int k = 0; k < (TH / 2) * (TW / 2) * VPP / NT; ++k) {
+            const int i = tid + k * NT;
+            const int pp = i / VPP, v = i % VPP;
+            const int pr = pp / (TW / 2), pc = pp % (TW / 2);
+            const int gy = (y0 >> 1) + pr, gx = (x0 >> 1) + pc;
+            if (gy < hp && gx < wp2) {
+                const char* base = smem + ((2 * pr) * TW + 2 * pc) * STRIDE + v * 16;
+                const u32x4 w0 = *reinterpret_cast<const u32x4*>(base);
+                const u32x4 w1 = *reinterpret_cast<const u32x4*>(base + STRIDE);
+                const u32x4 w2 = *reinterpret_cast<const u32x4*>(base + TW * STRIDE);
+                const u32x4 w3 = *reinterpret_cast<const u32x4*>(base + (TW + 1) * STRIDE);
+                const size_t eoff = ((size_t)(n * hp + gy) * wp2 + gx) * a.cout + cglob;   // element offset
+                if constexpr (ESZ == 4) {
+                    const float* f0 = reinterpret_cast<const float*>(&w0); const float* f1 = reinterpret_cast<const float*>(&w1);
+                    const float* f2 = reinterpret_cast<const float*>(&w2); const float* f3 = reinterpret_cast<const float*>(&w3);
+                    float o[4]; uint32_t idx = 0;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float best = f0[e]; uint32_t bi = 0;
+                        if (f1[e] > best || f1[e] != f1[e]) { best = f1[e]; bi = 1; }
+                        if (f2[e] > best || f2[e] != f2[e]) { best = f2[e]; bi = 2; }
+                        if (f3[e] > best || f3[e] != f3[e]) { best = f3[e]; bi = 3; }
+                        o[e] = best; idx |= bi << (8 * e);
+                    }
+                    *reinterpret_cast<f32x4*>(a.ypool + (eoff + v * 4) * 4) = mk_f4(o[0], o[1], o[2], o[3]);
+                    if (a.pidx) *reinterpret_cast<uint32_t*>(a.pidx + eoff + v * 4) = idx;
+                } else {
+                    const uint32_t u0[4] = {w0.x, w0.y, w0.z, w0.w}, u1[4] = {w1.x, w1.y, w1.z, w1.w};
+                    const uint32_t u2[4] = {w2.x, w2.y, w2.z, w2.w}, u3[4] = {w3.x, w3.y, w3.z, w3.w};
+                    uint32_t o[4]; uint32_t idx[2] = {0, 0};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int sh = (e & 1) * 16;
+                        const uint16_t h0 = (u0[e >> 1] >> sh) & 0xFFFF, h1 = (u1[e >> 1] >> sh) & 0xFFFF;
+                        const uint16_t h2 = (u2[e >> 1] >> sh) & 0xFFFF, h3 = (u3[e >> 1] >> sh) & 0xFFFF;
+                        float best = wsu_bf16_to_f32(h0); uint16_t bb = h0; uint32_t bi = 0; float t;
+                        t = wsu_bf16_to_f32(h1); if (t > best || t != t) { best = t; bb = h1; bi = 1; }
+                        t = wsu_bf16_to_f32(h2); if (t > best || t != t) { best = t; bb = h2; bi = 2; }
+                        t = wsu_bf16_to_f32(h3); if (t > best || t != t) { best = t; bb = h3; bi = 3; }
+                        if (e & 1) o[e >> 1] |= (uint32_t)bb << 16; else o[e >> 1] = bb;
+                        idx[e >> 2] |= bi << (8 * (e & 3));
+                    }
+                    *reinterpret_cast<u32x4*>(a.ypool + (eoff + v * 8) * 2) = mk_u4(o[0], o[1], o[2], o[3]);
+                    if (a.pidx) *reinterpret_cast<u32x2*>(a.pidx + eoff + v * 8) = mk_u2(idx[0], idx[1]);
+                }
+            }
+        }
+    }
+}
+
 template <int MODE, int NW, bool S16 = false>
 __global__ __launch_bounds__(NW * 64, NW >= 8 ? 4 : 2) void conv3x3_kernel(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -368,131 +499,195 @@ _Pragma("unroll")
     }
     __syncthreads();
 
-    // ---- coalesced NHWC store (16 B per thread), optional ReLU mask of the data-gradient pass --------
-    constexpr int VPP = Epi<MODE>::VPP;
-    const int cglob = cb * WSU_COB;                                   // first output channel of this block
-    char* ydst = a.y; int ych = a.csplit, ycoff = cglob;
-    const char* msk = a.relu_mask;
-    if (cglob >= a.csplit) { ydst = a.y2; ych = a.cout - a.csplit; ycoff = cglob - a.csplit; msk = a.relu_mask2; }
-    if (a.head_w && tid < TH * TW) {
-        // fused head: one thread per pixel, 64-wide dot per output plane from the LDS tile, sigmoid, NCHW fp32 store
-        const int r = tid / TW, c = tid % TW;
-        if (y0 + r < a.h && x0 + c < a.w) {
-            float z[4];
-#pragma unroll
-            for (int co = 0; co < 4; ++co) z[co] = (co < a.head_cout && a.head_b) ? a.head_b[co] : 0.f;
-#pragma unroll
-            for (int v = 0; v < VPP; ++v) {
-                const u32x4 raw = *reinterpret_cast<const u32x4*>(smem + tid * STRIDE + v * 16);
-                float xv[16 / ESZ];
-                if constexpr (ESZ == 4) { const f32x4 f = __builtin_bit_cast(f32x4, raw); xv[0] = f.x; xv[1] = f.y; xv[2] = f.z; xv[3] = f.w; }
-                else {
-                    const uint32_t u[4] = {raw.x, raw.y, raw.z, raw.w};
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) xv[e] = wsu_bf16_to_f32((u[e >> 1] >> ((e & 1) * 16)) & 0xFFFF);
-                }
-#pragma unroll
-                for (int co = 0; co < 4; ++co)
-                    if (co < a.head_cout)
-#pragma unroll
-                        for (int e = 0; e < 16 / ESZ; ++e) z[co] = fmaf(xv[e], a.head_w[co * WSU_COB + v * (16 / ESZ) + e], z[co]);
-            }
-            const size_t hw = (size_t)a.h * a.w, pix = (size_t)(y0 + r) * a.w + x0 + c;
-#pragma unroll
-            for (int co = 0; co < 4; ++co)
-                if (co < a.head_cout) {
-                    const size_t o = ((size_t)n * a.head_cout + co) * hw + pix;
-                    if (a.head_logit) a.head_logit[o] = z[co];
-                    a.head_out[o] = 1.f / (1.f + expf(-z[co]));
-                }
-        }
-    }
-    if (ydst)
-#pragma unroll
-    for (int k = 0; k < TH * TW * VPP / NT; ++k) {
-        const int i = tid + k * NT;
-        const int px = i / VPP, v = i % VPP;
-        const int r = px / TW, c = px % TW;
-        if (y0 + r < a.h && x0 + c < a.w) {
-            u32x4 val = *reinterpret_cast<const u32x4*>(smem + px * STRIDE + v * 16);
-            const size_t off = (((size_t)(n * a.h + y0 + r) * a.w + x0 + c) * ych + ycoff) * ESZ + v * 16;
-            if (msk) {
-                const u32x4 mk = *reinterpret_cast<const u32x4*>(msk + off);
-                if constexpr (ESZ == 4) {
-                    const f32x4 mf = __builtin_bit_cast(f32x4, mk);
-                    if (!(mf.x > 0.f)) val.x = 0; if (!(mf.y > 0.f)) val.y = 0;
-                    if (!(mf.z > 0.f)) val.z = 0; if (!(mf.w > 0.f)) val.w = 0;
-                } else {
-                    const uint32_t mm[4] = {mk.x, mk.y, mk.z, mk.w};
-                    uint32_t vv[4] = {val.x, val.y, val.z, val.w};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        if (!(wsu_bf16_to_f32(mm[e] & 0xFFFF) > 0.f)) vv[e] &= 0xFFFF0000u;
-                        if (!(wsu_bf16_to_f32(mm[e] >> 16) > 0.f)) vv[e] &= 0x0000FFFFu;
-                    }
-                    val = mk_u4(vv[0], vv[1], vv[2], vv[3]);
-                }
-            }
-            *reinterpret_cast<u32x4*>(ydst + off) = val;
-        }
-    }
+    tile_epilogue<MODE, NT, TH>(a, smem, tid, n, y0, x0, cb);
+}
 
-    WSU_STAMP(27);
-    if ((a.ablate & 512) && blockIdx.x < 2048 && threadIdx.x == 0) g_stamps[blockIdx.x * WSU_NSTAMP + 31] = __builtin_amdgcn_s_memrealtime();
-    // ---- fused 2x2/2 max-pool with first-max-wins argmax ------------------------------------------------
-    if (a.ypool) {
-        const int hp = a.h >> 1, wp2 = a.w >> 1;
+
+// =====================================================================================================
+// Winograd F(2,3) along x (mode bf16x3, forward only; wsu_conv3x3_wino_fwd).  The run time of the direct kernel is affine in its
+// MFMA count (profiles/r01/conv3x3_ablation.md, second pass), so this kernel trades MFMAs for a few VALU adds:
+//   y[2t], y[2t+1] = A^T [ (G w) .* (B^T d) ],  d = x[2t-1 .. 2t+2],  w = the three column taps of one kernel row
+//   B^T d = (d0-d2, d1+d2, d2-d1, d1-d3)   G w = (w0, (w0+w1+w2)/2, (w0-w1+w2)/2, w2)   A^T m = (m0+m1+m2, m1-m2-m3)
+// -> 3 rows x 4 positions = 12 "taps", each a GEMM over HALF the columns: 36 instead of 54 MFMAs per wave and 16-channel chunk.
+// Workgroup = 16 x 32 output pixels x 64 channels, 16 waves (the NW = 16 shape of the direct kernel), wave = 32 channels x
+// (2 rows x 16 column pairs) with one accumulator tile per position (4 x 16 registers).
+// LDS: transformed input  V[granule plane 4][position 4][18 rows][16 column pairs][16 B]   73 728 B  (bf16 hi / lo of B^T d)
+//      transformed weights U[12 taps][4 planes][64 co][16 B]                               49 152 B  (packed by pack_wino)
+// Staging: waves 0-8 own one (row, column pair, 8-channel half) each: 4 pixels x 32 B from global, B^T d in fp32, split, 8 x 16 B
+// to LDS; waves 9-15 copy the weight tile.  Register double-buffered like the direct kernel; the epilogue applies A^T on the
+// accumulators and then is the shared tile epilogue (bias, ReLU, stores, pool, head).
+// =====================================================================================================
+constexpr int WN_TAPS = 12, WN_TC = 16;
+constexpr int WN_LDS_W = WN_TAPS * WSU_GRAN * WSU_COB * 16;          // 49152
+constexpr int WN_TH = 16, WN_IH = WN_TH + 2, WN_NT = 1024;
+constexpr int WN_PLANE = 4 * WN_IH * WN_TC * 16;                     // 18432 B per granule plane
+constexpr int WN_LDS_V = WSU_GRAN * WN_PLANE;                        // 73728
+constexpr int WN_VTHREADS = WN_IH * WN_TC * 2;                       // 576 = waves 0..8
+constexpr int WN_WTHREADS = WN_NT - WN_VTHREADS;                     // 448
+constexpr int WN_WITEMS = WN_LDS_W / 16;                             // 3072
+constexpr int WN_WVEC = (WN_WITEMS + WN_WTHREADS - 1) / WN_WTHREADS; // 7
+constexpr int WN_ST = 8;
+
+struct WinoPlan { int rowbase; int xbase; int ldsoff; };             // rowbase < 0: the whole source row is zero padding
+
+__device__ __forceinline__ void wino_load(const ConvArgs& a, int cb, int c, int tid, const WinoPlan& pl, u32x4 (&st)[WN_ST]) {
+    if (tid < WN_VTHREADS) {
+        const char* src; int csrc, ch0;
+        if (c < a.nch1) { src = a.x1; csrc = a.c1; ch0 = c * 16; }
+        else            { src = a.x2; csrc = a.c2; ch0 = (c - a.nch1) * 16; }
+        const int h = tid & 1;
 #pragma unroll
-        for (int k = 0; k < (TH / 2) * (TW / 2) * VPP / NT; ++k) {
-            const int i = tid + k * NT;
-            const int pp = i / VPP, v = i % VPP;
-            const int pr = pp / (TW / 2), pc = pp % (TW / 2);
-            const int gy = (y0 >> 1) + pr, gx = (x0 >> 1) + pc;
-            if (gy < hp && gx < wp2) {
-                const char* base = smem + ((2 * pr) * TW + 2 * pc) * STRIDE + v * 16;
-                const u32x4 w0 = *reinterpret_cast<const u32x4*>(base);
-                const u32x4 w1 = *reinterpret_cast<const u32x4*>(base + STRIDE);
-                const u32x4 w2 = *reinterpret_cast<const u32x4*>(base + TW * STRIDE);
-                const u32x4 w3 = *reinterpret_cast<const u32x4*>(base + (TW + 1) * STRIDE);
-                const size_t eoff = ((size_t)(n * hp + gy) * wp2 + gx) * a.cout + cglob;   // element offset
-                if constexpr (ESZ == 4) {
-                    const float* f0 = reinterpret_cast<const float*>(&w0); const float* f1 = reinterpret_cast<const float*>(&w1);
-                    const float* f2 = reinterpret_cast<const float*>(&w2); const float* f3 = reinterpret_cast<const float*>(&w3);
-                    float o[4]; uint32_t idx = 0;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float best = f0[e]; uint32_t bi = 0;
-                        if (f1[e] > best || f1[e] != f1[e]) { best = f1[e]; bi = 1; }
-                        if (f2[e] > best || f2[e] != f2[e]) { best = f2[e]; bi = 2; }
-                        if (f3[e] > best || f3[e] != f3[e]) { best = f3[e]; bi = 3; }
-                        o[e] = best; idx |= bi << (8 * e);
-                    }
-                    *reinterpret_cast<f32x4*>(a.ypool + (eoff + v * 4) * 4) = mk_f4(o[0], o[1], o[2], o[3]);
-                    if (a.pidx) *reinterpret_cast<uint32_t*>(a.pidx + eoff + v * 4) = idx;
-                } else {
-                    const uint32_t u0[4] = {w0.x, w0.y, w0.z, w0.w}, u1[4] = {w1.x, w1.y, w1.z, w1.w};
-                    const uint32_t u2[4] = {w2.x, w2.y, w2.z, w2.w}, u3[4] = {w3.x, w3.y, w3.z, w3.w};
-                    uint32_t o[4]; uint32_t idx[2] = {0, 0};
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const int sh = (e & 1) * 16;
-                        const uint16_t h0 = (u0[e >> 1] >> sh) & 0xFFFF, h1 = (u1[e >> 1] >> sh) & 0xFFFF;
-                        const uint16_t h2 = (u2[e >> 1] >> sh) & 0xFFFF, h3 = (u3[e >> 1] >> sh) & 0xFFFF;
-                        float best = wsu_bf16_to_f32(h0); uint16_t bb = h0; uint32_t bi = 0; float t;
-                        t = wsu_bf16_to_f32(h1); if (t > best || t != t) { best = t; bb = h1; bi = 1; }
-                        t = wsu_bf16_to_f32(h2); if (t > best || t != t) { best = t; bb = h2; bi = 2; }
-                        t = wsu_bf16_to_f32(h3); if (t > best || t != t) { best = t; bb = h3; bi = 3; }
-                        if (e & 1) o[e >> 1] |= (uint32_t)bb << 16; else o[e >> 1] = bb;
-                        idx[e >> 2] |= bi << (8 * (e & 3));
-                    }
-                    *reinterpret_cast<u32x4*>(a.ypool + (eoff + v * 8) * 2) = mk_u4(o[0], o[1], o[2], o[3]);
-                    if (a.pidx) *reinterpret_cast<u32x2*>(a.pidx + eoff + v * 8) = mk_u2(idx[0], idx[1]);
-                }
+        for (int i = 0; i < 4; ++i) {
+            int xx = pl.xbase + i;
+            bool ok = pl.rowbase >= 0;
+            if (a.pad_zero) ok = ok && xx >= 0 && xx < a.w; else xx = wsu_reflect(xx, a.w);
+            u32x4 v0 = mk_u4(0, 0, 0, 0), v1 = v0;
+            if (ok) {
+                const u32x4* g = reinterpret_cast<const u32x4*>(src + ((size_t)(pl.rowbase + xx) * csrc + ch0) * 4 + h * 32);
+                v0 = g[0]; v1 = g[1];
             }
+            st[2 * i] = v0; st[2 * i + 1] = v1;
         }
+    } else {
+        const u32x4* wsrc = reinterpret_cast<const u32x4*>(a.wp + ((size_t)cb * a.nch + c) * WN_LDS_W);
+        const int t = tid - WN_VTHREADS;
+#pragma unroll
+        for (int k = 0; k < WN_WVEC; ++k)
+            if (t + k * WN_WTHREADS < WN_WITEMS) st[k] = wsrc[t + k * WN_WTHREADS];
     }
 }
 
+__device__ __forceinline__ void wino_commit(char* smem, int tid, const WinoPlan& pl, const u32x4 (&st)[WN_ST]) {
+    if (tid < WN_VTHREADS) {
+        f32x4 d[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { d[i][0] = __builtin_bit_cast(f32x4, st[2 * i]); d[i][1] = __builtin_bit_cast(f32x4, st[2 * i + 1]); }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            f32x4 v0, v1;
+            if (p == 0)      { v0 = d[0][0] - d[2][0]; v1 = d[0][1] - d[2][1]; }
+            else if (p == 1) { v0 = d[1][0] + d[2][0]; v1 = d[1][1] + d[2][1]; }
+            else if (p == 2) { v0 = d[2][0] - d[1][0]; v1 = d[2][1] - d[1][1]; }
+            else             { v0 = d[1][0] - d[3][0]; v1 = d[1][1] - d[3][1]; }
+            u32x4 hi, lo;
+            wsu_split8(v0, v1, hi, lo);
+            char* dst = smem + pl.ldsoff + p * (WN_IH * WN_TC * 16);
+            *reinterpret_cast<u32x4*>(dst) = hi;
+            *reinterpret_cast<u32x4*>(dst + 2 * WN_PLANE) = lo;
+        }
+    } else {
+        u32x4* wdst = reinterpret_cast<u32x4*>(smem + WN_LDS_V);
+        const int t = tid - WN_VTHREADS;
+#pragma unroll
+        for (int k = 0; k < WN_WVEC; ++k)
+            if (t + k * WN_WTHREADS < WN_WITEMS) wdst[t + k * WN_WTHREADS] = st[k];
+    }
+}
+
+__global__ __launch_bounds__(WN_NT, 4) void conv3x3_wino_kernel(const ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int MODE = WSU_MODE_BF16X3;
+    const int tid = threadIdx.x;
+    const unsigned lid = wsu_xcd_remap(blockIdx.x, gridDim.x);
+    const int cb = lid % a.ncb;
+    int tile = lid / a.ncb;
+    const int tx = tile % a.tiles_x; tile /= a.tiles_x;
+    const int ty = tile % a.tiles_y;
+    const int n = tile / a.tiles_y;
+    const int y0 = ty * WN_TH, x0 = tx * TW;
+
+    WinoPlan pl;
+    {
+        const int h = tid & 1, tc = (tid >> 1) & 15, row = tid >> 5;            // staging threads: tid < 576 -> row 0..17
+        int yy = y0 - 1 + row;
+        bool ok = true;
+        if (a.pad_zero) ok = yy >= 0 && yy < a.h; else yy = wsu_reflect(yy, a.h);
+        pl.rowbase = ok ? (n * a.h + yy) * a.w : -1;
+        pl.xbase = x0 - 1 + 2 * tc;
+        pl.ldsoff = h * WN_PLANE + (row * WN_TC + tc) * 16;                      // + position * (18 * 16 * 16); lo planes at + 2 * WN_PLANE
+    }
+
+    const int wv = tid >> 6, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+    const int rowpair = wv >> 1, mbase = (wv & 1) * 32;
+    f32x16 acc[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+    const char* ldsA = smem + WN_LDS_V + (mbase + l31) * 16;                     // + ((tap*4 + g)*64)*16
+    const char* ldsB = smem + ((2 * rowpair) * WN_TC + l31) * 16;                // + g*WN_PLANE + (p*18 + dy)*16*16   (l31 = row-in-pair*16 + tc)
+
+    u32x4 st[WN_ST];
+    wino_load(a, cb, 0, tid, pl, st);
+    for (int c = 0; c < a.nch; ++c) {
+        __syncthreads();
+        if (!(a.ablate & 2) || c == 0) wino_commit(smem, tid, pl, st);
+        __syncthreads();
+        if (c + 1 < a.nch && !(a.ablate & 1)) wino_load(a, cb, c + 1, tid, pl, st);
+        if (a.ablate & 4) continue;
+        WSU_STATIC_FOR(3, dy, {
+            WSU_STATIC_FOR(4, p, {
+                constexpr int tap = dy * 4 + p;
+                const u32x4 ahi = *reinterpret_cast<const u32x4*>(ldsA + ((tap * 4 + hh) * 64) * 16);
+                const u32x4 alo = *reinterpret_cast<const u32x4*>(ldsA + ((tap * 4 + 2 + hh) * 64) * 16);
+                const u32x4 bhi = *reinterpret_cast<const u32x4*>(ldsB + hh * WN_PLANE + (p * WN_IH + dy) * (WN_TC * 16));
+                const u32x4 blo = *reinterpret_cast<const u32x4*>(ldsB + (2 + hh) * WN_PLANE + (p * WN_IH + dy) * (WN_TC * 16));
+                wsu_mfma_step<MODE>(alo, bhi, acc[p]);
+                wsu_mfma_step<MODE>(ahi, blo, acc[p]);
+                wsu_mfma_step<MODE>(ahi, bhi, acc[p]);
+            });
+        });
+    }
+
+    // ---- output transform A^T on the accumulators -> [pixel][channel] tile ------------------------------
+    __syncthreads();
+    constexpr int STRIDE = Epi<MODE>::STRIDE;
+    const int prow = 2 * rowpair + (l31 >> 4), pcol = 2 * (l31 & 15);
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+        const int co = mbase + 8 * g4 + 4 * hh;
+        f32x4 b4 = mk_f4(0.f, 0.f, 0.f, 0.f);
+        if (a.bias) b4 = *reinterpret_cast<const f32x4*>(a.bias + cb * WSU_COB + co);
+        f32x4 e, o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float m0 = acc[0][4 * g4 + k], m1 = acc[1][4 * g4 + k], m2 = acc[2][4 * g4 + k], m3 = acc[3][4 * g4 + k];
+            float ye = (m0 + m1) + m2 + b4[k], yo = (m1 - m2) - m3 + b4[k];
+            if (a.relu) { ye = fmaxf(ye, 0.f); yo = fmaxf(yo, 0.f); }
+            e[k] = ye; o[k] = yo;
+        }
+        *reinterpret_cast<f32x4*>(smem + (prow * TW + pcol) * STRIDE + co * 4) = e;
+        *reinterpret_cast<f32x4*>(smem + (prow * TW + pcol + 1) * STRIDE + co * 4) = o;
+    }
+    __syncthreads();
+    tile_epilogue<MODE, WN_NT, WN_TH>(a, smem, tid, n, y0, x0, cb);
+}
+
+// OIHW fp32 -> [cob][chunk of 16 ci][tap = row*4 + position][plane: hi ch 0-7, hi ch 8-15, lo 0-7, lo 8-15][co 64][8 x bf16]
+__global__ void pack_wino_kernel(const float* __restrict__ w, uint16_t* __restrict__ dst, int cin, int cout) {
+    const int nch = cin / 16;
+    const long long total = (long long)(cout / WSU_COB) * nch * WN_TAPS * WSU_GRAN * WSU_COB * 8;
+    for (long long d = (long long)blockIdx.x * blockDim.x + threadIdx.x; d < total; d += (long long)gridDim.x * blockDim.x) {
+        long long t = d;
+        const int e = t % 8; t /= 8;
+        const int co = t % WSU_COB; t /= WSU_COB;
+        const int g = t % WSU_GRAN; t /= WSU_GRAN;
+        const int tap = t % WN_TAPS; t /= WN_TAPS;
+        const int c = t % nch; t /= nch;
+        const int cb = (int)t;
+        const int ci = c * 16 + 8 * (g & 1) + e, part = g >> 1;
+        const int u = tap >> 2, pos = tap & 3;
+        const float* wr = w + (((size_t)(cb * WSU_COB + co) * cin + ci) * 3 + u) * 3;
+        const float w0 = wr[0], w1 = wr[1], w2 = wr[2];
+        float val;
+        if (pos == 0) val = w0;
+        else if (pos == 1) val = 0.5f * ((w0 + w2) + w1);
+        else if (pos == 2) val = 0.5f * ((w0 + w2) - w1);
+        else val = w2;
+        const float x = part ? wsu_bf16_lo_residual(val) : val;
+        dst[d] = __builtin_bit_cast(uint16_t, (__bf16)x);
+    }
+}
 
 // =====================================================================================================
 // Ping-pong kernel (experimental, WSU_CONV_IMPL=pp).  Why it was written: with two independent workgroups per CU the v1 kernel's matrix phase
@@ -1025,6 +1220,56 @@ static int conv3x3_launch_full(const void* x1, const void* x2, const void* w_pac
     if (mode == WSU_MODE_F32) return launch_conv<WSU_MODE_F32>(a, s);
     if (mode == WSU_MODE_BF16X3) return launch_conv<WSU_MODE_BF16X3>(a, s);
     return launch_conv<WSU_MODE_BF16>(a, s);
+}
+
+size_t wsu_conv3x3_wino_packed_bytes(int cin, int cout) {
+    if (cin <= 0 || cout <= 0 || cin % 16 || cout % WSU_COB) return 0;
+    return (size_t)(cout / WSU_COB) * (cin / 16) * WN_LDS_W;
+}
+
+int wsu_conv3x3_wino_pack(const float* w_oihw, void* w_packed, int cin, int cout, void* stream) {
+    WSU_REQUIRE(w_oihw && w_packed, "conv3x3_wino_pack: null pointer");
+    WSU_REQUIRE(cin > 0 && cin % 16 == 0 && cout > 0 && cout % WSU_COB == 0, "conv3x3_wino_pack: cin=%d must be a multiple of 16, cout=%d of %d", cin, cout, WSU_COB);
+    hipLaunchKernelGGL(pack_wino_kernel, dim3(1024), dim3(256), 0, static_cast<hipStream_t>(stream), w_oihw, (uint16_t*)w_packed, cin, cout);
+    return wsu_check_launch("pack_wino_kernel");
+}
+
+// Forward 3x3 conv in mode bf16x3 through the Winograd F(2,3) kernel: same arguments and fusions as wsu_conv3x3_fwd /
+// wsu_conv3x3_head_fwd (head_w == NULL: no head), weights from wsu_conv3x3_wino_pack, fp32 NHWC activations.
+int wsu_conv3x3_wino_fwd(const void* x1, const void* x2, const void* w_packed, const float* bias, void* y,
+                         void* y_pool, uint8_t* pool_idx,
+                         const float* head_w, const float* head_b, float* head_out, float* head_logit, int head_cout,
+                         int n, int h, int w, int c1, int c2, int cout, int relu, void* stream) {
+    WSU_REQUIRE(x1 && w_packed && (y || head_w), "conv3x3_wino: null pointer");
+    WSU_REQUIRE(!head_w || (head_out && cout == WSU_COB && head_cout >= 1 && head_cout <= 4), "conv3x3_wino: fused head needs cout == %d and 1..4 head planes", WSU_COB);
+    WSU_REQUIRE(n > 0 && h >= 2 && w >= 2, "conv3x3_wino: bad shape n=%d h=%d w=%d (reflect pad 1 needs h,w >= 2)", n, h, w);
+    WSU_REQUIRE(c1 > 0 && c1 % 16 == 0 && c2 >= 0 && c2 % 16 == 0 && (c2 == 0) == (x2 == nullptr), "conv3x3_wino: c1=%d c2=%d must be multiples of 16", c1, c2);
+    WSU_REQUIRE(cout > 0 && cout % WSU_COB == 0, "conv3x3_wino: cout=%d must be a multiple of %d", cout, WSU_COB);
+    WSU_REQUIRE((long long)n * h * w < 0x7FFFFFFFLL, "conv3x3_wino: n*h*w overflows int32");
+    WSU_REQUIRE(!(pool_idx && !y_pool), "conv3x3_wino: pool_idx without y_pool");
+    ConvArgs a{};
+    a.x1 = (const char*)x1; a.x2 = (const char*)x2; a.wp = (const char*)w_packed; a.bias = bias;
+    a.y = (char*)y; a.y2 = nullptr; a.ypool = (char*)y_pool; a.pidx = pool_idx;
+    a.n = n; a.h = h; a.w = w; a.c1 = c1; a.c2 = c2; a.cout = cout; a.csplit = cout;
+    a.tiles_x = (w + TW - 1) / TW; a.tiles_y = (h + WN_TH - 1) / WN_TH; a.ncb = cout / WSU_COB;
+    a.nch1 = c1 / 16; a.nch = (c1 + c2) / 16;
+    a.relu = relu; a.pad_zero = 0;
+    static int ablate = -1;                                            // timing-only experiment mask, 0 in production
+    if (ablate < 0) { const char* e = getenv("WSU_CONV_ABLATE"); ablate = e ? atoi(e) : 0; }
+    a.ablate = ablate;
+    a.head_w = head_w; a.head_b = head_b; a.head_out = head_out; a.head_logit = head_logit; a.head_cout = head_cout;
+    constexpr int EPI_BYTES = WN_TH * TW * Epi<WSU_MODE_BF16X3>::STRIDE;
+    constexpr int LDS = EPI_BYTES > WN_LDS_V + WN_LDS_W ? EPI_BYTES : WN_LDS_V + WN_LDS_W;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) { wsu_set_error("hipFuncSetAttribute(conv3x3_wino): %s", hipGetErrorString(e)); return WSU_ERR_HIP; }
+        attr_done = true;
+    }
+    const long long nblk = (long long)n * a.tiles_x * a.tiles_y * a.ncb;
+    WSU_REQUIRE(nblk > 0 && nblk <= 0x7FFFFFFFLL, "conv3x3_wino: grid of %lld workgroups out of range", nblk);
+    hipLaunchKernelGGL(conv3x3_wino_kernel, dim3((unsigned)nblk), dim3(WN_NT), LDS, static_cast<hipStream_t>(stream), a);
+    return wsu_check_launch("conv3x3_wino_kernel");
 }
 
 int wsu_conv3x3_launch_ex(const void* x1, const void* x2, const void* w_packed, const float* bias,

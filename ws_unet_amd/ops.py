@@ -170,6 +170,51 @@ def conv3x3_head(x1: torch.Tensor, x2: Optional[torch.Tensor], w_packed: torch.T
     return res[0] if len(res) == 1 else tuple(res)
 
 
+def pack_conv3x3_wino(w: torch.Tensor) -> torch.Tensor:
+    """OIHW fp32 -> Winograd F(2,3) packed weights of wsu_conv3x3_wino_fwd (mode bf16x3)."""
+    lib = _lib.load()
+    w = w.detach().contiguous().float()
+    _dev_check(w)
+    cout, cin = w.shape[0], w.shape[1]
+    nbytes = lib.wsu_conv3x3_wino_packed_bytes(cin, cout)
+    if nbytes == 0:
+        raise _lib.WsuError(f"Winograd packing needs cin % 16 == 0 and cout % 64 == 0 (got {cin}, {cout})")
+    wp = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    check(lib.wsu_conv3x3_wino_pack(w.data_ptr(), wp.data_ptr(), cin, cout, _stream()), "wsu_conv3x3_wino_pack")
+    return wp
+
+
+def conv3x3_wino(x1: torch.Tensor, x2: Optional[torch.Tensor], w_packed: torch.Tensor, bias: Optional[torch.Tensor], cout: int,
+                 relu: bool = True, pool: bool = False, pool_idx: bool = False,
+                 head_w: Optional[torch.Tensor] = None, head_b: Optional[torch.Tensor] = None, want_logit: bool = False, want_y: bool = True):
+    """3x3 reflect conv (+ReLU, +pool, +head) in mode bf16x3 through the Winograd kernel.  Returns y [, y_pool [, idx]] or,
+    with head_w, out [, logit][, y] like conv3x3_head."""
+    lib = _lib.load()
+    hw2 = None if head_w is None else head_w.detach().reshape(head_w.shape[0], -1)
+    _dev_check(x1, x2, w_packed, bias, hw2, head_b)
+    assert x1.dtype == torch.float32
+    n, h, w, c1 = x1.shape
+    c2 = 0 if x2 is None else x2.shape[3]
+    y = torch.empty((n, h, w, cout), dtype=torch.float32, device=x1.device) if (want_y or hw2 is None) else None
+    yp = torch.empty((n, h // 2, w // 2, cout), dtype=torch.float32, device=x1.device) if pool else None
+    idx = torch.empty((n, h // 2, w // 2, cout), dtype=torch.uint8, device=x1.device) if (pool and pool_idx) else None
+    hc = 0 if hw2 is None else hw2.shape[0]
+    out = torch.empty((n, hc, h, w), dtype=torch.float32, device=x1.device) if hc else None
+    logit = torch.empty_like(out) if (hc and want_logit) else None
+    meta = {"flops": 2.0 * 9 * (c1 + c2) * cout * n * h * w,
+            "bytes": float(n * h * w * ((c1 + c2) * 4 + (cout * 4 if y is not None else hc * 4)) + 9 * (c1 + c2) * cout * 4
+                           + (n * (h // 2) * (w // 2) * cout * 4 if pool else 0))}
+    check(_launch("conv3x3", meta, lambda: lib.wsu_conv3x3_wino_fwd(
+        x1.data_ptr(), _ptr(x2), w_packed.data_ptr(), _ptr(bias), _ptr(y), _ptr(yp), _ptr(idx),
+        _ptr(hw2), _ptr(head_b), _ptr(out), _ptr(logit), hc, n, h, w, c1, c2, cout, int(relu), _stream())), "wsu_conv3x3_wino_fwd")
+    if hc:
+        res = [out] + ([logit] if want_logit else []) + ([y] if want_y else [])
+        return res[0] if len(res) == 1 else tuple(res)
+    if pool:
+        return (y, yp, idx) if pool_idx else (y, yp)
+    return y
+
+
 def conv3x3_first(x_nchw: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], mode: int, relu: bool = True) -> torch.Tensor:
     lib = _lib.load()
     _dev_check(x_nchw, w, bias)
