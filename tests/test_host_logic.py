@@ -137,3 +137,69 @@ def test_imread_gray_png():
         np.testing.assert_array_equal(x4[..., c], x4[..., 3])
     np.testing.assert_array_equal(x4[..., 3:], imread_u8(GOLDEN / "cover_10.png"))
     assert imread4_f32(GOLDEN / "cover_10.png").dtype == np.float32
+
+
+def test_native_png_reader_matches_pil(tmp_path):
+    """libwsu_io (include/wsu_io.h): every PNG filter type, gray and RGB, vs PIL / the imread4_u8 luma; fallbacks and errors."""
+    import ctypes
+    from PIL import Image
+    from ws_unet_amd import _io, formula
+    from ws_unet_amd.imread import imread4_u8, png_shape, read_luma_batch
+    lib = _io.load()
+    assert lib.wsu_io_version() == 100
+    text = (Path(__file__).resolve().parent.parent / "include" / "wsu_io.h").read_text()
+    import re
+    decl = sorted(set(re.findall(r"\b(wsu_[a-z0-9_]+)\s*\(", re.sub(r"/\*.*?\*/", "", text, flags=re.S))))
+    assert decl == sorted(_io.SIGNATURES) and all(hasattr(lib, s) for s in decl)
+    u8 = formula.synthetic_images(3, 40, 56, seed=11)
+    files = []
+    for i, (img, kw) in enumerate([(u8[0], {}), (u8[1], {"compress_level": 1}), (u8[2], {"optimize": True})]):
+        f = tmp_path / f"g{i}.png"
+        Image.fromarray(img).save(f, **kw)
+        files.append(f)
+    # a noisy and a smooth RGB image (different filter choices inside the encoder)
+    rgb = np.stack([u8[0], u8[1], u8[2]], axis=-1)
+    Image.fromarray(rgb).save(tmp_path / "c0.png")
+    grad = (np.add.outer(np.arange(40), np.arange(56)) % 256).astype(np.uint8)
+    Image.fromarray(np.stack([grad, grad[::-1], grad.T[:40, :56] if grad.T.shape == (40, 56) else grad], axis=-1)).save(tmp_path / "c1.png")
+    files += [tmp_path / "c0.png", tmp_path / "c1.png"]
+    assert png_shape(files[0]) == (40, 56)
+    out = read_luma_batch(files, threads=3)
+    for i, f in enumerate(files):
+        np.testing.assert_array_equal(out[i], imread4_u8(f)[..., 3], err_msg=str(f))
+    np.testing.assert_array_equal(read_luma_batch([GOLDEN / "cover_10.png"])[0], imread4_u8(GOLDEN / "cover_10.png")[..., 3])
+    # unsupported variant (palette) falls back to PIL for that file only
+    Image.fromarray(u8[0]).convert("P").save(tmp_path / "p.png")
+    out2 = read_luma_batch([files[0], tmp_path / "p.png"])
+    np.testing.assert_array_equal(out2[1], imread4_u8(tmp_path / "p.png")[..., 3])
+    # errors: ragged shapes, missing file
+    Image.fromarray(u8[0][:20]).save(tmp_path / "small.png")
+    with pytest.raises(ValueError, match="shape"):
+        read_luma_batch([files[0], tmp_path / "small.png"])
+    with pytest.raises(OSError):
+        read_luma_batch([files[0], tmp_path / "missing.png"])
+    assert read_luma_batch([]).shape[0] == 0
+
+
+def test_batched_iterator_prefetch_runs_one_chunk_ahead(tmp_path):
+    (tmp_path / "images").mkdir()
+    names = [f"images/{i}.png" for i in range(7)]
+    (tmp_path / "images" / "files.csv").write_text("name,height,width\n" + "".join(f"{n},8,8\n" for n in names))
+    log = []
+
+    def fn(fnames, kws, prefetched=None):
+        log.append(("run", [Path(f).name for f in fnames], prefetched))
+        return [{**kw, "tag": prefetched} for kw in kws]
+
+    def prefetch(fnames, kws):
+        log.append(("pre", [Path(f).name for f in fnames]))
+        return "staged:" + Path(fnames[0]).name
+
+    fn.prefetch = prefetch
+    df = fabrika.precovers(iterator="batched", convert_to="pandas", ignore_missing=False, batch_size=3)(fn)(tmp_path)
+    assert df["name"].tolist() == sorted(names) and len(df) == 7
+    assert df["tag"].tolist() == ["staged:0.png"] * 3 + ["staged:3.png"] * 3 + ["staged:6.png"]
+    runs = [e for e in log if e[0] == "run"]
+    assert [r[1] for r in runs] == [["0.png", "1.png", "2.png"], ["3.png", "4.png", "5.png"], ["6.png"]]
+    # every chunk was staged exactly once, and staging of chunk k+1 was submitted before chunk k ran
+    assert [e[1][0] for e in log if e[0] == "pre"] == ["0.png", "3.png", "6.png"]

@@ -41,4 +41,4 @@ err = float(np.abs(dfb["beta_hat"].to_numpy(float)[:n1] - df1["beta_hat"].to_num
 print(json.dumps({"metric": "evaluate loop images/s (PNG on disk -> beta_hat, l1)", "mode": a.mode, "images": a.images,
                   "batched_images_per_s": a.images / t_b, "per_image_api_images_per_s": n1 / t_1,
                   "png_decode_ms_per_image_1thread": t_dec * 1e3, "max_abs_beta_diff_batched_vs_per_image": err,
-                  "note": "batched path is bound by single-thread PNG decode on the host, not by the GPU"}))
+                  "note": "batched path: PNG decode by libwsu_io on C++ threads, one chunk ahead of the GPU (fabrika iterator='batched' prefetch); the per-image API decodes with PIL on one thread"}))

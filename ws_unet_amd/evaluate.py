@@ -123,8 +123,7 @@ _POOL = None
 
 
 def _decode_pool():
-    """PNG decode is the bottleneck of a GPU evaluate run (2.6 ms per 512x512 image on one host thread vs 0.6 ms of GPU
-    time); PIL releases the GIL while decoding, so a small thread pool over the batch's files restores the balance."""
+    """Thread pool for user-supplied `imread` callables (the default reader goes through libwsu_io instead)."""
     global _POOL
     if _POOL is None:
         import os
@@ -146,27 +145,60 @@ def predict_u8_batch(x_u8: torch.Tensor, model: torch.nn.Module):
     return ops.ws_residual_stats(x_u8, y[:, 0].contiguous())
 
 
-def predict_unet_batch(fnames, kws, *, model: torch.nn.Module, imread: typing.Callable = imread4_u8, device=None, **_ignored):
-    """Batched predict_unet for `fabrika` iterator='batched': one result dict per (fname, kw)."""
-    imgs = _decode_pool().map(lambda f: np.ascontiguousarray(imread(f)[..., 3]), fnames)
-    imgs = list(imgs)
-    shapes = {im.shape for im in imgs}
-    if shapes != {(512, 512)}:
+_PINNED = {}
+
+
+def load_planes_u8(fnames, imread: typing.Callable = imread4_u8) -> typing.Optional[torch.Tensor]:
+    """Y planes of a chunk of files as one (N,H,W) uint8 host tensor, or None when the files differ in shape.
+    With the default reader the files are decoded by libwsu_io on C++ threads straight into a reused pinned buffer
+    (PIL / cv2 style readers hold the GIL: Python threads do not scale them); any other `imread` is called per file."""
+    fnames = [str(f) for f in fnames]
+    if imread is imread4_u8:
+        from .imread import png_shape, read_luma_batch
+        hw = png_shape(fnames[0]) or imread4_u8(fnames[0]).shape[:2]
+        key = (len(fnames), hw[0], hw[1])
+        if key not in _PINNED:
+            if len(_PINNED) > 8:
+                _PINNED.clear()
+            pin = torch.cuda.is_available()
+            _PINNED[key] = [[torch.empty(key, dtype=torch.uint8, pin_memory=pin) for _ in range(2)], 0]
+        slot = _PINNED[key]
+        buf = slot[0][slot[1]]                               # two buffers: chunk k+1 is decoded while chunk k is uploaded / in use
+        slot[1] ^= 1
+        try:
+            read_luma_batch(fnames, out=buf.numpy())
+        except ValueError:                                   # ragged shapes
+            return None
+        return buf
+    imgs = list(_decode_pool().map(lambda f: np.ascontiguousarray(imread(f)[..., 3]), fnames))
+    if len({im.shape for im in imgs}) != 1:
+        return None
+    return torch.from_numpy(np.stack(imgs))
+
+
+def predict_unet_batch(fnames, kws, *, model: torch.nn.Module, imread: typing.Callable = imread4_u8, device=None,
+                       prefetched=None, **_ignored):
+    """Batched predict_unet for `fabrika` iterator='batched': one result dict per (fname, kw).  `prefetched`: the planes of
+    this chunk if the iterator already decoded them (load_planes_u8 run one chunk ahead)."""
+    planes = prefetched[0] if prefetched is not None else load_planes_u8(fnames, imread)
+    if planes is None or tuple(planes.shape[1:]) != (512, 512):
         # CenterCrop(512) would change the geometry; only the per-image path defines what happens then
         return [predict_unet(f, model, imread=imread4_f32, **kw) for f, kw in zip(fnames, kws)]
-    dev = _model_device(model)
-    x_u8 = torch.from_numpy(np.stack(imgs)).to(dev, non_blocking=True)
+    x_u8 = planes.to(_model_device(model), non_blocking=True)
     beta, l1 = predict_u8_batch(x_u8, model)
-    beta, l1 = beta.cpu().numpy(), l1.cpu().numpy()
+    beta, l1 = beta.cpu().numpy(), l1.cpu().numpy()          # also orders the reuse of the pinned staging buffer
     return [{**kw, "beta_hat": beta[i], "l1": l1[i]} for i, kw in enumerate(kws)]
 
 
 def _drop_model_kw(fn):
-    def wrapped(fnames, kws):
+    def wrapped(fnames, kws, prefetched=None):
         model = kws[0]["model"]
         extra = {k: kws[0][k] for k in ("imread",) if k in kws[0]}
         clean = [{k: v for k, v in kw.items() if k not in ("model", "imread", "device")} for kw in kws]
-        return fn(fnames, clean, model=model, **extra)
+        return fn(fnames, clean, model=model, prefetched=prefetched, **extra)
+    # decode of the next chunk beside the GPU work of the current one (fabrika iterator='batched'); a 1-tuple so that
+    # "ragged chunk" (None) stays distinguishable from "nothing prefetched"
+    wrapped.prefetch = lambda fnames, kws: (load_planes_u8(fnames, kws[0].get("imread", imread4_u8)),)
     return wrapped
 
 

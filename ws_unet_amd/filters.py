@@ -66,4 +66,5 @@ def get_processor_2d(channels: typing.List[int]) -> typing.Callable:
     def process_gray(x: np.ndarray) -> np.ndarray:
         return x[..., channels].astype("float32")
 
+    process_gray.plane_selector = tuple(channels)          # lets the batched WS path skip the host arrays for the Y plane
     return process_gray

@@ -131,16 +131,34 @@ def attack_stego(*args, **kw):
 
 # ---- batched device path ------------------------------------------------------------------------------
 
+def _native_planes_ok(channels, pixel_estimator, imread, process_image) -> bool:
+    """The default gray pipeline (Y plane, built-in predictor) needs no host arrays: native batched decode -> pinned buffer -> device."""
+    builtin = isinstance(pixel_estimator, (UNetEstimator, filters.FilterEstimator))
+    plain = process_image is None or getattr(process_image, "plane_selector", None) == (3,)
+    return builtin and imread is imread4_u8 and plain and tuple(channels) == (3,)
+
+
 def attack_batch(fnames, kws, *, channels, pixel_estimator, mean_estimator=NAMED_FILTERS["AVG"], correct_bias=False,
-                 weighted=1, imread=imread4_u8, process_image=None, **_ignored):
+                 weighted=1, imread=imread4_u8, process_image=None, prefetched=None, **_ignored):
     """`attack` for a chunk of files (fabrika iterator='batched'): one result dict per (fname, kw)."""
-    process_image = process_image or filters.get_processor_2d(channels)
-    planes = list(_decode_pool().map(lambda f: process_image(imread(f)), fnames))
-    if len({p.shape for p in planes}) != 1:
+    if _native_planes_ok(channels, pixel_estimator, imread, process_image):
+        from ..evaluate import load_planes_u8
+        u8 = prefetched[0] if prefetched is not None else load_planes_u8(fnames, imread)
+        planes = None if u8 is None else [None] * len(fnames)
+    else:
+        process_image = process_image or filters.get_processor_2d(channels)
+        planes = list(_decode_pool().map(lambda f: process_image(imread(f)), fnames))
+        u8 = None
+        if len({p.shape for p in planes}) != 1:
+            planes = None
+    if planes is None:
+        process_image = process_image or filters.get_processor_2d(channels)
         return [attack(f, channels, pixel_estimator, mean_estimator, correct_bias, weighted, imread, process_image, **kw)
                 for f, kw in zip(fnames, kws)]
     try:
-        x_u8 = torch.from_numpy(np.stack([_as_u8_plane(p) for p in planes])).to(_device_of(pixel_estimator))
+        if u8 is None:
+            u8 = torch.from_numpy(np.stack([_as_u8_plane(p) for p in planes]))
+        x_u8 = u8.to(_device_of(pixel_estimator), non_blocking=True)
         beta = _stat(x_u8, pixel_estimator, mean_estimator, weighted, correct_bias, host_planes=planes).cpu().numpy()
     except ValueError:
         beta = [None] * len(fnames)
@@ -152,10 +170,19 @@ _ATTACK_KEYS = ("channels", "pixel_estimator", "mean_estimator", "correct_bias",
 
 
 def _split_attack_kw(fn):
-    def wrapped(fnames, kws):
+    def wrapped(fnames, kws, prefetched=None):
         shared = {k: kws[0][k] for k in _ATTACK_KEYS if k in kws[0]}
         clean = [{k: v for k, v in kw.items() if k not in _ATTACK_KEYS} for kw in kws]
-        return fn(fnames, clean, **shared)
+        return fn(fnames, clean, prefetched=prefetched, **shared)
+
+    def prefetch(fnames, kws):
+        k0 = kws[0]
+        if not _native_planes_ok(k0["channels"], k0["pixel_estimator"], k0.get("imread", imread4_u8), k0.get("process_image")):
+            return None
+        from ..evaluate import load_planes_u8
+        return (load_planes_u8(fnames, imread4_u8),)
+
+    wrapped.prefetch = prefetch
     return wrapped
 
 
