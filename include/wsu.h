@@ -145,6 +145,10 @@ int wsu_filter3x3_valid_f32(const float* x, const float* filter, float* y, int n
 /* (x ^ 1 - x) / 255. as fp32: the network input of the bias term `pixel_estimator(x_bar - x)` (estimate.py:127, evaluate.py:45) */
 int wsu_lsb_delta_unit_f32(const uint8_t* x, float* y, size_t count, void* stream);
 
+/* Epoch meter of the training loop (src/_defs/metrics.py:122-142 WSMeter.update): per-image fp64 beta_hat over the interior from the
+ * FLOAT inputs x01 and outputs y01, both (N,H,W) single-plane fp32 in [0,1]; the caller clips and averages |beta - alpha/2|. */
+int wsu_ws_meter_beta(const float* x01, const float* y01, double* beta_hat, int n, int h, int w, void* stream);
+
 /* ---- u8 -> [0,1] fp32, numpy float32 division semantics of evaluate.py:45 (x / 255.) */
 int wsu_u8_to_unit_f32(const uint8_t* x, float* y, size_t count, void* stream);
 

@@ -226,6 +226,19 @@ def test_training_reduces_loss_and_checkpoints(tmp_path):
     assert set(ck) == {"epoch", "state_dict", "best_val_loss", "patience", "optimizer", "scheduler"}
     assert list(ck["state_dict"]) == list(model.state_dict())
     assert (tmp_path / "run" / "config.json").exists() and (tmp_path / "run" / "log" / "scalars.csv").exists()
+    # the device-side epoch meters (wsu_ws_meter_beta + the fused loss kernel's L1 sum) equal the reference's numpy meters
+    from ws_unet_amd import metrics
+    mae, wsm = metrics.MAEMeter(multiplier=1), metrics.WSMeter()
+    with torch.no_grad():
+        for x, (c, a) in loader:
+            o = model(x.to(DEV)).cpu().numpy()
+            mae.update(c.numpy(), o)
+            wsm.update(x.numpy(), o, a.numpy())
+    val = tr._run_epoch(loader, False, 99)
+    got = {t: v for e, t, v in tr.scalars if e == 99}
+    assert abs(got["val/mae"] - mae.avg) <= 1e-6 * max(1.0, abs(mae.avg))
+    assert abs(got["val/ws"] - wsm.avg) <= 1e-6 * max(1.0, abs(wsm.avg)) + 1e-9
+    assert val == got["val/loss"]
 
 
 def test_saliency_style_input_gradient():

@@ -54,6 +54,7 @@ SIGNATURES = {
     "wsu_ws_attack": (c_int, [_P, _P, _P, _P, _P, c_int, c_float, c_int, c_int, _P, _P, _P, c_size_t, c_int, c_int, c_int, _P]),
     "wsu_lsb_delta_unit_f32": (c_int, [_P, _P, c_size_t, _P]),
     "wsu_filter3x3_valid_f32": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),
+    "wsu_ws_meter_beta": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),
     "wsu_u8_to_unit_f32": (c_int, [_P, _P, c_size_t, _P]),
     # ---- backward / train step
     "wsu_conv3x3_bwd_data": (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, _P] + [c_int] * 6 + [_P]),

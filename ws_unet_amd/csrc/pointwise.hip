@@ -236,6 +236,31 @@ __global__ __launch_bounds__(1024) void ws_stats_kernel(const uint8_t* __restric
     }
 }
 
+// Epoch meter of the training loop, src/_defs/metrics.py:122-142 `WSMeter.update`: per-image beta_hat on the [1:-1,1:-1] interior from
+// the float inputs (xi = x*255 in float32, x_bar = int(round(xi)) ^ 1, the product in float64 like numpy's float32 - int64 promotion).
+__global__ __launch_bounds__(1024) void ws_meter_kernel(const float* __restrict__ x01, const float* __restrict__ y01,
+                                                        double* __restrict__ beta_hat, int h, int w) {
+    __shared__ double sb[1024];
+    const int nn = blockIdx.x, tid = threadIdx.x;
+    const int ih = h - 2, iw = w - 2;
+    const long long cnt = (long long)ih * iw;
+    double ab = 0.0;
+    for (long long i = tid; i < cnt; i += 1024) {
+        const int r = (int)(i / iw) + 1, c = (int)(i % iw) + 1;
+        const size_t o = ((size_t)nn * h + r) * w + c;
+        const float xi = __fmul_rn(x01[o], 255.0f), xh = __fmul_rn(y01[o], 255.0f);
+        const long long xbar = (long long)rintf(xi) ^ 1LL;                       // np.round = half-to-even = rintf
+        ab += ((double)xi - (double)xbar) * (double)__fsub_rn(xi, xh) / (double)cnt;
+    }
+    sb[tid] = ab;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if (tid < s) sb[tid] += sb[tid + s];
+        __syncthreads();
+    }
+    if (tid == 0) beta_hat[nn] = sb[0];
+}
+
 }  // namespace
 
 extern "C" {
@@ -315,6 +340,13 @@ int wsu_ws_residual_stats(const uint8_t* x_u8, const float* y01, float* beta_hat
     WSU_REQUIRE(n > 0 && h >= 3 && w >= 3, "ws_residual_stats: bad shape n=%d h=%d w=%d", n, h, w);
     hipLaunchKernelGGL(ws_stats_kernel, dim3(n), dim3(1024), 0, static_cast<hipStream_t>(stream), x_u8, y01, beta_hat, l1, h, w);
     return wsu_check_launch("ws_stats_kernel");
+}
+
+int wsu_ws_meter_beta(const float* x01, const float* y01, double* beta_hat, int n, int h, int w, void* stream) {
+    WSU_REQUIRE(x01 && y01 && beta_hat, "ws_meter_beta: null pointer");
+    WSU_REQUIRE(n > 0 && h >= 3 && w >= 3, "ws_meter_beta: bad shape n=%d h=%d w=%d", n, h, w);
+    hipLaunchKernelGGL(ws_meter_kernel, dim3(n), dim3(1024), 0, static_cast<hipStream_t>(stream), x01, y01, beta_hat, h, w);
+    return wsu_check_launch("ws_meter_kernel");
 }
 
 }  // extern "C"

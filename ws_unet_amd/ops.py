@@ -362,6 +362,18 @@ def lsb_delta_unit(x_u8: torch.Tensor) -> torch.Tensor:
     return y
 
 
+def ws_meter_beta(x01: torch.Tensor, y01: torch.Tensor) -> torch.Tensor:
+    """WSMeter's per-image beta_hat (fp64, interior crop) from float inputs / outputs of shape (N,1,H,W) or (N,H,W)."""
+    lib = _lib.load()
+    _dev_check(x01, y01)
+    assert x01.dtype == torch.float32 and y01.dtype == torch.float32 and x01.numel() == y01.numel()
+    n, h, w = x01.shape[0], x01.shape[-2], x01.shape[-1]
+    assert x01.numel() == n * h * w, "single-plane images expected"
+    beta = torch.empty(n, dtype=torch.float64, device=x01.device)
+    check(lib.wsu_ws_meter_beta(x01.data_ptr(), y01.data_ptr(), beta.data_ptr(), n, h, w, _stream()), "wsu_ws_meter_beta")
+    return beta
+
+
 def u8_to_unit(x_u8: torch.Tensor) -> torch.Tensor:
     lib = _lib.load()
     _dev_check(x_u8)

@@ -110,6 +110,7 @@ class Trainer:
         self.patience0 = self.patience = patience
         self.best_val_loss = np.inf
         self.scalars = []                                                # (epoch, tag, value) rows, tags as in the tfevents
+        self._last_l1 = None
         if self.out_dir and self.rank == 0:
             (self.out_dir / "model").mkdir(parents=True, exist_ok=True)
             (self.out_dir / "log").mkdir(parents=True, exist_ok=True)
@@ -121,6 +122,7 @@ class Trainer:
         self.opt.zero_grad()
         outputs = self.model(inputs)
         loss = self.criterion(outputs, (covers, alphas), inputs)
+        self._last_l1 = self.criterion.last_parts[0]
         loss.backward()
         scale = parallel.allreduce_flat_(self.opt.flat_grad)             # C1: one 7.45 MB fp32 bucket over xGMI
         self.opt.step(grad_scale=scale)
@@ -132,23 +134,39 @@ class Trainer:
         loss, _, parts, _ = ops.l1ws_loss_fwd_bwd(outputs, covers.contiguous(), inputs.contiguous(),
                                                    torch.as_tensor(alphas, dtype=torch.float32, device=outputs.device),
                                                    self.criterion.use_l1, self.criterion.use_ws)
+        self._last_l1 = parts[0]
         return loss, outputs
 
+    def step_meters(self, inputs, covers, outputs, alphas, loss) -> torch.Tensor:
+        """[loss, mae, ws] of one batch as a DEVICE fp64 tensor, with the batch values the reference's meters take
+        (src/_defs/metrics.py: MAEMeter(multiplier=1) = mean |cover - output|, WSMeter = mean |clip(beta_hat, 0) - alpha/2| on
+        the interior crop).  Nothing but three scalars per batch ever leaves the device."""
+        if self._last_l1 is not None and self.criterion.use_l1 != 2:    # the fused loss kernel already reduced mean |cover - out|
+            mae = self._last_l1.double()
+        else:
+            mae = (covers - outputs).abs().mean(dtype=torch.float64)
+        beta = ops.ws_meter_beta(inputs.contiguous(), outputs.contiguous())
+        ws = (beta.clamp_min(0) - alphas.double() / 2.).abs().mean()
+        return torch.stack([loss.detach().double().reshape(()), mae.reshape(()), ws])
+
     def _run_epoch(self, loader, train: bool, epoch: int):
-        lm, mae, ws = metrics.LossMeter(), metrics.MAEMeter(multiplier=1), metrics.WSMeter()
+        dev = next(self.model.parameters()).device
+        acc = torch.zeros(3, dtype=torch.float64, device=dev)           # sum loss*n, sum mae, sum ws
+        nimg, nbatch = 0, 0
         for inputs, (covers, alphas) in loader:
-            dev = next(self.model.parameters()).device
-            inputs, covers = inputs.to(dev), covers.to(dev)
+            inputs, covers = inputs.to(dev, non_blocking=True), covers.to(dev, non_blocking=True)
             alphas = torch.as_tensor(alphas, dtype=torch.float32, device=dev)
             loss, outputs = (self.train_step if train else self.eval_step)(inputs.clone(), covers, alphas)
-            lm.update(loss.item(), inputs.shape[0])
-            o = outputs.cpu().numpy()
-            mae.update(covers.cpu().numpy(), o)
-            ws.update(inputs.cpu().numpy(), o, alphas.cpu().numpy())
+            m = self.step_meters(inputs, covers, outputs, alphas, loss)
+            acc += m * torch.tensor([float(inputs.shape[0]), 1.0, 1.0], dtype=torch.float64, device=dev)
+            nimg += inputs.shape[0]
+            nbatch += 1
+        tot = acc.cpu().numpy()                                          # the epoch's only device -> host copy
+        avg = {"loss": tot[0] / max(nimg, 1), "mae": tot[1] / max(nbatch, 1), "ws": tot[2] / max(nbatch, 1)}
         prefix = "train/" if train else "val/"
-        for meter in (lm, mae, ws):
-            self.scalars.append((epoch, prefix + meter.name, float(meter.avg)))
-        return lm.avg
+        for name in ("loss", "mae", "ws"):
+            self.scalars.append((epoch, prefix + name, float(avg[name])))
+        return float(avg["loss"])
 
     def save_checkpoint(self, epoch: int, val_loss: float):
         """Checkpoint dict keys and files as src/detector/train.py:281-296 writes them."""
