@@ -263,3 +263,33 @@ def test_saliency_style_input_gradient():
     assert nz[:, 0].min() >= 30 - 24 and nz[:, 0].max() <= 30 + 24           # receptive field of unet_2 ~ +-22
     with torch.no_grad():
         assert model(torch.zeros(0, 1, 64, 64, device=DEV)).shape == (0, 1, 64, 64)     # empty batch
+
+
+def test_pair_loader_feeds_the_trainer_from_png_files(tmp_path):
+    """PNG pairs on disk -> libwsu_io decode -> uint8 upload -> wsu_u8_to_unit_f32 -> Trainer.fit; the device batches equal the
+    host-logic (uint8) batches / 255 exactly."""
+    from PIL import Image
+    from ws_unet_amd.data.pairs import PairLoader
+    (tmp_path / "images").mkdir()
+    sd = tmp_path / "stego_LSBR_alpha_0.4"
+    sd.mkdir()
+    u8 = formula.synthetic_images(6, 64, 64, seed=88)
+    for i in range(6):
+        Image.fromarray(u8[i]).save(tmp_path / "images" / f"{i}.png")
+        Image.fromarray(formula.lsbr_embed(u8[i], 0.4, seed=i)).save(sd / f"{i}.png")
+    (tmp_path / "images" / "files.csv").write_text("name,height,width\n" + "".join(f"images/{i}.png,64,64\n" for i in range(6)))
+    (sd / "files.csv").write_text("name,height,width,stego_method,alpha\n" + "".join(f"stego_LSBR_alpha_0.4/{i}.png,64,64,LSBR,0.4\n" for i in range(6)))
+    host = list(PairLoader(tmp_path, None, "LSBR", 0.4, batch_size=4, seed=3))
+    dev = PairLoader(tmp_path, None, "LSBR", 0.4, batch_size=4, seed=3, device=torch.device(DEV))
+    got = list(dev)
+    assert len(got) == len(host) == 3
+    for (x, (c, a)), (xh, (ch, ah)) in zip(got, host):
+        assert x.is_cuda and x.shape == (4, 1, 64, 64) and x.dtype == torch.float32
+        np.testing.assert_array_equal(x[:, 0].cpu().numpy(), xh.numpy().astype(np.float32) / np.float32(255.))
+        np.testing.assert_array_equal(c[:, 0].cpu().numpy(), ch.numpy().astype(np.float32) / np.float32(255.))
+        assert torch.equal(a.cpu(), ah)
+    model = gpu_model(1, "default", "f32")
+    tr = Trainer(model, loss="l1ws", lr=1e-3, patience=5)
+    tr.fit(dev, dev, num_epochs=3)
+    tl = [v for e, t, v in tr.scalars if t == "train/loss"]
+    assert len(tl) == 3 and tl[-1] < tl[0] and all(np.isfinite(tl))

@@ -203,3 +203,56 @@ def test_batched_iterator_prefetch_runs_one_chunk_ahead(tmp_path):
     assert [r[1] for r in runs] == [["0.png", "1.png", "2.png"], ["3.png", "4.png", "5.png"], ["6.png"]]
     # every chunk was staged exactly once, and staging of chunk k+1 was submitted before chunk k ran
     assert [e[1][0] for e in log if e[0] == "pre"] == ["0.png", "3.png", "6.png"]
+
+
+def _pair_dataset(root, n=10, size=16):
+    from PIL import Image
+    from ws_unet_amd import formula
+    (root / "images").mkdir()
+    u8 = formula.synthetic_images(n, size, size, seed=21)
+    for i in range(n):
+        Image.fromarray(u8[i]).save(root / "images" / f"{i}.png")
+    (root / "images" / "files.csv").write_text("name,height,width\n" + "".join(f"images/{i}.png,{size},{size}\n" for i in range(n)))
+    sd = root / "stego_LSBR_alpha_0.4"
+    sd.mkdir()
+    st = {}
+    for i in range(n - 1):                                    # cover n-1 has no stego twin
+        st[i] = formula.lsbr_embed(u8[i], 0.4, seed=i)
+        Image.fromarray(st[i]).save(sd / f"{i}.png")
+    (sd / "files.csv").write_text("name,height,width,stego_method,alpha\n" + "".join(
+        f"stego_LSBR_alpha_0.4/{i}.png,{size},{size},LSBR,0.4\n" for i in range(n - 1)))
+    return u8, st
+
+
+def test_pair_loader_batches_and_rank_shards(tmp_path):
+    from ws_unet_amd.data.pairs import PairLoader
+    u8, st = _pair_dataset(tmp_path)
+    ld = PairLoader(tmp_path, None, "LSBR", 0.4, batch_size=4, shuffle=False)
+    assert len(ld) == 4 and len(ld.covers) == 9               # 9 pairs, 2 per batch, tail dropped
+    batches = list(ld)
+    assert len(batches) == 4
+    x, (c, a) = batches[0]
+    assert x.dtype == torch.uint8 and x.shape == (4, 16, 16) and a.tolist() == [0.0, pytest.approx(0.4), 0.0, pytest.approx(0.4)]
+    names = sorted(f"images/{i}.png" for i in range(9))        # fabrika's lexical order
+    i0, i1 = int(Path(names[0]).stem), int(Path(names[1]).stem)
+    np.testing.assert_array_equal(x[0].numpy(), u8[i0]); np.testing.assert_array_equal(x[1].numpy(), st[i0])
+    np.testing.assert_array_equal(c[0].numpy(), u8[i0]); np.testing.assert_array_equal(c[1].numpy(), u8[i0])
+    np.testing.assert_array_equal(x[3].numpy(), st[i1]); np.testing.assert_array_equal(c[3].numpy(), u8[i1])
+    # data-parallel shards: disjoint, equal step counts, union = the single-rank epoch (same seed / epoch)
+    full = PairLoader(tmp_path, None, "LSBR", 0.4, batch_size=2, shuffle=True, seed=5)
+    r0 = PairLoader(tmp_path, None, "LSBR", 0.4, batch_size=2, shuffle=True, seed=5, rank=0, world=2)
+    r1 = PairLoader(tmp_path, None, "LSBR", 0.4, batch_size=2, shuffle=True, seed=5, rank=1, world=2)
+    assert len(r0) == len(r1) == 4
+    p0, p1 = r0.pair_order().ravel().tolist(), r1.pair_order().ravel().tolist()
+    assert not set(p0) & set(p1) and sorted(p0 + p1) == sorted(full.pair_order().ravel().tolist()[:8])
+    e0 = full.pair_order().ravel().tolist()
+    full.reshuffle()
+    assert full.pair_order().ravel().tolist() != e0 and sorted(full.pair_order().ravel().tolist()) == sorted(e0)
+    # covers only (the 'dropout' run): one sample per cover, alpha 0, the unpaired cover is kept
+    co = PairLoader(tmp_path, None, None, None, batch_size=5, covers_only=True, shuffle=False)
+    xb, (cb, ab) = next(iter(co))
+    assert len(co.covers) == 10 and torch.equal(xb, cb) and ab.tolist() == [0.0] * 5
+    with pytest.raises(ValueError, match="even"):
+        PairLoader(tmp_path, None, "LSBR", 0.4, batch_size=3)
+    with pytest.raises(Exception):
+        PairLoader(tmp_path, None, "HILLR", 0.4, batch_size=2)
