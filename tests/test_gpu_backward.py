@@ -293,3 +293,44 @@ def test_pair_loader_feeds_the_trainer_from_png_files(tmp_path):
     tr.fit(dev, dev, num_epochs=3)
     tl = [v for e, t, v in tr.scalars if t == "train/loss"]
     assert len(tl) == 3 and tl[-1] < tl[0] and all(np.isfinite(tl))
+
+
+def test_train_driver_replays_a_published_style_config(tmp_path):
+    """ws_unet_amd.train.train(): run directory layout, config.json keys, checkpoints, weight-only resume (detector/train.py:143-304)."""
+    import json
+    from PIL import Image
+    from ws_unet_amd import train as train_mod
+    data = tmp_path / "data"
+    (data / "images").mkdir(parents=True)
+    sd = data / "stego_LSBR_alpha_0.4_independent_images"
+    sd.mkdir()
+    u8 = formula.synthetic_images(6, 64, 64, seed=91)
+    rows = []
+    for i in range(6):
+        Image.fromarray(u8[i]).save(data / "images" / f"{i}.png")
+        Image.fromarray(formula.lsbr_embed(u8[i], 0.4, seed=i)).save(sd / f"{i}.png")
+    hdr = "name,height,width,channels,device,stego_method,simulator,alpha,demosaic,color,color_strategy,beta_hat\n"
+    def split(ids):
+        return hdr + "".join(f"images/{i}.png,64,64,,,,,,,,,\n" for i in ids) + "".join(
+            f"stego_LSBR_alpha_0.4_independent_images/{i}.png,64,64,,,LSBR,mi,0.4,,,independent,\n" for i in ids)
+    (data / "split_tr.csv").write_text(split([0, 1, 2, 3]))
+    (data / "split_va.csv").write_text(split([4, 5]))
+    cfg = {"dataset": str(data), "output_dir": str(tmp_path / "runs"), "network": "unet_1", "stego_method": "LSBR", "alpha": "0.400",
+           "loss": "l1ws", "batch_size": 4, "num_epochs": 2, "patience": 5, "learning_rate": 1e-3, "drop_rate": 0.0, "seed": 7,
+           "SLURM_JOB_ID": "42", "mode": "f32"}
+    best = train_mod.train(cfg)
+    runs = list((tmp_path / "runs" / "LSBR").iterdir())
+    assert len(runs) == 1 and runs[0].name.split("-", 2)[1] == "42"
+    assert runs[0].name.endswith("unet_1-alpha_0.400_grayscale_l1ws_0.25_lr_0.001_")
+    saved = json.loads((runs[0] / "config.json").read_text())
+    assert saved["network"] == "unet_1" and saved["tr_csv"] == "split_tr.csv" and saved["batch_size"] == 4 and "mode" not in saved
+    for f in ("model/latest_model.pt.tar", "model/best_model.pt.tar", "log/scalars.csv"):
+        assert (runs[0] / f).exists(), f
+    assert np.isfinite(best)
+    # the evaluate-side discovery finds the run, and a second run can resume from its weights
+    from ws_unet_amd import evaluate
+    assert evaluate.get_model_name("LSBR", model_dir=tmp_path / "runs") == runs[0].name
+    best2 = train_mod.train({**cfg, "resume": runs[0].name, "num_epochs": 1, "experiment_dir_suffix": "ft"})
+    assert np.isfinite(best2) and len(list((tmp_path / "runs" / "LSBR").iterdir())) == 2
+    with pytest.raises(Exception, match="no checkpoint"):
+        train_mod.train({**cfg, "resume": "missing-run"})

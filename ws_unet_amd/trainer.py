@@ -188,6 +188,8 @@ class Trainer:
 
     def fit(self, tr_loader, va_loader, num_epochs: int):
         for epoch in range(num_epochs):
+            if hasattr(tr_loader, "reshuffle"):
+                tr_loader.reshuffle()                                    # detector/train.py:255
             self._run_epoch(tr_loader, True, epoch)
             val_loss = self._run_epoch(va_loader, False, epoch)
             self.save_checkpoint(epoch, val_loss)
