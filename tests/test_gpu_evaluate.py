@@ -113,3 +113,33 @@ def test_model_discovery_and_checkpoint_roundtrip(tmp_path):
     from ws_unet_amd.model import get_model
     with pytest.raises(NotImplementedError):
         get_model("cnn_1", in_channels=1)
+
+
+def test_sharded_dataset_evaluate_and_cli(tmp_path):
+    """predict_unet_sharded == the per-image iterators' table (single rank), and the `python -m ws_unet_amd.evaluate` driver writes it."""
+    data = tmp_path / "data"
+    data.mkdir()
+    _make_dataset(data)
+    model = gpu_model(2, "he", "f32", drop_rate=0.)
+    ref_c = evaluate.predict_unet_cover(data, model=model, progress_on=False)
+    got_c = evaluate.predict_unet_sharded(data, model, batch_size=2)
+    assert got_c["name"].tolist() == ref_c["name"].tolist() and list(got_c.columns) == list(ref_c.columns)
+    np.testing.assert_allclose(got_c["beta_hat"].to_numpy(float), ref_c["beta_hat"].to_numpy(float), atol=2e-5)
+    np.testing.assert_allclose(got_c["l1"].to_numpy(float), ref_c["l1"].to_numpy(float), atol=2e-5)
+    ref_s = evaluate.predict_unet_stego(data, model=model, stego_method="LSBR")
+    got_s = evaluate.predict_unet_sharded(data, model, stego_method="LSBR")
+    assert got_s["name"].tolist() == ref_s["name"].tolist() and set(ref_s.columns) <= set(got_s.columns)
+    np.testing.assert_allclose(got_s["beta_hat"].to_numpy(float), ref_s["beta_hat"].to_numpy(float), atol=2e-5)
+    # driver: a model directory with one run, covers + LSBR rows -> CSV
+    sd = formula.formula_state_dict(2, "he")
+    run = tmp_path / "models" / "LSBR" / "run-x"
+    (run / "model").mkdir(parents=True)
+    (run / "config.json").write_text(json.dumps({"stego_method": "LSBR", "alpha": "0.400", "loss": "l1ws", "network": "unet_2",
+                                                 "drop_rate": 0.0, "debug": False}))
+    torch.save({"epoch": 1, "state_dict": {k: torch.from_numpy(v) for k, v in sd.items()}}, run / "model" / "best_model.pt.tar")
+    out = tmp_path / "res" / "ws.csv"
+    evaluate.main(["--data", str(data), "--model-dir", str(tmp_path / "models"), "--stego-method", "LSBR", "--eval-methods", "LSBR",
+                   "--out", str(out), "--mode", "f32"])
+    table = pd.read_csv(out)
+    assert len(table) == 7 and table["name"].tolist()[:5] == ref_c["name"].tolist()
+    np.testing.assert_allclose(table["beta_hat"].to_numpy(float)[:5], ref_c["beta_hat"].to_numpy(float), atol=2e-5)

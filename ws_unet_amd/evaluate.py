@@ -232,3 +232,83 @@ def get_pretrained(
     model.load_state_dict(checkpoint["state_dict"])
     logging.info(f"model {model_name} loaded")
     return model
+
+
+# ---- whole-dataset evaluate, batch-sharded over the ranks of a torch.distributed job -----------------------------
+
+@fabrika.precovers(iterator=None, convert_to=None, ignore_missing=False)
+def _cover_rows(df, **kw):
+    return df
+
+
+@fabrika.stego_spatial(iterator=None, convert_to=None, ignore_missing=False)
+def _stego_rows(df, **kw):
+    return df
+
+
+def predict_unet_sharded(dataset, model: torch.nn.Module, *, stego_method: str = None, alpha: float = None, batch_size: int = 32,
+                         **kw_iter) -> pd.DataFrame:
+    """`predict_unet_cover` (stego_method None) / `predict_unet_stego` over a data set with the rows split contiguously over the
+    ranks: every rank decodes and predicts its shard in batches, `(beta_hat, l1)` rows are all-gathered and every
+    rank returns the full table in fabrika order with the per-image functions' columns.  Single process: same result, no
+    collective."""
+    from . import parallel
+    dataset = pathlib.Path(dataset)
+    if stego_method is None:
+        df = _cover_rows(dataset, **kw_iter)
+    else:
+        kw = {"stego_method": stego_method, **({"alpha": alpha} if alpha is not None else {})}
+        df = _stego_rows(dataset, **kw, **kw_iter)
+    df = df.reset_index(drop=True)
+    files = df["name"].tolist()                              # iterator=None hands over absolute paths (fabrika.py:104-110)
+
+    def predict_chunk(chunk):
+        planes = load_planes_u8(chunk)
+        if planes is None or tuple(planes.shape[1:]) != (512, 512):
+            res = [predict_unet(f, model, imread=imread4_f32) for f in chunk]
+            return torch.tensor([[r["beta_hat"], r["l1"]] for r in res], dtype=torch.float32)
+        beta, l1 = predict_u8_batch(planes.to(_model_device(model), non_blocking=True), model)
+        out = torch.stack([beta, l1], dim=1)
+        torch.cuda.current_stream().synchronize()            # the pinned staging buffer is reused by the next chunk
+        return out
+
+    table = parallel.evaluate_sharded(files, predict_chunk, batch_size).cpu().numpy()
+    df["name"] = [str(pathlib.Path(f).relative_to(dataset)) for f in files]
+    df["beta_hat"], df["l1"] = table[:, 0], table[:, 1]
+    if stego_method is not None:
+        df = df.assign(stego_method=stego_method, **({"alpha": alpha} if alpha is not None else {}))
+    return df
+
+
+def main(argv=None) -> None:
+    """The reference's `python unet/evaluate.py` (evaluate.py:190-233): covers + LSBR + HILLR stego rows of one trained model
+    -> results/estimation/ws_<stego_method>.csv; run under torch.distributed.run to shard the rows over GPUs."""
+    import argparse
+    from . import parallel
+    ap = argparse.ArgumentParser(description=main.__doc__)
+    ap.add_argument("--data", default="../data")
+    ap.add_argument("--model-dir", default="../models/unet")
+    ap.add_argument("--stego-method", default="HILLR", help="which trained model: dropout | LSBR | HILLR")
+    ap.add_argument("--eval-methods", nargs="*", default=["LSBR", "HILLR"])
+    ap.add_argument("--out", default=None)
+    ap.add_argument("--batch-size", type=int, default=32)
+    ap.add_argument("--mode", default=None)
+    a = ap.parse_args(argv)
+    logging.basicConfig(level=logging.INFO)
+    rank, world = parallel.init_from_env()
+    model_dir = pathlib.Path(a.model_dir)
+    model_name = get_model_name(model_dir=model_dir, stego_method=a.stego_method)
+    model = get_pretrained(model_path=model_dir / a.stego_method, channels=(3,), model_name=model_name, mode=a.mode)
+    frames = [predict_unet_sharded(a.data, model, batch_size=a.batch_size)]
+    for sm in a.eval_methods:
+        frames.append(predict_unet_sharded(a.data, model, stego_method=sm, batch_size=a.batch_size))
+    df = pd.concat(frames)
+    if rank == 0:
+        out = pathlib.Path(a.out or f"../results/estimation/ws_{a.stego_method}.csv")
+        out.parent.mkdir(parents=True, exist_ok=True)
+        df.to_csv(out, index=False)
+        logging.info(f"output saved to {out}")
+
+
+if __name__ == "__main__":
+    main()
