@@ -206,3 +206,30 @@ def test_run_with_unet_checkpoint(tmp_path):
                            imread=imread4_u8, process_image=filters.get_processor_2d((3,)))
     row = res[res["name"] == "images/10.png"]["beta_hat"].iloc[0]
     assert _close(host["beta_hat"], row, 1e-5, 1e-6)
+
+
+def test_estimate_driver_writes_the_result_table(tmp_path):
+    """`python -m ws_unet_amd.ws.estimate` (reference estimate.py:208-275): filters + both UNets over covers and stego -> one CSV."""
+    import pandas as pd
+    (tmp_path / "data").mkdir()
+    _make_dataset(tmp_path / "data", size=512, n=2)
+    sd = formula.formula_state_dict(2, "he")
+    for method, loss, dr in (("LSBR", "l1ws", 0.0), ("dropout", "l1", 0.1)):
+        rundir = tmp_path / "models" / method / f"run-{method}"
+        (rundir / "model").mkdir(parents=True)
+        (rundir / "config.json").write_text(json.dumps({"stego_method": method, "alpha": "0.400" if method == "LSBR" else None, "loss": loss,
+                                                        "network": "unet_2", "drop_rate": dr, "debug": False}))
+        torch.save({"epoch": 1, "state_dict": {k: torch.from_numpy(v) for k, v in sd.items()}}, rundir / "model" / "best_model.pt.tar")
+    out = tmp_path / "res" / "ws.csv"
+    estimate.main(["--data", str(tmp_path / "data"), "--model-dir", str(tmp_path / "models"), "--alphas", "0.4", "--out", str(out)])
+    t = pd.read_csv(out)
+    assert set(t["model_name"]) == {"AVG", "KB", "UNet_l1", "UNet_l1ws_LSBR"}
+    assert set(t["stego_method"]) == {"Cover", "LSBR"}
+    assert len(t) == 4 * (2 + 2)                                  # 4 predictors x (2 covers + 2 stego images)
+    for col in ("name", "beta_hat", "channels", "weighted", "correct_bias"):
+        assert col in t.columns
+    assert (t["beta_hat"] >= 0).all() and t["weighted"].eq(0).all()
+    # same checkpoint in both model directories -> both UNet variants give the same estimates
+    a = t[t.model_name == "UNet_l1"].sort_values("name")["beta_hat"].to_numpy()
+    b = t[t.model_name == "UNet_l1ws_LSBR"].sort_values("name")["beta_hat"].to_numpy()
+    np.testing.assert_allclose(a, b, rtol=1e-6)

@@ -97,8 +97,16 @@ def predict_unet(
     imread: typing.Callable = imread4_f32,
     **kw,
 ):
-    """Per-image WS estimate and MAE exactly as the reference computes them on the host (evaluate.py:109-139)."""
+    """Per-image WS estimate and MAE (evaluate.py:109-139).  With this package's UNet and a 512x512 image the pixels go up as
+    uint8 and only the two statistics come back (wsu_u8_to_unit_f32 -> forward -> wsu_ws_residual_stats, same float32 arithmetic);
+    for any other predictor callable the reference's host formulas below are evaluated on its returned array."""
     x = imread(fname)[..., 3:]
+    if isinstance(model, torch.nn.Module) and hasattr(model, "forward_features") and x.shape[:2] == (512, 512):
+        xi = np.ascontiguousarray(x[..., 0])
+        if xi.dtype == np.uint8 or np.array_equal(xi, np.rint(xi)):
+            x_u8 = torch.from_numpy(xi.astype(np.uint8))[None].to(_model_device(model))
+            beta, l1 = predict_u8_batch(x_u8, model)
+            return {**kw, "beta_hat": np.float32(beta[0].item()), "l1": np.float32(l1[0].item())}
     x_hat = infere_single(x, model=model, device=device)
     x = x[1:-1, 1:-1]
     x_bar = (x.astype("uint8") ^ 1).astype("float32")          # integer LSB flip

@@ -230,3 +230,51 @@ def run(
     res["channels"] = "".join(map(str, channels))
     res = res[~res.beta_hat.isna()]
     return res
+
+
+def main(argv=None) -> None:
+    """The reference's `python ws/estimate.py` (estimate.py:208-275): WS estimates of the covers and of the stego images at
+    alpha 0.4 / 0.2 / 0.1 with the AVG and KB filters and with the trained UNets ('l1' = dropout run, 'l1ws' = the run trained on
+    --train-method), one table -> results/estimation/ws_<train-method>.csv."""
+    import argparse
+    import pandas as pd
+    from .. import get_model_name
+    ap = argparse.ArgumentParser(description=main.__doc__)
+    ap.add_argument("--data", default="../data/")
+    ap.add_argument("--model-dir", default="../models/unet")
+    ap.add_argument("--train-method", default="LSBR", help="stego method the l1ws UNet was trained on")
+    ap.add_argument("--stego-methods", nargs="*", default=["LSBR"])
+    ap.add_argument("--alphas", nargs="*", type=float, default=[.4, .2, .1])
+    ap.add_argument("--filters", nargs="*", default=["AVG", "KB"])
+    ap.add_argument("--losses", nargs="*", default=["l1", "l1ws"])
+    ap.add_argument("--weighted", type=int, default=0)
+    ap.add_argument("--correct-bias", action="store_true")
+    ap.add_argument("--per-image", action="store_true", help="use the per-image iterators instead of the batched ones")
+    ap.add_argument("--out", default=None)
+    a = ap.parse_args(argv)
+    model_dir = pathlib.Path(a.model_dir)
+    settings = [(None, .0)] + [(sm, al) for sm in a.stego_methods for al in a.alphas]
+    common = dict(demosaic=None, channels=(3,), correct_bias=a.correct_bias, weighted=a.weighted, batched=not a.per_image)
+    res = []
+    for stego_method, alpha in settings:
+        for model_name in a.filters:
+            res.append(run(input_dir=pathlib.Path(a.data), stego_method=stego_method, alpha=alpha, model_path=None,
+                           model_name=model_name, **common))
+    for loss in a.losses:
+        train_method = a.train_method if loss == "l1ws" else "dropout"
+        name = get_model_name(stego_method=train_method, model_dir=model_dir)
+        for stego_method, alpha in settings:
+            r = run(input_dir=pathlib.Path(a.data), stego_method=stego_method, alpha=alpha, model_path=model_dir / train_method,
+                    model_name=name, **common)
+            r["model_name"] = f"UNet_{loss}" + (f"_{train_method}" if loss == "l1ws" else "")
+            res.append(r)
+    res = pd.concat(res).reset_index(drop=True)
+    res["stego_method"] = res["stego_method"].fillna("Cover") if "stego_method" in res else "Cover"
+    out = pathlib.Path(a.out or f"../results/estimation/ws_{a.train_method}.csv")
+    out.parent.mkdir(parents=True, exist_ok=True)
+    res.to_csv(out, index=False)
+    print(f"output saved to {out}")
+
+
+if __name__ == "__main__":
+    main()
