@@ -256,3 +256,10 @@ def test_pair_loader_batches_and_rank_shards(tmp_path):
         PairLoader(tmp_path, None, "LSBR", 0.4, batch_size=3)
     with pytest.raises(Exception):
         PairLoader(tmp_path, None, "HILLR", 0.4, batch_size=2)
+
+
+def test_gpu_predictor_refuses_pickling_clearly():
+    import pickle
+    from ws_unet_amd.ws.estimate import UNetEstimator
+    with pytest.raises(TypeError, match="cannot be pickled"):
+        pickle.dumps(UNetEstimator(model=object()))

@@ -10,7 +10,7 @@
 // registers (v_mfma 32x32 C/D map: col = lane&31 -> pixel, row = (r&3)+8(r>>2)+4(lane>>5) -> channel),
 // so the epilogue packs 16-byte NHWC pieces without any cross-lane traffic.
 //
-// LDS (one workgroup = 4 waves, 2 workgroups per CU):
+// LDS (one workgroup = 8 waves for bf16x3 / bf16, 4 waves for f32; 2 workgroups per CU):
 //   input tile   [4 granule planes][10 x 34 pixels][16 B]   halo resolved (reflect / zero) while staging
 //   weight tile  [9 taps][4 granule planes][64 co][16 B]    straight copy of the packed weights
 //   both granule-planar, so every fragment read is a contiguous 512-byte ds_read_b128 (conflict free).

@@ -42,6 +42,11 @@ class UNetEstimator:
         from ..evaluate import infere_single
         return infere_single(x, model=self.model)
 
+    def __reduce__(self):
+        # the reference ships its CPU predictor into joblib / loky workers (ws/estimate.py:139); a GPU model must not travel
+        raise TypeError("UNetEstimator holds GPU state and cannot be pickled into worker processes: "
+                        "use the fabrika iterators 'python' or 'batched' (ws.estimate.attack_cover / attack_cover_batched)")
+
 
 def _as_u8_plane(x: np.ndarray) -> np.ndarray:
     """First channel of the processed image as uint8; the LSB flip is only defined for integer pixel values."""
