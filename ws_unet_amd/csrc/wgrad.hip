@@ -203,51 +203,126 @@ __global__ __launch_bounds__(NT, 2) void wgrad_x3_kernel(const WgArgs a) {
 
     const int t0 = split * a.tiles_per_split;
     const int t1 = min(t0 + a.tiles_per_split, a.ntiles);
-    for (int tile = t0; tile < t1; ++tile) {
+    // KIND 0 walks its tiles DOWN the image columns (ty fastest): vertically adjacent tiles share VH - TH = 2 input rows, which
+    // stay in LDS (rolling row slots, `rot`), and the TH new rows + the next U tile are fetched into registers while the current
+    // tile is multiplied.  Only the first tile of a split / of a column stages everything directly.
+    constexpr bool ROLL = KIND == 0;
+    constexpr int U_IT = (G::U_PIX * 8 + NT - 1) / NT;                 // U items of 8 channels per thread (exact: 2)
+    constexpr int VN_ROW0 = ROLL ? VH - TH : 0;                        // first window row that is new per step (KIND 1: all rows)
+    constexpr int VN_PIX = (VH - VN_ROW0) * VW;
+    constexpr int VN_IT = (VN_PIX * 8 + NT - 1) / NT;                  // 3 (KIND 0), 4 (KIND 1)
+    static_assert((G::U_PIX * 8) % NT == 0, "U tile must divide evenly over the threads");
+    f32x4 pu[U_IT][2], pv[VN_IT][2];
+    bool have_pref = false;
+    int rot = 0;
+
+    auto decode = [&](int tile, int& n, int& y0, int& x0) __attribute__((always_inline)) {
         int tt = tile;
-        const int tx = tt % a.tiles_x; tt /= a.tiles_x;
-        const int ty = tt % a.tiles_y;
-        const int n = tt / a.tiles_y;
-        const int y0 = ty * TH, x0 = tx * TW;
+        if (ROLL) { const int ty = tt % a.tiles_y; tt /= a.tiles_y; const int tx = tt % a.tiles_x; n = tt / a.tiles_x; y0 = ty * TH; x0 = tx * TW; }
+        else      { const int tx = tt % a.tiles_x; tt /= a.tiles_x; const int ty = tt % a.tiles_y; n = tt / a.tiles_y; y0 = ty * TH; x0 = tx * TW; }
+    };
+    auto u_src = [&](int n, int y0, int x0, int i, bool& ok) __attribute__((always_inline)) {
+        const int p = i >> 3, cg = i & 7, r = p / TW, c = p % TW;
+        ok = y0 + r < a.hu && x0 + c < a.wu;
+        return reinterpret_cast<const f32x4*>(a.u + ((size_t)(n * a.hu + y0 + r) * a.wu + x0 + c) * a.cu + mb * 64 + cg * 8);
+    };
+    auto v_src = [&](int n, int y0, int x0, int p, int cg) __attribute__((always_inline)) {
+        const int r = p / VW, c = p % VW;
+        int yy, xx;
+        if (KIND == 0) { yy = wsu_reflect(y0 - 1 + r, hv); xx = wsu_reflect(x0 - 1 + c, wv); }
+        else           { yy = min(2 * y0 + r, hv - 1);     xx = min(2 * x0 + c, wv - 1); }
+        return reinterpret_cast<const f32x4*>(vsrc + ((size_t)(n * hv + yy) * wv + xx) * cv + vch0 + cg * 8);
+    };
+
+    for (int tile = t0; tile < t1; ++tile) {
+        int n, y0, x0;
+        decode(tile, n, y0, x0);
         __syncthreads();
-        // ---- stage: 8 fp32 channels per item -> bf16 hi row piece + bf16 lo row piece (16 B each)
-        for (int i = tid; i < G::U_PIX * 8; i += NT) {
-            const int p = i >> 3, cg = i & 7;
-            const int r = p / TW, c = p % TW;
-            u32x4 hi = mk_u4(0, 0, 0, 0), lo = hi;
-            if (y0 + r < a.hu && x0 + c < a.wu) {
-                const f32x4* src = reinterpret_cast<const f32x4*>(a.u + ((size_t)(n * a.hu + y0 + r) * a.wu + x0 + c) * a.cu + mb * 64 + cg * 8);
-                const f32x4 s0 = src[0], s1 = src[1];
-                if (bias_on) { bs0 = bs0 + s0; bs1 = bs1 + s1; }
-                wsu_split8(s0, s1, hi, lo);
+        if (!have_pref) {
+            // ---- direct staging: 8 fp32 channels per item -> bf16 hi row piece + bf16 lo row piece (16 B each)
+            rot = 0;
+            for (int i = tid; i < G::U_PIX * 8; i += NT) {
+                const int p = i >> 3, cg = i & 7;
+                bool ok;
+                const f32x4* src = u_src(n, y0, x0, i, ok);
+                u32x4 hi = mk_u4(0, 0, 0, 0), lo = hi;
+                if (ok) {
+                    const f32x4 s0 = src[0], s1 = src[1];
+                    if (bias_on) { bs0 = bs0 + s0; bs1 = bs1 + s1; }
+                    wsu_split8(s0, s1, hi, lo);
+                }
+                *reinterpret_cast<u32x4*>(u_hi + p * X3_ROW + cg * 16) = hi;
+                *reinterpret_cast<u32x4*>(u_lo + p * X3_ROW + cg * 16) = lo;
             }
-            *reinterpret_cast<u32x4*>(u_hi + p * X3_ROW + cg * 16) = hi;
-            *reinterpret_cast<u32x4*>(u_lo + p * X3_ROW + cg * 16) = lo;
-        }
-        for (int i = tid; i < G::V_PIX * 8; i += NT) {
-            const int p = i >> 3, cg = i & 7;
-            const int r = p / VW, c = p % VW;
-            int yy, xx;
-            if (KIND == 0) { yy = wsu_reflect(y0 - 1 + r, hv); xx = wsu_reflect(x0 - 1 + c, wv); }
-            else           { yy = min(2 * y0 + r, hv - 1);     xx = min(2 * x0 + c, wv - 1); }
-            const f32x4* src = reinterpret_cast<const f32x4*>(vsrc + ((size_t)(n * hv + yy) * wv + xx) * cv + vch0 + cg * 8);
-            u32x4 hi, lo;
-            wsu_split8(src[0], src[1], hi, lo);
-            *reinterpret_cast<u32x4*>(v_hi + p * X3_ROW + cg * 16) = hi;
-            *reinterpret_cast<u32x4*>(v_lo + p * X3_ROW + cg * 16) = lo;
+            for (int i = tid; i < G::V_PIX * 8; i += NT) {
+                const int p = i >> 3, cg = i & 7;
+                const f32x4* src = v_src(n, y0, x0, p, cg);
+                u32x4 hi, lo;
+                wsu_split8(src[0], src[1], hi, lo);
+                *reinterpret_cast<u32x4*>(v_hi + p * X3_ROW + cg * 16) = hi;
+                *reinterpret_cast<u32x4*>(v_lo + p * X3_ROW + cg * 16) = lo;
+            }
+        } else {
+            // ---- commit the prefetched registers: the whole U tile and the TH new V rows (window rows VH-TH .. VH-1)
+            if (ROLL) rot = (rot + TH) & (VH - 1);
+#pragma unroll
+            for (int k = 0; k < U_IT; ++k) {
+                const int i = tid + k * NT, p = i >> 3, cg = i & 7;
+                u32x4 hi, lo;
+                if (bias_on) { bs0 = bs0 + pu[k][0]; bs1 = bs1 + pu[k][1]; }
+                wsu_split8(pu[k][0], pu[k][1], hi, lo);
+                *reinterpret_cast<u32x4*>(u_hi + p * X3_ROW + cg * 16) = hi;
+                *reinterpret_cast<u32x4*>(u_lo + p * X3_ROW + cg * 16) = lo;
+            }
+#pragma unroll
+            for (int k = 0; k < VN_IT; ++k) {
+                const int i = tid + k * NT;
+                if (i < VN_PIX * 8) {
+                    const int pn = i >> 3, cg = i & 7, rn = pn / VW, c = pn % VW;
+                    const int slot = (VN_ROW0 + rn + rot) & (VH - 1);
+                    u32x4 hi, lo;
+                    wsu_split8(pv[k][0], pv[k][1], hi, lo);
+                    *reinterpret_cast<u32x4*>(v_hi + (slot * VW + c) * X3_ROW + cg * 16) = hi;
+                    *reinterpret_cast<u32x4*>(v_lo + (slot * VW + c) * X3_ROW + cg * 16) = lo;
+                }
+            }
         }
         __syncthreads();
-        // ---- MFMA: k-steps of 16 pixels along a tile row
+        {
+            // ---- prefetch for the next tile (KIND 0: only if it continues this column: same image, same tx, ty + 1)
+            have_pref = tile + 1 < t1 && (!ROLL || (tile + 1) % a.tiles_y != 0);
+            if (have_pref) {
+                int n2, y2, x2;
+                decode(tile + 1, n2, y2, x2);
 #pragma unroll
+                for (int k = 0; k < U_IT; ++k) {
+                    bool ok;
+                    const f32x4* src = u_src(n2, y2, x2, tid + k * NT, ok);
+                    pu[k][0] = mk_f4(0.f, 0.f, 0.f, 0.f); pu[k][1] = pu[k][0];
+                    if (ok) { pu[k][0] = src[0]; pu[k][1] = src[1]; }
+                }
+#pragma unroll
+                for (int k = 0; k < VN_IT; ++k) {
+                    const int i = tid + k * NT;
+                    if (i < VN_PIX * 8) {
+                        const f32x4* src = v_src(n2, y2, x2, VN_ROW0 * VW + (i >> 3), i & 7);
+                        pv[k][0] = src[0]; pv[k][1] = src[1];
+                    }
+                }
+            }
+        }
+        // ---- MFMA: k-steps of 16 pixels along a tile row (only the tap loop is unrolled: 144 accumulator + 40 prefetch registers
+        //      leave no room for the fragment working set of several k-steps at once)
+#pragma unroll 1
         for (int r = 0; r < TH; ++r) {
-#pragma unroll
+#pragma unroll 1
             for (int c0 = 0; c0 < TW; c0 += 16) {
                 const int up = r * TW + c0 + 8 * hh;                                    // first U pixel of this lane half
                 const u32x4 ahi = x3_frag(u_hi, up, 1, colA), alo = x3_frag(u_lo, up, 1, colA);
 #pragma unroll
                 for (int t = 0; t < NTAPS; ++t) {
                     int vp, vstep;
-                    if (KIND == 0) { vp = (r + t / 3) * VW + c0 + 8 * hh + t % 3; vstep = 1; }
+                    if (KIND == 0) { vp = ((r + t / 3 + rot) & (VH - 1)) * VW + c0 + 8 * hh + t % 3; vstep = 1; }
                     else           { vp = (2 * r + (t >> 1)) * VW + 2 * (c0 + 8 * hh) + (t & 1); vstep = 2; }
                     const u32x4 bhi = x3_frag(v_hi, vp, vstep, colB), blo = x3_frag(v_lo, vp, vstep, colB);
                     wsu_mfma_step<WSU_MODE_BF16X3>(alo, bhi, acc[t]);
