@@ -81,6 +81,13 @@ int wsu_conv3x3_head_fwd(const void* x1, const void* x2, const void* w_packed, c
                          const float* head_w, const float* head_b, float* out, float* logit,
                          int n, int h, int w, int c1, int c2, int cout, int head_cout, int mode, void* stream);
 
+/* ---- K1f: first layer fused into the conv behind it (e11 -> e12 [-> pool], unet.py:141-144) for single-plane inputs: the 64
+ *      channels of e11 are computed from the image while e12 stages its input tile and never reach HBM.  Bitwise the same result
+ *      as wsu_conv3x3_first_fwd followed by wsu_conv3x3_fwd.  img: (N,1,H,W) fp32; w1: (64,1,3,3) OIHW; b1: (64) or NULL;
+ *      w_packed / bias: the second conv (cin = 64) as for wsu_conv3x3_fwd; y: (N,H,W,cout); y_pool / pool_idx optional. */
+int wsu_conv3x3_fused_first_fwd(const float* img, const float* w1, const float* b1, const void* w_packed, const float* bias,
+                                void* y, void* y_pool, uint8_t* pool_idx, int n, int h, int w, int cout, int mode, int relu, void* stream);
+
 /* ---- K1w: the same forward conv (mode bf16x3 only: fp32 NHWC activations) through a Winograd F(2,3) kernel along x:
  *      1.5x fewer MFMAs, results equal to the direct kernel up to fp32 re-association.  Weights from wsu_conv3x3_wino_pack
  *      ([cob][chunk][12 taps][4 planes][64 co][16 B], row taps pre-multiplied by G).  Same fusions: x2 = second concat source,

@@ -283,3 +283,40 @@ def test_fused_head_matches_unfused(mode):
         model.fuse_head = False
         y_u = model(x.to(DEV))
     np.testing.assert_allclose(y_f.cpu().numpy(), y_u.cpu().numpy(), atol=1e-6, rtol=0)
+
+
+@pytest.mark.parametrize("mode", MODE_NAMES)
+@pytest.mark.parametrize("shape", [(2, 16, 32), (1, 24, 40), (1, 2, 2), (2, 37, 70), (1, 8, 96)])
+def test_fused_first_layer_is_bitwise_the_two_kernel_path(mode, shape):
+    """wsu_conv3x3_fused_first_fwd == wsu_conv3x3_first_fwd -> wsu_conv3x3_fwd, bit for bit (same e11 tap order, same staging),
+    including tiles that hang over the image and the double reflection at the borders; with and without the fused pool."""
+    n, h, w = shape
+    m = ops.mode_id(mode)
+    x = rand_act((n, 1, h, w), f"ff/x/{shape}", relu=False).abs().to(DEV)
+    w1 = torch.from_numpy(formula.formula_tensor(f"ff/w1/{shape}", (64, 1, 3, 3), 0.5)).to(DEV)
+    b1 = torch.from_numpy(formula.formula_tensor(f"ff/b1/{shape}", (64,), 0.1)).to(DEV)
+    w2 = torch.from_numpy(formula.formula_tensor(f"ff/w2/{shape}", (64, 64, 3, 3), 0.06)).to(DEV)
+    b2 = torch.from_numpy(formula.formula_tensor(f"ff/b2/{shape}", (64,), 0.1)).to(DEV)
+    wp = ops.pack_conv3x3(w2, m)
+    e11 = ops.conv3x3_first(x, w1, b1, m, relu=True)
+    ref = ops.conv3x3(e11, None, wp, b2, 64, m)
+    got = ops.conv3x3_fused_first(x, w1, b1, wp, b2, 64, m)
+    assert torch.equal(got, ref)
+    if h % 2 == 0 and w % 2 == 0:
+        ry, rp, ri = ops.conv3x3(e11, None, wp, b2, 64, m, pool=True, pool_idx=True)
+        gy, gp, gi = ops.conv3x3_fused_first(x, w1, b1, wp, b2, 64, m, pool=True, pool_idx=True)
+        assert torch.equal(gy, ry) and torch.equal(gp, rp) and torch.equal(gi, ri)
+    # and against the oracle
+    refo = F.relu(unet_ref.conv3x3_reflect(F.relu(unet_ref.conv3x3_reflect(x.cpu(), w1.cpu(), b1.cpu())), w2.cpu(), b2.cpu()))
+    _assert_close(from_nhwc(got), refo, mode, f"fused first {shape}")
+
+
+def test_model_with_and_without_first_layer_fusion_agree():
+    x = images01(2, 64, 64, seed=9)[1].to(DEV)
+    for ns in (0, 2):
+        m = gpu_model(ns, "he", "bf16x3")
+        assert m.fuse_first
+        y1 = m(x.clone())
+        m.fuse_first = False
+        y0 = m(x.clone())
+        assert torch.equal(y0, y1)

@@ -41,6 +41,7 @@ SIGNATURES = {
     "wsu_convt2x2_pack": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "wsu_conv3x3_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P] + [c_int] * 9 + [_P]),
     "wsu_conv3x3_head_fwd": (c_int, [_P] * 9 + [c_int] * 8 + [_P]),
+    "wsu_conv3x3_fused_first_fwd": (c_int, [_P] * 8 + [c_int] * 6 + [_P]),
     "wsu_conv3x3_wino_packed_bytes": (c_size_t, [c_int, c_int]),
     "wsu_conv3x3_wino_pack": (c_int, [_P, _P, c_int, c_int, _P]),
     "wsu_conv3x3_wino_fwd": (c_int, [_P] * 11 + [c_int] * 8 + [_P]),

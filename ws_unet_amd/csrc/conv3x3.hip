@@ -70,7 +70,9 @@ struct ConvArgs {
     int relu, pad_zero;
     int ablate;        // timing-only experiment mask (WSU_CONV_ABLATE), 0 in production
     // fused 1x1 head + sigmoid (outconv, unet.py:189) on this layer's 64 output channels; y may then be null
-    const float* head_w; const float* head_b; float* head_out; float* head_logit; int head_cout;
+    const float* head_w; const float* head_b; float* head_out; float* head_logit; int head_cout;    // fused first layer (e11, unet.py:141): the 64 input channels of THIS conv are computed while staging from a 1-plane image
+    // (img: (N,1,H,W) fp32, w1: (64,1,3,3), b1: (64) or null); x1 is then null
+    const float* img; const float* w1; const float* b1;
 };
 
 template <int MODE> struct Epi {
@@ -82,7 +84,7 @@ template <int MODE> struct Epi {
 
 
 // Global -> registers for chunk c (input tile items + this workgroup's packed-weight slice).
-template <int MODE, int NW>
+template <int MODE, int NW, bool F1 = false>
 __device__ __forceinline__ void stage_load(const ConvArgs& a, int cb, int c, int tid, const int (&pixidx)[Shape<NW>::IN_VEC],
                                            u32x4 (&st_in)[Shape<NW>::ST_IN], u32x4 (&st_w)[Shape<NW>::W_VEC]) {
     constexpr int NT = Shape<NW>::NT, W_VEC = Shape<NW>::W_VEC;
@@ -92,6 +94,7 @@ __device__ __forceinline__ void stage_load(const ConvArgs& a, int cb, int c, int
     const char* src; int csrc, ch0;
     if (c < a.nch1) { src = a.x1; csrc = a.c1; ch0 = c * CK; }
     else            { src = a.x2; csrc = a.c2; ch0 = (c - a.nch1) * CK; }
+    if constexpr (!F1)                                          // fused first layer: the activations are computed in the commit
 #pragma unroll
     for (int j = 0; j < NLOOP; ++j) {
         const int p = pixidx[j];
@@ -114,6 +117,68 @@ __device__ __forceinline__ void stage_load(const ConvArgs& a, int cb, int c, int
 #pragma unroll
     for (int k = 0; k < W_VEC; ++k)
         if (W_ITEMS % NT == 0 || tid + k * NT < W_ITEMS) st_w[k] = wsrc[tid + k * NT];
+}
+
+// ---- fused first layer: LDS extras behind the main region -------------------------------------------------------
+//   P  [input-tile pixel][12]  the 3x3 image neighbourhood (reflect) of the e11 output pixel that this tile position maps to
+//   W1 [64 channels][12]       e11 taps (9 used), B1 [64]
+constexpr int F1_W1_OFF(int npix) { return npix * 48; }
+constexpr int F1_B1_OFF(int npix) { return npix * 48 + 64 * 48; }
+constexpr int F1_BYTES(int npix) { return npix * 48 + 64 * 48 + 256; }
+
+// relu(b + sum_t x_t * w_t) for channels ch..ch+3, taps in the order of conv3x3_first_kernel (bitwise the same values)
+__device__ __forceinline__ f32x4 e11_quad(const float* P12, const float* W1, const float* B1, int ch) {
+    const f32x4 p0 = *reinterpret_cast<const f32x4*>(P12), p1 = *reinterpret_cast<const f32x4*>(P12 + 4), p2 = *reinterpret_cast<const f32x4*>(P12 + 8);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(B1 + ch);
+    f32x4 r;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float* wr = W1 + (ch + k) * 12;
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(wr), w1 = *reinterpret_cast<const f32x4*>(wr + 4), w2 = *reinterpret_cast<const f32x4*>(wr + 8);
+        float acc = b[k];
+        acc = fmaf(p0.x, w0.x, acc); acc = fmaf(p0.y, w0.y, acc); acc = fmaf(p0.z, w0.z, acc); acc = fmaf(p0.w, w0.w, acc);
+        acc = fmaf(p1.x, w1.x, acc); acc = fmaf(p1.y, w1.y, acc); acc = fmaf(p1.z, w1.z, acc); acc = fmaf(p1.w, w1.w, acc);
+        acc = fmaf(p2.x, w2.x, acc);
+        r[k] = fmaxf(acc, 0.f);
+    }
+    return r;
+}
+
+// Chunk c of the virtual 64-channel input, computed into the granule-planar tile (same LDS contents as staging e11's output)
+template <int MODE, int NW>
+__device__ __forceinline__ void stage_commit_first(char* smem, int tid, int c, const int (&pixidx)[Shape<NW>::IN_VEC], const int (&ldsoff)[Shape<NW>::IN_VEC],
+                                                   const u32x4 (&st_w)[Shape<NW>::W_VEC]) {
+    constexpr int NT = Shape<NW>::NT, W_VEC = Shape<NW>::W_VEC;
+    constexpr int PLANE_IN = Shape<NW>::PLANE_IN, LDS_IN = Shape<NW>::LDS_IN, NPIX_IN = Shape<NW>::NPIX_IN;
+    constexpr int NLOOP = (MODE == WSU_MODE_BF16X3) ? Shape<NW>::IN_VEC3 : Shape<NW>::IN_VEC;
+    const float* P = reinterpret_cast<const float*>(smem + Shape<NW>::LDS_MAIN);
+    const float* W1 = reinterpret_cast<const float*>(smem + Shape<NW>::LDS_MAIN + F1_W1_OFF(NPIX_IN));
+    const float* B1 = reinterpret_cast<const float*>(smem + Shape<NW>::LDS_MAIN + F1_B1_OFF(NPIX_IN));
+#pragma unroll
+    for (int j = 0; j < NLOOP; ++j) {
+        if (pixidx[j] != -2) {
+            const int i = tid + j * NT;
+            if constexpr (MODE == WSU_MODE_BF16X3) {
+                const int pix = i >> 1, ch0 = c * 16 + (i & 1) * 8;
+                u32x4 hi, lo;
+                wsu_split8(e11_quad(P + pix * 12, W1, B1, ch0), e11_quad(P + pix * 12, W1, B1, ch0 + 4), hi, lo);
+                *reinterpret_cast<u32x4*>(smem + ldsoff[j]) = hi;
+                *reinterpret_cast<u32x4*>(smem + ldsoff[j] + 2 * PLANE_IN) = lo;
+            } else if constexpr (MODE == WSU_MODE_F32) {
+                const int pix = i >> 2, ch0 = c * 16 + (i & 3) * 4;
+                *reinterpret_cast<f32x4*>(smem + ldsoff[j]) = e11_quad(P + pix * 12, W1, B1, ch0);
+            } else {
+                const int pix = i >> 2, ch0 = c * 32 + (i & 3) * 8;
+                const f32x4 q0 = e11_quad(P + pix * 12, W1, B1, ch0), q1 = e11_quad(P + pix * 12, W1, B1, ch0 + 4);
+                *reinterpret_cast<u32x4*>(smem + ldsoff[j]) = mk_u4(wsu_pack_bf16x2(q0.x, q0.y), wsu_pack_bf16x2(q0.z, q0.w),
+                                                                   wsu_pack_bf16x2(q1.x, q1.y), wsu_pack_bf16x2(q1.z, q1.w));
+            }
+        }
+    }
+    u32x4* wdst = reinterpret_cast<u32x4*>(smem + LDS_IN);
+#pragma unroll
+    for (int k = 0; k < W_VEC; ++k)
+        if (W_ITEMS % NT == 0 || tid + k * NT < W_ITEMS) wdst[tid + k * NT] = st_w[k];
 }
 
 // Registers -> LDS (granule-planar input tile, linear weight tile); BF16X3 splits fp32 into bf16 hi/lo here.
@@ -273,7 +338,7 @@ __device__ __forceinline__ void tile_epilogue(const ConvArgs& a, char* smem, int
     }
 }
 
-template <int MODE, int NW, bool S16 = false>
+template <int MODE, int NW, bool S16 = false, bool F1 = false>
 __global__ __launch_bounds__(NW * 64, NW >= 8 ? 4 : 2) void conv3x3_kernel(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int ESZ = Epi<MODE>::ESZ;
@@ -338,17 +403,37 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 4 : 2) void conv3x3_kernel(const
     const char* ldsA16 = smem + LDS_IN + (mbase + l15) * 16;         // + ((tap*4+plane)*64 + ct*16)*16
     const char* ldsB16 = smem + ((2 * rowpair) * IW + l15) * 16;     // + plane*PLANE_IN + ((q+dy)*IW + dx + half*16)*16
 
+    if constexpr (F1) {
+        // image neighbourhoods of the tile's 340 input positions: position -> e11 output pixel (reflect) -> its 3x3 window (reflect)
+        float* P = reinterpret_cast<float*>(smem + Shape<NW>::LDS_MAIN);
+        float* W1 = reinterpret_cast<float*>(smem + Shape<NW>::LDS_MAIN + F1_W1_OFF(NPIX_IN));
+        float* B1 = reinterpret_cast<float*>(smem + Shape<NW>::LDS_MAIN + F1_B1_OFF(NPIX_IN));
+        const float* img = a.img + (size_t)n * a.h * a.w;
+        for (int i = tid; i < NPIX_IN * 12; i += NT) {
+            const int pix = i / 12, t = i - pix * 12;
+            float v = 0.f;
+            if (t < 9) {
+                const int r = pix / IW, c = pix - r * IW;
+                const int yy = wsu_reflect(y0 - 1 + r, a.h), xx = wsu_reflect(x0 - 1 + c, a.w);
+                v = img[(size_t)wsu_reflect(yy + t / 3 - 1, a.h) * a.w + wsu_reflect(xx + t % 3 - 1, a.w)];
+            }
+            P[i] = v;
+        }
+        for (int i = tid; i < 64 * 12; i += NT) { const int ch = i / 12, t = i - ch * 12; W1[i] = t < 9 ? a.w1[ch * 9 + t] : 0.f; }
+        if (tid < 64) B1[tid] = a.b1 ? a.b1[tid] : 0.f;
+    }
     WSU_STAMP(0);
     if ((a.ablate & 512) && blockIdx.x < 2048 && threadIdx.x == 0) g_stamps[blockIdx.x * WSU_NSTAMP + 30] = __builtin_amdgcn_s_memrealtime();
-    stage_load<MODE, NW>(a, cb, 0, tid, pixidx, st_in, st_w);
+    stage_load<MODE, NW, F1>(a, cb, 0, tid, pixidx, st_in, st_w);
     WSU_STAMP(1);
     for (int c = 0; c < a.nch; ++c) {
         __syncthreads();
         if (c < 6) WSU_STAMP(2 + 4 * c);
-        if (!(a.ablate & 2) || c == 0) stage_commit<MODE, NW>(smem, tid, pixidx, ldsoff, st_in, st_w);
+        if constexpr (F1) stage_commit_first<MODE, NW>(smem, tid, c, pixidx, ldsoff, st_w);
+        else if (!(a.ablate & 2) || c == 0) stage_commit<MODE, NW>(smem, tid, pixidx, ldsoff, st_in, st_w);
         __syncthreads();
         if (c < 6) WSU_STAMP(3 + 4 * c);
-        if (c + 1 < a.nch && !(a.ablate & 1)) stage_load<MODE, NW>(a, cb, c + 1, tid, pixidx, st_in, st_w);
+        if (c + 1 < a.nch && !(a.ablate & 1)) stage_load<MODE, NW, F1>(a, cb, c + 1, tid, pixidx, st_in, st_w);
         if (c < 6) WSU_STAMP(4 + 4 * c);
         if (a.ablate & 4) continue;                                     // no LDS fragment reads, no MFMA
         if constexpr (S16 && MODE == WSU_MODE_BF16) {
@@ -1064,22 +1149,23 @@ int launch_conv_pp(const ConvArgs& a, hipStream_t s) {
     return wsu_check_launch("conv3x3_pp_kernel");
 }
 
-template <int MODE, int NW, bool S16 = false>
+template <int MODE, int NW, bool S16 = false, bool F1 = false>
 int launch_conv_nw(const ConvArgs& a_in, hipStream_t s) {
     constexpr int EPI_BYTES = Shape<NW>::TH * TW * Epi<MODE>::STRIDE;
-    const int lds = EPI_BYTES > Shape<NW>::LDS_MAIN ? EPI_BYTES : Shape<NW>::LDS_MAIN;
+    constexpr int MAIN_BYTES = Shape<NW>::LDS_MAIN + (F1 ? F1_BYTES(Shape<NW>::NPIX_IN) : 0);
+    const int lds = EPI_BYTES > MAIN_BYTES ? EPI_BYTES : MAIN_BYTES;
     ConvArgs a = a_in;
     a.tiles_y = (a.h + Shape<NW>::TH - 1) / Shape<NW>::TH;
     static bool attr_done = false;     // benign race: idempotent
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<MODE, NW, S16>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<MODE, NW, S16, F1>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) { wsu_set_error("hipFuncSetAttribute(conv3x3): %s", hipGetErrorString(e)); return WSU_ERR_HIP; }
         attr_done = true;
     }
     const long long nblk = (long long)a.n * a.tiles_x * a.tiles_y * a.ncb;
     if (nblk <= 0 || nblk > 0x7FFFFFFFLL) { wsu_set_error("conv3x3: grid of %lld workgroups out of range", nblk); return WSU_ERR_ARG; }
-    hipLaunchKernelGGL((conv3x3_kernel<MODE, NW, S16>), dim3((unsigned)nblk), dim3(NW * 64), lds, s, a);
+    hipLaunchKernelGGL((conv3x3_kernel<MODE, NW, S16, F1>), dim3((unsigned)nblk), dim3(NW * 64), lds, s, a);
     return wsu_check_launch("conv3x3_kernel");
 }
 
@@ -1088,6 +1174,11 @@ template <int MODE>
 int launch_conv(const ConvArgs& a, hipStream_t s) {
     // Default = the per-tile kernel (v1): measured faster (bench conv3x3 15.8 ms vs 17.9 ms per batch-32 forward in bf16x3).
     // WSU_CONV_IMPL=pp selects the ping-pong kernel (kept for the next tuning round; profiles/r01/conv3x3_ablation.md).
+    if (a.img) {                                                // fused first layer: the measured default shape of each mode
+        if constexpr (MODE == WSU_MODE_F32) return launch_conv_nw<MODE, 4, false, true>(a, s);
+        else if constexpr (MODE == WSU_MODE_BF16) return launch_conv_nw<MODE, 8, true, true>(a, s);
+        else return launch_conv_nw<MODE, 8, false, true>(a, s);
+    }
     static int impl = -1;
     if (impl < 0) { const char* e = getenv("WSU_CONV_IMPL"); impl = (e && e[0] == 'p' && e[1] == 'p') ? 0 : 1; }
     const bool mask_bf16 = MODE == WSU_MODE_BF16 && (a.relu_mask || a.relu_mask2);
@@ -1190,10 +1281,13 @@ static int conv3x3_launch_full(const void* x1, const void* x2, const void* w_pac
                           const void* relu_mask, const void* relu_mask2,
                           const float* head_w, const float* head_b, float* head_out, float* head_logit, int head_cout,
                           int n, int h, int w, int c1, int c2, int cout,
-                          int mode, int relu, int pad_zero, void* stream) {
+                          int mode, int relu, int pad_zero, void* stream,
+                          const float* first_img = nullptr, const float* first_w = nullptr, const float* first_b = nullptr) {
     WSU_REQUIRE(mode >= 0 && mode <= 2, "conv3x3: bad mode %d", mode);
     const int ck = wsu_chunk_channels(mode);
-    WSU_REQUIRE(x1 && w_packed && (y || head_w), "conv3x3: null pointer");
+    WSU_REQUIRE((x1 || first_img) && w_packed && (y || head_w), "conv3x3: null pointer");
+    WSU_REQUIRE(!first_img || (first_w && !x1 && !x2 && c1 == 64 && c2 == 0 && !pad_zero && !relu_mask),
+                "conv3x3: the fused first layer feeds exactly 64 channels into a reflect-padded forward conv");
     WSU_REQUIRE(!head_w || (head_out && cout == WSU_COB && head_cout >= 1 && head_cout <= 4 && !y2),
                 "conv3x3: fused head needs cout == %d, 1..4 head planes and an output pointer", WSU_COB);
     WSU_REQUIRE(n > 0 && h >= 2 && w >= 2, "conv3x3: bad shape n=%d h=%d w=%d (reflect pad 1 needs h,w >= 2)", n, h, w);
@@ -1213,6 +1307,7 @@ static int conv3x3_launch_full(const void* x1, const void* x2, const void* w_pac
     a.nch1 = c1 / ck; a.nch = (c1 + c2) / ck;
     a.relu = relu; a.pad_zero = pad_zero;
     a.head_w = head_w; a.head_b = head_b; a.head_out = head_out; a.head_logit = head_logit; a.head_cout = head_cout;
+    a.img = first_img; a.w1 = first_w; a.b1 = first_b;
     static int ablate = -1;
     if (ablate < 0) { const char* e = getenv("WSU_CONV_ABLATE"); ablate = e ? atoi(e) : 0; }
     a.ablate = ablate;
@@ -1220,6 +1315,15 @@ static int conv3x3_launch_full(const void* x1, const void* x2, const void* w_pac
     if (mode == WSU_MODE_F32) return launch_conv<WSU_MODE_F32>(a, s);
     if (mode == WSU_MODE_BF16X3) return launch_conv<WSU_MODE_BF16X3>(a, s);
     return launch_conv<WSU_MODE_BF16>(a, s);
+}
+
+// e11 + e12 (+pool) in one launch for single-plane inputs: the first layer's 64 channels (unet.py:141) are computed while staging and
+// never reach HBM.  img: (N,1,H,W) fp32, w1: (64,1,3,3), b1: (64) or NULL; the rest as wsu_conv3x3_fwd with cin = 64.
+int wsu_conv3x3_fused_first_fwd(const float* img, const float* w1, const float* b1, const void* w_packed, const float* bias,
+                                void* y, void* y_pool, uint8_t* pool_idx, int n, int h, int w, int cout, int mode, int relu, void* stream) {
+    WSU_REQUIRE(img && w1, "conv3x3_fused_first: null pointer");
+    return conv3x3_launch_full(nullptr, nullptr, w_packed, bias, y, nullptr, cout, y_pool, pool_idx, nullptr, nullptr,
+                               nullptr, nullptr, nullptr, nullptr, 0, n, h, w, 64, 0, cout, mode, relu, 0, stream, img, w1, b1);
 }
 
 size_t wsu_conv3x3_wino_packed_bytes(int cin, int cout) {

@@ -76,6 +76,7 @@ class UNet(nn.Module):
         self.nsteps = nsteps
         self.mode = mode or os.environ.get("WSU_MODE", "bf16x3")
         self.fuse_head = os.environ.get("WSU_FUSE_HEAD", "1") != "0"  # fold outconv + sigmoid into the last 3x3 conv
+        self.fuse_first = os.environ.get("WSU_FUSE_FIRST", "1") != "0"  # fold e11 into e12's input staging
         self.train_mode = os.environ.get("WSU_TRAIN_MODE", "f32")      # arithmetic of the autograd path ('f32' | 'bf16x3')
         ops.mode_id(self.mode)                                    # validate early
         conv_kw = {"kernel_size": 3, "padding": 1, "padding_mode": "reflect"}
@@ -143,13 +144,27 @@ class UNet(nn.Module):
         t = keep if keep is not None else {}
         save = keep is not None
         e11 = self.e11
-        cur = ops.conv3x3_first(x, e11.weight.detach(), e11.bias.detach(), m, relu=True)
+        # e11 is folded into e12's input staging unless its output is asked for (xe11 then never reaches HBM)
+        fuse_first = self.fuse_first and not save and e11.in_channels == 1 and e11.out_channels == 64
+        cur = None
+        if not fuse_first:
+            cur = ops.conv3x3_first(x, e11.weight.detach(), e11.bias.detach(), m, relu=True)
         if save:
             t["xe11"] = cur
         skips: List[torch.Tensor] = []
         oc_fusable = self.fuse_head and self.outconv.out_channels <= 4
         for lvl in range(self.nsteps + 1):
             a, b = ENC[lvl]
+            if lvl == 0 and fuse_first:
+                lb = self.e12
+                res = ops.conv3x3_fused_first(x, e11.weight, e11.bias.detach(), self._packed("e12", m, "conv"), lb.bias.detach(),
+                                              lb.out_channels, m, pool=self.nsteps > 0)
+                if self.nsteps > 0:
+                    skips.append(res[0])
+                    cur = res[1]
+                else:
+                    cur = res
+                continue
             if lvl >= 1:
                 la = getattr(self, a)
                 cur = ops.conv3x3(cur, None, self._packed(a, m, "conv"), la.bias.detach(), la.out_channels, m)

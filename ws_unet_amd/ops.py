@@ -170,6 +170,28 @@ def conv3x3_head(x1: torch.Tensor, x2: Optional[torch.Tensor], w_packed: torch.T
     return res[0] if len(res) == 1 else tuple(res)
 
 
+def conv3x3_fused_first(x_nchw: torch.Tensor, w1: torch.Tensor, b1: Optional[torch.Tensor], w_packed: torch.Tensor,
+                        bias: Optional[torch.Tensor], cout: int, mode: int, relu: bool = True, pool: bool = False, pool_idx: bool = False):
+    """e11 + e12 (+pool) in one launch (wsu_conv3x3_fused_first_fwd): x_nchw (N,1,H,W) fp32 -> y NHWC [, y_pool [, idx]]."""
+    lib = _lib.load()
+    w1 = w1.detach().contiguous()
+    _dev_check(x_nchw, w1, b1, w_packed, bias)
+    n, cin, h, w = x_nchw.shape
+    assert cin == 1 and tuple(w1.shape) == (64, 1, 3, 3) and x_nchw.dtype == torch.float32
+    y = torch.empty((n, h, w, cout), dtype=act_dtype(mode), device=x_nchw.device)
+    yp = torch.empty((n, h // 2, w // 2, cout), dtype=act_dtype(mode), device=x_nchw.device) if pool else None
+    idx = torch.empty((n, h // 2, w // 2, cout), dtype=torch.uint8, device=x_nchw.device) if (pool and pool_idx) else None
+    esz = 2 if mode == MODE_BF16 else 4
+    meta = {"flops": 2.0 * 9 * 64 * cout * n * h * w,
+            "bytes": float(n * h * w * (4 + cout * esz) + 9 * 64 * cout * esz + (n * (h // 2) * (w // 2) * cout * esz if pool else 0))}
+    check(_launch("conv3x3", meta, lambda: lib.wsu_conv3x3_fused_first_fwd(
+        x_nchw.data_ptr(), w1.data_ptr(), _ptr(b1), w_packed.data_ptr(), _ptr(bias), y.data_ptr(), _ptr(yp), _ptr(idx),
+        n, h, w, cout, mode, int(relu), _stream())), "wsu_conv3x3_fused_first_fwd")
+    if pool:
+        return (y, yp, idx) if pool_idx else (y, yp)
+    return y
+
+
 def pack_conv3x3_wino(w: torch.Tensor) -> torch.Tensor:
     """OIHW fp32 -> Winograd F(2,3) packed weights of wsu_conv3x3_wino_fwd (mode bf16x3)."""
     lib = _lib.load()
