@@ -170,7 +170,8 @@ int wsu_u8_to_unit_f32(const uint8_t* x, float* y, size_t count, void* stream);
  * g: (N,H,W,Cout) fp32.  dx1: (N,H,W,csplit), dx2: (N,H,W,cin-csplit) or NULL (the two inputs of a fused concat).
  * relu_mask1/2 (optional, shapes of dx1/dx2): saved post-ReLU activations; where they are <= 0 the gradient is zeroed,
  * which makes dx the pre-activation gradient of the producing layers.  mode: WSU_MODE_F32 or WSU_MODE_BF16X3. */
-int wsu_conv3x3_bwd_data(const void* g, const void* w_packed_dgrad, const float* w_oihw, float* w_scratch /* 9*cin*cout floats */,
+size_t wsu_conv3x3_bwd_data_workspace_bytes(int n, int h, int w, int cin, int cout, int mode);
+int wsu_conv3x3_bwd_data(const void* g, const void* w_packed_dgrad, const float* w_oihw, void* workspace, size_t workspace_bytes,
                          void* dx1, void* dx2, int csplit, const void* relu_mask1, const void* relu_mask2,
                          int n, int h, int w, int cin, int cout, int mode, void* stream);
 

@@ -58,7 +58,8 @@ SIGNATURES = {
     "wsu_ws_meter_beta": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),
     "wsu_u8_to_unit_f32": (c_int, [_P, _P, c_size_t, _P]),
     # ---- backward / train step
-    "wsu_conv3x3_bwd_data": (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, _P] + [c_int] * 6 + [_P]),
+    "wsu_conv3x3_bwd_data_workspace_bytes": (c_size_t, [c_int] * 6),
+    "wsu_conv3x3_bwd_data": (c_int, [_P, _P, _P, _P, c_size_t, _P, _P, c_int, _P, _P] + [c_int] * 6 + [_P]),
     "wsu_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "wsu_conv3x3_bwd_weight": (c_int, [_P, _P, _P, _P, _P, _P, c_size_t] + [c_int] * 7 + [_P]),
     "wsu_first_bwd_workspace_bytes": (c_size_t, [c_int] * 5),

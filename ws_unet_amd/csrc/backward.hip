@@ -14,93 +14,97 @@ extern "C" int wsu_conv3x3_launch_ex(const void* x1, const void* x2, const void*
                                      int n, int h, int w, int c1, int c2, int cout,
                                      int mode, int relu, int pad_zero, void* stream);
 
+extern "C" int wsu_conv3x3_pack_dgrad_swapped(const float* w_oihw, void* w_packed, int cin, int cout, int mode, void* stream);
+
 namespace {
 
 // ---------------------------------------------------------------------------------------------------
-// Reflect adjoint.  y = conv(reflect_pad(x)) means dx = fold(dxpad), dxpad = full correlation of the
-// zero-extended g with the flipped weights.  The interior part (dxpad restricted to the image) is the
-// zero-padded conv computed by conv3x3_kernel with transposed weights; this kernel adds what the padded
-// border ring folds back:  dx[y, x] += sum over (yp, xp) in preimage(y, x) \ {(y, x)} of dxpad[yp, xp],
-// preimage rows of y = {y} U {-1 if y == 1} U {H if y == H-2}, same for columns.  Only rows 1, H-2 and
-// columns 1, W-2 receive anything.  One workgroup per 16 destination pixels, 16 lanes x 4 input channels per pixel,
-// fixed summation order; the ReLU mask of the producing layer is applied to the addend.
+// Reflect adjoint.  y = conv(reflect_pad(x)) means dx = fold(dxpad), dxpad = full correlation of the zero-extended g with the
+// flipped weights.  The interior part (dxpad restricted to the image) is the zero-padded conv computed by conv3x3_kernel with
+// transposed weights; what the padded border RING (rows -1 and H, columns -1 and W) folds back is added here:
+//   dx[y, x] += sum over (yp, xp) in preimage(y, x) \ {(y, x)} of dxpad[yp, xp],
+//   preimage rows of y = {y} U {-1 if y == 1} U {H if y == H-2}, same for columns  (only rows 1, H-2 and columns 1, W-2 receive).
+// The ring values are themselves zero-padded convolutions of thin strips of g, so they go through the same MFMA kernel:
+//   top / bottom:  2 x (W+2) images [0 ; g row 0] and [g row H-1 ; 0]          -> output row 0 / 1 = dxpad[-1, -1..W] / dxpad[H, ..]
+//   left / right:  the columns g[:, 0] and g[:, W-1] laid out as ROWS of 2 x (H+2) images, multiplied with the tap-swapped
+//                  weights                                                      -> dxpad[-1..H, -1] / dxpad[.., W]
+// (2 launches of ~3 % of the main conv each instead of a scalar kernel), then one thread per destination adds its 1-3 ring values
+// in a fixed order and applies the ReLU mask of the producing layer.
 // ---------------------------------------------------------------------------------------------------
-constexpr int BORDER_PXB = 16;        // destination pixels per workgroup; 16 lanes x 4 channels cover 64 input channels per pixel
+// strips[b][r][j][c], b in [0, 2N): images 0..N-1 = top (left), N..2N-1 = bottom (right); L = W (H) is the strip length
+__global__ __launch_bounds__(256) void ring_gather_kernel(const float* __restrict__ g, float* __restrict__ tb, float* __restrict__ lr,
+                                                          int n, int h, int w, int c) {
+    const int c4 = c >> 2;
+    const long long ntb = (long long)2 * n * 2 * (w + 2) * c4, nlr = (long long)2 * n * 2 * (h + 2) * c4;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < ntb + nlr; i += (long long)gridDim.x * 256) {
+        const bool is_tb = i < ntb;
+        long long t = is_tb ? i : i - ntb;
+        const int len = is_tb ? w : h;
+        const int q = (int)(t % c4); t /= c4;
+        const int j = (int)(t % (len + 2)); t /= (len + 2);
+        const int r = (int)(t & 1); const int bimg = (int)(t >> 1);
+        const int img = bimg < n ? bimg : bimg - n;
+        const bool second = bimg >= n;                                   // bottom / right
+        f32x4 v = mk_f4(0.f, 0.f, 0.f, 0.f);
+        if (j >= 1 && j <= len && r == (second ? 0 : 1)) {
+            const int yy = is_tb ? (second ? h - 1 : 0) : j - 1;
+            const int xx = is_tb ? j - 1 : (second ? w - 1 : 0);
+            v = *reinterpret_cast<const f32x4*>(g + ((size_t)(img * h + yy) * w + xx) * c + 4 * q);
+        }
+        float* dst = is_tb ? tb : lr;
+        *reinterpret_cast<f32x4*>(dst + (((size_t)bimg * 2 + r) * (len + 2) + j) * c + 4 * q) = v;
+    }
+}
 
-__global__ __launch_bounds__(256) void dgrad_border_kernel(const float* __restrict__ g, const float* __restrict__ w_t,
-                                                           float* __restrict__ dx1, float* __restrict__ dx2,
-                                                           const float* __restrict__ mask1, const float* __restrict__ mask2,
-                                                           int n, int h, int w, int cin, int csplit, int cout) {
+__global__ __launch_bounds__(256) void ring_fold_kernel(const float* __restrict__ tb, const float* __restrict__ lr,
+                                                        float* __restrict__ dx1, float* __restrict__ dx2,
+                                                        const float* __restrict__ mask1, const float* __restrict__ mask2,
+                                                        int n, int h, int w, int cin, int csplit) {
     // destination list per image: row 1 (w px), row h-2 (w px, if h-2 != 1), then columns 1 and w-2 for the other rows
     const int nrows = (h - 2 != 1) ? 2 : 1;
     const int ncols = (w - 2 != 1) ? 2 : 1;
     const int per_img = nrows * w + ncols * (h - nrows);
-    const int blocks_per_img = (per_img + BORDER_PXB - 1) / BORDER_PXB;
-    const int img = blockIdx.x / blocks_per_img;
-    int b = (blockIdx.x - img * blocks_per_img) * BORDER_PXB + (threadIdx.x >> 4);
-    const int cg = threadIdx.x & 15;
-    if (b >= per_img) return;
-    int y, x;
-    if (b < nrows * w) { y = (b / w == 0) ? 1 : h - 2; x = b % w; }
-    else {
-        b -= nrows * w;
-        const int k = b / ncols, which = b % ncols;       // k-th row that is not a border-destination row
-        int row = k;
-        if (row >= 1) ++row;                              // skip row 1
-        if (nrows == 2 && row >= h - 2) ++row;            // skip row h-2
-        y = row; x = (which == 0) ? 1 : w - 2;
-    }
-    int ys[3], xs[3]; int ny = 0, nx = 0;
-    ys[ny++] = y; if (y == 1) ys[ny++] = -1; if (y == h - 2) ys[ny++] = h;
-    xs[nx++] = x; if (x == 1) xs[nx++] = -1; if (x == w - 2) xs[nx++] = w;
-    // (source pixel, tap) pairs of this destination, in a fixed order (at most 8 x 9)
-    for (int ci = 4 * cg; ci < cin; ci += 64) {
+    const int c4 = cin >> 2;
+    const long long total = (long long)n * per_img * c4;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int q = (int)(i % c4); long long t = i / c4;
+        int b = (int)(t % per_img); const int img = (int)(t / per_img);
+        int y, x;
+        if (b < nrows * w) { y = (b / w == 0) ? 1 : h - 2; x = b % w; }
+        else {
+            b -= nrows * w;
+            const int k = b / ncols, which = b % ncols;
+            int row = k;
+            if (row >= 1) ++row;                              // skip row 1
+            if (nrows == 2 && row >= h - 2) ++row;            // skip row h-2
+            y = row; x = (which == 0) ? 1 : w - 2;
+        }
+        int ys[3], xs[3]; int ny = 0, nx = 0;
+        ys[ny++] = y; if (y == 1) ys[ny++] = -1; if (y == h - 2) ys[ny++] = h;
+        xs[nx++] = x; if (x == 1) xs[nx++] = -1; if (x == w - 2) xs[nx++] = w;
+        const int ci = 4 * q;
         f32x4 acc = mk_f4(0.f, 0.f, 0.f, 0.f);
         for (int iy = 0; iy < ny; ++iy)
             for (int ix = 0; ix < nx; ++ix) {
-                if (iy == 0 && ix == 0) continue;         // (y, x) itself is the interior part
+                if (iy == 0 && ix == 0) continue;             // (y, x) itself is the interior part
                 const int yp = ys[iy], xp = xs[ix];
-                for (int u = 0; u < 3; ++u) {
-                    const int sy = yp - u + 1;
-                    if (sy < 0 || sy >= h) continue;
-                    for (int v = 0; v < 3; ++v) {
-                        const int sx = xp - v + 1;
-                        if (sx < 0 || sx >= w) continue;
-                        const f32x4* gp = reinterpret_cast<const f32x4*>(g + ((size_t)(img * h + sy) * w + sx) * cout);
-                        const float* wp = w_t + ((size_t)(u * 3 + v) * cout) * cin + ci;      // [tap][co][ci]: 4 consecutive ci per lane
-                        f32x4 s4 = mk_f4(0.f, 0.f, 0.f, 0.f);
-                        for (int co = 0; co < cout; co += 4) {
-                            const f32x4 gv = gp[co >> 2];
-                            const f32x4 w0 = *reinterpret_cast<const f32x4*>(wp + (size_t)(co + 0) * cin);
-                            const f32x4 w1 = *reinterpret_cast<const f32x4*>(wp + (size_t)(co + 1) * cin);
-                            const f32x4 w2 = *reinterpret_cast<const f32x4*>(wp + (size_t)(co + 2) * cin);
-                            const f32x4 w3 = *reinterpret_cast<const f32x4*>(wp + (size_t)(co + 3) * cin);
-                            s4 = s4 + gv.x * w0; s4 = s4 + gv.y * w1; s4 = s4 + gv.z * w2; s4 = s4 + gv.w * w3;
-                        }
-                        acc = acc + s4;
-                    }
-                }
+                const float* src;
+                if (yp == -1)      src = tb + (((size_t)img * 2 + 0) * (w + 2) + xp + 1) * cin;
+                else if (yp == h)  src = tb + (((size_t)(n + img) * 2 + 1) * (w + 2) + xp + 1) * cin;
+                else if (xp == -1) src = lr + (((size_t)img * 2 + 0) * (h + 2) + yp + 1) * cin;
+                else               src = lr + (((size_t)(n + img) * 2 + 1) * (h + 2) + yp + 1) * cin;
+                acc = acc + *reinterpret_cast<const f32x4*>(src + ci);
             }
         float* dst; const float* mk; int c, cc;
         if (ci < csplit) { dst = dx1; mk = mask1; c = csplit; cc = ci; }
         else             { dst = dx2; mk = mask2; c = cin - csplit; cc = ci - csplit; }
         const size_t o = ((size_t)(img * h + y) * w + x) * c + cc;
-        f32x4 cur = *reinterpret_cast<f32x4*>(dst + o);
         if (mk) {
             const f32x4 m = *reinterpret_cast<const f32x4*>(mk + o);
             if (!(m.x > 0.f)) acc.x = 0.f; if (!(m.y > 0.f)) acc.y = 0.f;
             if (!(m.z > 0.f)) acc.z = 0.f; if (!(m.w > 0.f)) acc.w = 0.f;
         }
-        *reinterpret_cast<f32x4*>(dst + o) = cur + acc;
-    }
-}
-
-// OIHW -> [tap][co][ci] so that the border kernel's lanes (one per ci) read consecutive floats
-__global__ void border_weight_transpose_kernel(const float* __restrict__ w, float* __restrict__ wt, int cin, int cout) {
-    const int total = 9 * cout * cin;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-        const int ci = i % cin, co = (i / cin) % cout, tap = i / (cin * cout);
-        wt[i] = w[((size_t)co * cin + ci) * 9 + tap];
+        *reinterpret_cast<f32x4*>(dst + o) = *reinterpret_cast<const f32x4*>(dst + o) + acc;
     }
 }
 
@@ -471,29 +475,55 @@ int wsu_conv3x3_first_bwd_data(const float* g, const float* w_oihw, float* dx_nc
 }
 
 // dx (= pre-activation gradient of the producing layer when relu_mask is given) of the 3x3 reflect conv.
-//   g: (N,H,W,Cout) fp32;  w_packed_dgrad: wsu_conv3x3_pack_dgrad output;  w_oihw: the plain weight (border fold).
+//   g: (N,H,W,Cout) fp32;  w_packed_dgrad: wsu_conv3x3_pack_dgrad output;  w_oihw: the plain weight (re-packed with swapped taps
+//   for the left / right strips);  workspace: wsu_conv3x3_bwd_data_workspace_bytes().
 //   dx1: (N,H,W,csplit), dx2: (N,H,W,cin-csplit) or NULL (csplit == cin);  relu_mask*: tensors of the dx shapes or NULL.
-int wsu_conv3x3_bwd_data(const void* g, const void* w_packed_dgrad, const float* w_oihw, float* w_scratch,
+static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+size_t wsu_conv3x3_bwd_data_workspace_bytes(int n, int h, int w, int cin, int cout, int mode) {
+    if (n <= 0 || h < 2 || w < 2 || cin <= 0 || cout <= 0) return 0;
+    const size_t strips = (size_t)2 * n * 2 * ((size_t)(w + 2) + (size_t)(h + 2));
+    return align256(wsu_conv3x3_packed_bytes(cout, cin, mode)) + align256(strips * cout * sizeof(float)) + align256(strips * cin * sizeof(float));
+}
+
+int wsu_conv3x3_bwd_data(const void* g, const void* w_packed_dgrad, const float* w_oihw, void* workspace, size_t workspace_bytes,
                          void* dx1, void* dx2, int csplit, const void* relu_mask1, const void* relu_mask2,
                          int n, int h, int w, int cin, int cout, int mode, void* stream) {
     WSU_REQUIRE(mode == WSU_MODE_F32 || mode == WSU_MODE_BF16X3, "conv3x3_bwd_data: fp32-storage modes only (got %d)", mode);
-    WSU_REQUIRE(w_oihw && w_scratch, "conv3x3_bwd_data: null weight / scratch (scratch: 9*cin*cout floats)");
-    WSU_REQUIRE(cin % WSU_COB == 0, "conv3x3_bwd_data: cin=%d must be a multiple of %d", cin, WSU_COB);
+    WSU_REQUIRE(w_oihw && workspace, "conv3x3_bwd_data: null weight / workspace");
+    WSU_REQUIRE(cin % WSU_COB == 0 && csplit % 4 == 0 && cout % 4 == 0, "conv3x3_bwd_data: cin=%d must be a multiple of %d", cin, WSU_COB);
+    WSU_REQUIRE(workspace_bytes >= wsu_conv3x3_bwd_data_workspace_bytes(n, h, w, cin, cout, mode), "conv3x3_bwd_data: workspace too small");
     int rc = wsu_conv3x3_launch_ex(g, nullptr, w_packed_dgrad, nullptr, dx1, dx2, csplit, nullptr, nullptr,
                                    relu_mask1, relu_mask2, n, h, w, cout, 0, cin, mode, 0, 1, stream);
     if (rc) return rc;
-    const int nrows = (h - 2 != 1) ? 2 : 1, ncols = (w - 2 != 1) ? 2 : 1;
-    const int per_img = nrows * w + ncols * (h - nrows);
-    const long long nblk = (long long)n * ((per_img + BORDER_PXB - 1) / BORDER_PXB);
-    WSU_REQUIRE(nblk < 0x7FFFFFFFLL, "conv3x3_bwd_data: border grid too large");
-    WSU_REQUIRE(csplit % 4 == 0 && cout % 4 == 0, "conv3x3_bwd_data: csplit=%d / cout=%d must be multiples of 4", csplit, cout);
-    hipLaunchKernelGGL(border_weight_transpose_kernel, dim3(64), dim3(256), 0, static_cast<hipStream_t>(stream), w_oihw, w_scratch, cin, cout);
-    rc = wsu_check_launch("border_weight_transpose_kernel");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    char* wsp = static_cast<char*>(workspace);
+    void* wp_swapped = wsp;
+    float* in_tb = reinterpret_cast<float*>(wsp + align256(wsu_conv3x3_packed_bytes(cout, cin, mode)));
+    float* in_lr = in_tb + (size_t)2 * n * 2 * (w + 2) * cout;
+    float* out_tb = reinterpret_cast<float*>(reinterpret_cast<char*>(in_tb) + align256((size_t)2 * n * 2 * ((size_t)(w + 2) + (h + 2)) * cout * sizeof(float)));
+    float* out_lr = out_tb + (size_t)2 * n * 2 * (w + 2) * cin;
+    rc = wsu_conv3x3_pack_dgrad_swapped(w_oihw, wp_swapped, cin, cout, mode, stream);
     if (rc) return rc;
-    hipLaunchKernelGGL(dgrad_border_kernel, dim3((unsigned)nblk), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       (const float*)g, (const float*)w_scratch, (float*)dx1, (float*)dx2, (const float*)relu_mask1, (const float*)relu_mask2,
-                       n, h, w, cin, csplit, cout);
-    return wsu_check_launch("dgrad_border_kernel");
+    {
+        const long long items = (long long)2 * n * 2 * ((long long)(w + 2) + (h + 2)) * (cout / 4);
+        const unsigned nblk = (unsigned)((items + 255) / 256 < 65536 ? (items + 255) / 256 : 65536);
+        hipLaunchKernelGGL(ring_gather_kernel, dim3(nblk), dim3(256), 0, s, (const float*)g, in_tb, in_lr, n, h, w, cout);
+        rc = wsu_check_launch("ring_gather_kernel");
+        if (rc) return rc;
+    }
+    rc = wsu_conv3x3_launch_ex(in_tb, nullptr, w_packed_dgrad, nullptr, out_tb, nullptr, cin, nullptr, nullptr, nullptr, nullptr,
+                               2 * n, 2, w + 2, cout, 0, cin, mode, 0, 1, stream);
+    if (rc) return rc;
+    rc = wsu_conv3x3_launch_ex(in_lr, nullptr, wp_swapped, nullptr, out_lr, nullptr, cin, nullptr, nullptr, nullptr, nullptr,
+                               2 * n, 2, h + 2, cout, 0, cin, mode, 0, 1, stream);
+    if (rc) return rc;
+    const int nrows = (h - 2 != 1) ? 2 : 1, ncols = (w - 2 != 1) ? 2 : 1;
+    const long long items = (long long)n * (nrows * w + ncols * (h - nrows)) * (cin / 4);
+    const unsigned nblk = (unsigned)((items + 255) / 256 < 65536 ? (items + 255) / 256 : 65536);
+    hipLaunchKernelGGL(ring_fold_kernel, dim3(nblk), dim3(256), 0, s, out_tb, out_lr, (float*)dx1, (float*)dx2,
+                       (const float*)relu_mask1, (const float*)relu_mask2, n, h, w, cin, csplit);
+    return wsu_check_launch("ring_fold_kernel");
 }
 
 int wsu_maxpool2x2_bwd(float* g_full, const float* dy_pool, const uint8_t* pool_idx, const float* xp_relu_mask,

@@ -1225,7 +1225,8 @@ __global__ void pack_conv3x3_kernel(const float* __restrict__ w, char* __restric
         const int m = cb * WSU_COB + co;
         const int u = tap / 3, v = tap % 3;
         float val;
-        if (transpose_flip) val = w[(((size_t)ci * cin + m) * 3 + (2 - u)) * 3 + (2 - v)];   // W[co=ci_d][ci=m]
+        if (transpose_flip == 2) val = w[(((size_t)ci * cin + m) * 3 + (2 - v)) * 3 + (2 - u)];   // as below with the two tap axes swapped
+        else if (transpose_flip) val = w[(((size_t)ci * cin + m) * 3 + (2 - u)) * 3 + (2 - v)];   // W[co=ci_d][ci=m]
         else                val = w[(((size_t)m * cin + ci) * 3 + u) * 3 + v];
         if (MODE == WSU_MODE_F32) {
             reinterpret_cast<float*>(dst)[d] = val;
@@ -1269,6 +1270,11 @@ size_t wsu_conv3x3_packed_bytes(int cin, int cout, int mode) {
 
 int wsu_conv3x3_pack(const float* w_oihw, void* w_packed, int cin, int cout, int mode, void* stream) {
     return pack_impl(w_oihw, w_packed, cin, cout, mode, 0, stream);
+}
+
+// internal (backward.hip): data-gradient weights with the row / column tap axes swapped, for the transposed left / right border strips
+int wsu_conv3x3_pack_dgrad_swapped(const float* w_oihw, void* w_packed, int cin, int cout, int mode, void* stream) {
+    return pack_impl(w_oihw, w_packed, cin, cout, mode, 2, stream);
 }
 
 int wsu_conv3x3_pack_dgrad(const float* w_oihw, void* w_packed, int cin, int cout, int mode, void* stream) {

@@ -441,10 +441,11 @@ def conv3x3_bwd_data(g: torch.Tensor, w_packed_dgrad: torch.Tensor, w_oihw: torc
     dx1 = torch.empty((n, h, w, csplit), dtype=torch.float32, device=g.device)
     dx2 = torch.empty((n, h, w, cin - csplit), dtype=torch.float32, device=g.device) if csplit < cin else None
     meta = {"flops": 2.0 * 9 * cin * cout * n * h * w}
-    scratch = torch.empty(9 * cin * cout, dtype=torch.float32, device=g.device)
+    nbytes = lib.wsu_conv3x3_bwd_data_workspace_bytes(n, h, w, cin, cout, mode)
+    ws = workspace(nbytes, g.device)                          # border strips + tap-swapped weights (fp32 view, grow-only)
     check(_launch("conv3x3_bwd_data", meta, lambda: lib.wsu_conv3x3_bwd_data(
-        g.data_ptr(), w_packed_dgrad.data_ptr(), w_oihw.data_ptr(), scratch.data_ptr(), dx1.data_ptr(), _ptr(dx2), csplit, _ptr(mask1), _ptr(mask2),
-        n, h, w, cin, cout, mode, _stream())), "wsu_conv3x3_bwd_data")
+        g.data_ptr(), w_packed_dgrad.data_ptr(), w_oihw.data_ptr(), ws.data_ptr(), ws.numel() * 4, dx1.data_ptr(), _ptr(dx2), csplit,
+        _ptr(mask1), _ptr(mask2), n, h, w, cin, cout, mode, _stream())), "wsu_conv3x3_bwd_data")
     return dx1, dx2
 
 
