@@ -136,11 +136,14 @@ def test_losses_golden(golden):
         losses.get_loss("crossentropy")
 
 
+@pytest.mark.parametrize("mode", ["f32", "bf16x3"])
 @pytest.mark.parametrize("ns", [0, 1, 2])
-def test_unet_gradients_golden(golden, ns):
-    """dL/dtheta of L1WS on 2x1x64x64 cover/stego pairs for all parameter tensors (reference autograd golden)."""
+def test_unet_gradients_golden(golden, ns, mode):
+    """dL/dtheta of L1WS on 2x1x64x64 cover/stego pairs for all parameter tensors (reference autograd golden); an 'f32' model
+    trains in exact fp32, the default 'bf16x3' model with split-bf16 arithmetic."""
     g = golden["unet_grad"]
-    model = gpu_model(ns, "he", "f32")
+    model = gpu_model(ns, "he", mode)
+    assert model.train_mode == mode
     cov_u8 = formula.synthetic_images(2, 64, 64, seed=11)
     st_u8 = cov_u8.copy(); st_u8[0] = formula.lsbr_embed(cov_u8[0], 0.4, seed=5)
     covers = torch.from_numpy(cov_u8.astype(np.float32) / np.float32(255.))[:, None].to(DEV)
@@ -151,7 +154,7 @@ def test_unet_gradients_golden(golden, ns):
     loss = losses.L1WSLoss()(out, (covers, alphas), inputs)
     loss.backward()
     assert math.isclose(loss.item(), float(g[f"grad{ns}_loss"][0]), rel_tol=1e-5)
-    np.testing.assert_allclose(out.detach().cpu().numpy(), g[f"grad{ns}_out"], atol=4e-6, rtol=0)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), g[f"grad{ns}_out"], atol=4e-6 if mode == "f32" else 2e-5, rtol=0)
     for k, p in model.named_parameters():
         got = p.grad.detach().cpu().numpy().reshape(-1)
         ref = g[f"grad{ns}_{k}_sub"]
@@ -161,11 +164,15 @@ def test_unet_gradients_golden(golden, ns):
         # sign(cover - out) and the ReLU masks flip on fp32 rounding noise.  Measured against an fp64 oracle
         # (tools/diag_grads.py, profiles/r01/grad_error_vs_fp64_unet2_64x64.txt): torch-CPU fp32 is off by 1e-4
         # relative L2 on every layer, libwsu by 2e-5..3e-4.
+        # The split-bf16 forward moves the outputs by ~2e-6, which flips more of those signs: against fp64 its gradients are off by
+        # 1-2.5e-4 relative L2 on unet_2 (2x torch-CPU fp32) and by 3e-3 / 1e-2 of the scale at worst on the ill-conditioned
+        # unet_0 case, where fp32 itself misses the fp64 loss by 2e-4 (profiles/r01/grad_error_vs_fp64_bf16x3.txt).
         scale = float(np.abs(ref).max())
-        np.testing.assert_allclose(got, ref, rtol=0, atol=1.5e-3 * scale + 1e-12, err_msg=f"unet_{ns} {k}")
+        tol = 1.5e-3 if mode == "f32" else 1.5e-2
+        np.testing.assert_allclose(got, ref, rtol=0, atol=tol * scale + 1e-12, err_msg=f"unet_{ns} {k}")
         s = g[f"grad{ns}_{k}_sum"]
         full = p.grad.detach().double().cpu().numpy()
-        assert math.isclose(float(np.sqrt((full ** 2).sum())), s[2], rel_tol=1e-3), k
+        assert math.isclose(float(np.sqrt((full ** 2).sum())), s[2], rel_tol=1e-3 if mode == "f32" else 8e-3), k
     # inputs.requires_grad exercises the input-gradient kernel here, but the golden grad{ns}_dx is not comparable: the
     # reference's WS term depends on `inputs` directly (losses.py:59-62) and autograd adds that path, while the fused loss
     # treats inputs as data (as the training loop does).  The input gradient is checked in test_saliency_style_input_gradient.

@@ -1,6 +1,6 @@
 """Train-step timing (BASELINE.json configs[2]): unet_2 fwd + L1WS loss + bwd + AdamW on a synthetic batch of
 512x512 cover/stego pairs, one GPU.  Prints one JSON line with images/s and the per-kernel time split.
-Usage: python tools/bench_train.py [--batch 16] [--steps 5] [--size 512] [--train-mode f32|bf16x3]"""
+Usage: python tools/bench_train.py [--batch 16] [--steps 5] [--size 512] [--train-mode bf16x3|f32]"""
 import argparse, json, sys, time
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
@@ -14,7 +14,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=16)
 ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--size", type=int, default=512)
-ap.add_argument("--train-mode", default="f32")
+ap.add_argument("--train-mode", default="bf16x3")
 a = ap.parse_args()
 dev = torch.device("cuda")
 m = get_model("unet_2", in_channels=1, out_channels=1, channel=[0], drop_rate=None, mode="f32")

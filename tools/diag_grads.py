@@ -1,5 +1,5 @@
 """Diagnostic (not a test): gradient error of the GPU backward vs an fp64 CPU oracle, next to the error of the
-fp32 CPU oracle vs the same fp64 truth.  Usage: python tools/diag_grads.py [nsteps] [size]"""
+fp32 CPU oracle vs the same fp64 truth.  Usage: python tools/diag_grads.py [nsteps] [size] [f32|bf16x3]"""
 import sys
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
@@ -12,6 +12,7 @@ from oracle import unet_ref, losses_ref
 
 ns = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 size = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+mode = sys.argv[3] if len(sys.argv) > 3 else "f32"          # 'f32' (exact) or 'bf16x3' (split-bf16 train arithmetic)
 cov_u8 = formula.synthetic_images(2, size, size, seed=11)
 st_u8 = cov_u8.copy(); st_u8[0] = formula.lsbr_embed(cov_u8[0], 0.4, seed=5)
 covers = torch.from_numpy(cov_u8.astype(np.float32) / np.float32(255.))[:, None]
@@ -27,7 +28,7 @@ def oracle(dtype):
 
 g64, l64 = oracle(torch.float64)
 g32, l32 = oracle(torch.float32)
-model = gpu_model(ns, "he", "f32")
+model = gpu_model(ns, "he", mode)
 out = model(inputs.to(DEV))
 loss = losses.L1WSLoss()(out, (covers.to(DEV), alphas.to(DEV)), inputs.to(DEV))
 loss.backward()

@@ -9,7 +9,7 @@ The arithmetic is libwsu (hand-written gfx950 kernels, include/wsu.h); there is 
 CPU / eager fallback: calling the model with CPU tensors raises.
 
 Precision modes (``mode=`` or env ``WSU_MODE``):
-  'f32'     exact fp32 MFMA                     -- parity anchor, training
+  'f32'     exact fp32 MFMA                     -- parity anchor (also trains in exact fp32)
   'bf16x3'  split-bf16 MFMA, fp32 storage       -- default; meets the 1e-4 MAE gate (~2e-6)
   'bf16'    bf16 storage + MFMA                 -- fastest; MAE ~1e-3 on full-range weights
 """
@@ -77,7 +77,9 @@ class UNet(nn.Module):
         self.mode = mode or os.environ.get("WSU_MODE", "bf16x3")
         self.fuse_head = os.environ.get("WSU_FUSE_HEAD", "1") != "0"  # fold outconv + sigmoid into the last 3x3 conv
         self.fuse_first = os.environ.get("WSU_FUSE_FIRST", "1") != "0"  # fold e11 into e12's input staging
-        self.train_mode = os.environ.get("WSU_TRAIN_MODE", "f32")      # arithmetic of the autograd path ('f32' | 'bf16x3')
+        # arithmetic of the autograd path: exact fp32 MFMA for an 'f32' model, split-bf16 (fp32 storage and accumulation,
+        # ~2^-16 relative per product -- finer than the TF32 convs PyTorch trains with by default on the reference's GPUs) otherwise
+        self.train_mode = os.environ.get("WSU_TRAIN_MODE") or ("f32" if self.mode == "f32" else "bf16x3")
         ops.mode_id(self.mode)                                    # validate early
         conv_kw = {"kernel_size": 3, "padding": 1, "padding_mode": "reflect"}
         ups_kw = {"kernel_size": 2, "stride": 2}
