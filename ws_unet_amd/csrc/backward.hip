@@ -367,39 +367,78 @@ __global__ void pack_convt_dgrad_kernel(const float* __restrict__ w, char* __res
 // x: NCHW fp32 planes, g: NHWC (N,H,W,cout).  64 output channels per block column, pixels chunked over
 // blocks, two-stage fixed-order reduction.
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void first_wgrad_partial_kernel(const float* __restrict__ g, const float* __restrict__ x,
-                                                                  float* __restrict__ part, int n, int h, int w, int cin, int cout, int chunk) {
-    const int ch = blockIdx.y * 64 + (threadIdx.x & 63);
-    const int grp = threadIdx.x >> 6;
+// Pixels are walked in tiles of 256: the g tile [256 px][64 co] (coalesced 16-byte loads) and the 3x3 input windows [256 px][12] go
+// through LDS, then thread (cg = 4 output channels, ps = pixel slice) accumulates its 9 x 4 products over the pixels ps, ps+16, ...
+// (a wave reads 4 consecutive 256-byte rows per step: conflict free).  One block column per 64 output channels.
+constexpr int FW_TILE = 256;
+constexpr int FW_LDS = FW_TILE * 64 * 4 + FW_TILE * 12 * 4;       // 77824 B
+
+__global__ __launch_bounds__(256, 2) void first_wgrad_partial_kernel(const float* __restrict__ g, const float* __restrict__ x,
+                                                                     float* __restrict__ part, int n, int h, int w, int cin, int cout, int chunk) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* gl = reinterpret_cast<float*>(smem);                    // [256][64]
+    float* xl = gl + FW_TILE * 64;                                 // [256][12]
+    const int tid = threadIdx.x, cg = tid & 15, ps = tid >> 4;
+    const int ch0 = blockIdx.y * 64;
     const long long npix = (long long)n * h * w;
     const long long p0 = (long long)blockIdx.x * chunk, p1 = min(p0 + chunk, npix);
-    __shared__ float red[256];
     float* dst = part + (size_t)blockIdx.x * (cin * 9 + 1) * cout;
-    for (int ci = 0; ci < cin; ++ci) {                      // the bias sum rides on the ci == 0 pass
-        float acc[9], accb = 0.f;
+    for (int ci = 0; ci < cin; ++ci) {                             // the bias sum rides on the ci == 0 pass
+        f32x4 acc[9], accb = mk_f4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int t = 0; t < 9; ++t) acc[t] = 0.f;
-#pragma unroll 4
-        for (long long p = p0 + grp; p < p1; p += 4) {
-            const float gv = g[(size_t)p * cout + ch];
-            accb += gv;
-            const int xx = (int)(p % w); const long long t2 = p / w;
-            const int yy = (int)(t2 % h); const int nn = (int)(t2 / h);
-            const float* xp = x + ((size_t)nn * cin + ci) * h * w;
-#pragma unroll
-            for (int t = 0; t < 9; ++t)
-                acc[t] = fmaf(gv, xp[(size_t)wsu_reflect(yy + t / 3 - 1, h) * w + wsu_reflect(xx + t % 3 - 1, w)], acc[t]);
-        }
-#pragma unroll
-        for (int t = 0; t < 10; ++t) {                      // compile-time t: acc[] stays in registers
-            if (t == 9 && ci != 0) break;
+        for (int t = 0; t < 9; ++t) acc[t] = mk_f4(0.f, 0.f, 0.f, 0.f);
+        for (long long t0 = p0; t0 < p1; t0 += FW_TILE) {
             __syncthreads();
-            red[threadIdx.x] = t < 9 ? acc[t < 9 ? t : 0] : accb;
-            __syncthreads();
-            if (threadIdx.x < 64) {
-                const int row = t < 9 ? ci * 9 + t : cin * 9;
-                dst[(size_t)row * cout + ch] = (red[threadIdx.x] + red[threadIdx.x + 64]) + (red[threadIdx.x + 128] + red[threadIdx.x + 192]);
+#pragma unroll
+            for (int k = 0; k < FW_TILE * 16 / 256; ++k) {             // 16 granules of 16 B per pixel row
+                const int i = tid + k * 256, pl = i >> 4, q = i & 15;
+                f32x4 v = mk_f4(0.f, 0.f, 0.f, 0.f);
+                if (t0 + pl < p1) v = *reinterpret_cast<const f32x4*>(g + (size_t)(t0 + pl) * cout + ch0 + 4 * q);
+                *reinterpret_cast<f32x4*>(gl + pl * 64 + 4 * q) = v;
             }
+            {
+                const long long p = t0 + tid;                          // one pixel's window per thread
+                float win[12];
+#pragma unroll
+                for (int t = 0; t < 12; ++t) win[t] = 0.f;
+                if (p < p1) {
+                    const int xx = (int)(p % w); const long long t2 = p / w;
+                    const int yy = (int)(t2 % h); const int nn = (int)(t2 / h);
+                    const float* xp = x + ((size_t)nn * cin + ci) * h * w;
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) win[t] = xp[(size_t)wsu_reflect(yy + t / 3 - 1, h) * w + wsu_reflect(xx + t % 3 - 1, w)];
+                }
+#pragma unroll
+                for (int t = 0; t < 3; ++t) *reinterpret_cast<f32x4*>(xl + tid * 12 + 4 * t) = mk_f4(win[4 * t], win[4 * t + 1], win[4 * t + 2], win[4 * t + 3]);
+            }
+            __syncthreads();
+#pragma unroll 4
+            for (int i = 0; i < FW_TILE / 16; ++i) {
+                const int pl = ps + 16 * i;
+                const f32x4 gv = *reinterpret_cast<const f32x4*>(gl + pl * 64 + 4 * cg);
+                const f32x4 w0 = *reinterpret_cast<const f32x4*>(xl + pl * 12), w1 = *reinterpret_cast<const f32x4*>(xl + pl * 12 + 4);
+                const float w8 = xl[pl * 12 + 8];
+                accb = accb + gv;
+                acc[0] = acc[0] + gv * w0.x; acc[1] = acc[1] + gv * w0.y; acc[2] = acc[2] + gv * w0.z; acc[3] = acc[3] + gv * w0.w;
+                acc[4] = acc[4] + gv * w1.x; acc[5] = acc[5] + gv * w1.y; acc[6] = acc[6] + gv * w1.z; acc[7] = acc[7] + gv * w1.w;
+                acc[8] = acc[8] + gv * w8;
+            }
+        }
+        // reduce the 16 pixel slices in a fixed order through LDS: red[slice][10 rows][64 co]
+        __syncthreads();
+        float* red = gl;                                            // 16 * 10 * 64 floats = 40 KB, inside the g tile
+#pragma unroll
+        for (int t = 0; t < 10; ++t)
+            *reinterpret_cast<f32x4*>(red + (ps * 10 + t) * 64 + 4 * cg) = t < 9 ? acc[t < 9 ? t : 0] : accb;
+        __syncthreads();
+        for (int i = tid; i < 10 * 64; i += 256) {
+            const int t = i >> 6, co = i & 63;
+            if (t == 9 && ci != 0) continue;
+            float sum = 0.f;
+#pragma unroll
+            for (int sl = 0; sl < 16; ++sl) sum += red[(sl * 10 + t) * 64 + co];
+            const int row = t < 9 ? ci * 9 + t : cin * 9;
+            dst[(size_t)row * cout + ch0 + co] = sum;
         }
     }
 }
@@ -612,7 +651,13 @@ int wsu_conv3x3_first_bwd_weight(const float* g, const float* x_nchw, float* dw,
     const int nchunks = (int)((npix + chunk - 1) / chunk);
     WSU_REQUIRE(wsu_first_bwd_workspace_bytes(n, h, w, cin, cout) <= workspace_bytes, "conv3x3_first_bwd_weight: workspace too small");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(first_wgrad_partial_kernel, dim3(nchunks, cout / 64), dim3(256), 0, s, g, x_nchw, workspace, n, h, w, cin, cout, chunk);
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&first_wgrad_partial_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, FW_LDS);
+        if (e != hipSuccess) { wsu_set_error("hipFuncSetAttribute(first_wgrad): %s", hipGetErrorString(e)); return WSU_ERR_HIP; }
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(first_wgrad_partial_kernel, dim3(nchunks, cout / 64), dim3(256), FW_LDS, s, g, x_nchw, workspace, n, h, w, cin, cout, chunk);
     int rc = wsu_check_launch("first_wgrad_partial_kernel");
     if (rc) return rc;
     const int tot = (cin * 9 + 1) * cout;
