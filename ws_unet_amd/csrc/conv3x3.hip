@@ -594,59 +594,89 @@ _Pragma("unroll")
 //   y[2t], y[2t+1] = A^T [ (G w) .* (B^T d) ],  d = x[2t-1 .. 2t+2],  w = the three column taps of one kernel row
 //   B^T d = (d0-d2, d1+d2, d2-d1, d1-d3)   G w = (w0, (w0+w1+w2)/2, (w0-w1+w2)/2, w2)   A^T m = (m0+m1+m2, m1-m2-m3)
 // -> 3 rows x 4 positions = 12 "taps", each a GEMM over HALF the columns: 36 instead of 54 MFMAs per wave and 16-channel chunk.
-// Workgroup = 16 x 32 output pixels x 64 channels, 16 waves (the NW = 16 shape of the direct kernel), wave = 32 channels x
-// (2 rows x 16 column pairs) with one accumulator tile per position (4 x 16 registers).
-// LDS: transformed input  V[granule plane 4][position 4][18 rows][16 column pairs][16 B]   73 728 B  (bf16 hi / lo of B^T d)
+// Workgroup = 12 x 32 output pixels x 64 channels, 12 waves (3 per SIMD, 168 registers: 16 waves at 128 registers spilled), wave =
+// 32 channels x (2 rows x 16 column pairs) with one accumulator tile per position (4 x 16 registers).
+// LDS: transformed input  V[granule plane 4][position 4][14 rows][16 column pairs][16 B]   57 344 B  (bf16 hi / lo of B^T d)
 //      transformed weights U[12 taps][4 planes][64 co][16 B]                               49 152 B  (packed by pack_wino)
-// Staging: waves 0-8 own one (row, column pair, 8-channel half) each: 4 pixels x 32 B from global, B^T d in fp32, split, 8 x 16 B
-// to LDS; waves 9-15 copy the weight tile.  Register double-buffered like the direct kernel; the epilogue applies A^T on the
-// accumulators and then is the shared tile epilogue (bias, ReLU, stores, pool, head).
+// Staging: waves 0-6 own one (row, column pair, 8-channel half) each: their own two pixels (+ the tile's edge pixels) from global
+// memory, the other two from the neighbour lanes (ds_bpermute), B^T d in fp32, split, 8 x 16 B to LDS; waves 7-11 copy the weight
+// tile.  Loads of the next chunk are issued one per MFMA step; the epilogue applies A^T on the accumulators and then is the shared
+// tile epilogue (bias, ReLU, stores, pool, head).
+// Status (profiles/r01/conv3x3_ablation.md): parity-green and as fast as the direct kernel (0.96-1.02x) -- the MFMA saving (its
+// matrix + epilogue part is 1.2x faster) is spent on the input transform, which one workgroup per CU cannot hide behind another
+// workgroup's matrix phase.  Not the product path.
 // =====================================================================================================
 constexpr int WN_TAPS = 12, WN_TC = 16;
 constexpr int WN_LDS_W = WN_TAPS * WSU_GRAN * WSU_COB * 16;          // 49152
-constexpr int WN_TH = 16, WN_IH = WN_TH + 2, WN_NT = 1024;
+constexpr int WN_TH = 12, WN_IH = WN_TH + 2, WN_NT = 768;           // 12 waves = 3 per SIMD -> 168 registers each (16 waves spilled at 128)
 constexpr int WN_PLANE = 4 * WN_IH * WN_TC * 16;                     // 18432 B per granule plane
 constexpr int WN_LDS_V = WSU_GRAN * WN_PLANE;                        // 73728
-constexpr int WN_VTHREADS = WN_IH * WN_TC * 2;                       // 576 = waves 0..8
-constexpr int WN_WTHREADS = WN_NT - WN_VTHREADS;                     // 448
+constexpr int WN_VTHREADS = WN_IH * WN_TC * 2;                       // 448 = waves 0..6
+constexpr int WN_WTHREADS = WN_NT - WN_VTHREADS;                     // 320
 constexpr int WN_WITEMS = WN_LDS_W / 16;                             // 3072
-constexpr int WN_WVEC = (WN_WITEMS + WN_WTHREADS - 1) / WN_WTHREADS; // 7
-constexpr int WN_ST = 8;
+constexpr int WN_WVEC = (WN_WITEMS + WN_WTHREADS - 1) / WN_WTHREADS; // 10
+constexpr int WN_ST = WN_WVEC > 8 ? WN_WVEC : 8;
 
 struct WinoPlan { int rowbase; int xbase; int ldsoff; };             // rowbase < 0: the whole source row is zero padding
 
-__device__ __forceinline__ void wino_load(const ConvArgs& a, int cb, int c, int tid, const WinoPlan& pl, u32x4 (&st)[WN_ST]) {
+// Staging registers of a V thread (row, column pair tc, 8-channel half): st[0..1] = own pixel d1, st[2..3] = own pixel d2,
+// st[4..5] = the halo pixel that no neighbour lane owns (d0 for tc == 0, d3 for tc == 15); d0 / d3 of the inner column pairs come
+// from the neighbour lanes at commit time (ds_bpermute), so every input pixel is fetched from global memory once per workgroup.
+template <int K>
+__device__ __forceinline__ void wino_load_slot(const ConvArgs& a, int cb, int c, int tid, const WinoPlan& pl, u32x4 (&st)[WN_ST]) {
     if (tid < WN_VTHREADS) {
-        const char* src; int csrc, ch0;
-        if (c < a.nch1) { src = a.x1; csrc = a.c1; ch0 = c * 16; }
-        else            { src = a.x2; csrc = a.c2; ch0 = (c - a.nch1) * 16; }
-        const int h = tid & 1;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        if constexpr (K < 6) {
+            const char* src; int csrc, ch0;
+            if (c < a.nch1) { src = a.x1; csrc = a.c1; ch0 = c * 16; }
+            else            { src = a.x2; csrc = a.c2; ch0 = (c - a.nch1) * 16; }
+            constexpr int half = K & 1;
+            const int tc = (tid >> 1) & 15;
+            const int i = K < 2 ? 1 : (K < 4 ? 2 : (tc == 0 ? 0 : 3));
             int xx = pl.xbase + i;
-            bool ok = pl.rowbase >= 0;
+            bool ok = pl.rowbase >= 0 && (K < 4 || tc == 0 || tc == 15);
             if (a.pad_zero) ok = ok && xx >= 0 && xx < a.w; else xx = wsu_reflect(xx, a.w);
-            u32x4 v0 = mk_u4(0, 0, 0, 0), v1 = v0;
-            if (ok) {
-                const u32x4* g = reinterpret_cast<const u32x4*>(src + ((size_t)(pl.rowbase + xx) * csrc + ch0) * 4 + h * 32);
-                v0 = g[0]; v1 = g[1];
-            }
-            st[2 * i] = v0; st[2 * i + 1] = v1;
+            u32x4 v = mk_u4(0, 0, 0, 0);
+            if (ok) v = reinterpret_cast<const u32x4*>(src + ((size_t)(pl.rowbase + xx) * csrc + ch0) * 4 + (tid & 1) * 32)[half];
+            st[K] = v;
         }
     } else {
-        const u32x4* wsrc = reinterpret_cast<const u32x4*>(a.wp + ((size_t)cb * a.nch + c) * WN_LDS_W);
-        const int t = tid - WN_VTHREADS;
-#pragma unroll
-        for (int k = 0; k < WN_WVEC; ++k)
-            if (t + k * WN_WTHREADS < WN_WITEMS) st[k] = wsrc[t + k * WN_WTHREADS];
+        if constexpr (K < WN_WVEC) {
+            const u32x4* wsrc = reinterpret_cast<const u32x4*>(a.wp + ((size_t)cb * a.nch + c) * WN_LDS_W);
+            const int t = tid - WN_VTHREADS;
+            if (t + K * WN_WTHREADS < WN_WITEMS) st[K] = wsrc[t + K * WN_WTHREADS];
+        }
     }
+}
+
+__device__ __forceinline__ void wino_load(const ConvArgs& a, int cb, int c, int tid, const WinoPlan& pl, u32x4 (&st)[WN_ST]) {
+    WSU_STATIC_FOR(WN_ST, k, { wino_load_slot<k>(a, cb, c, tid, pl, st); });
 }
 
 __device__ __forceinline__ void wino_commit(char* smem, int tid, const WinoPlan& pl, const u32x4 (&st)[WN_ST]) {
     if (tid < WN_VTHREADS) {
         f32x4 d[4][2];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { d[i][0] = __builtin_bit_cast(f32x4, st[2 * i]); d[i][1] = __builtin_bit_cast(f32x4, st[2 * i + 1]); }
+        d[1][0] = __builtin_bit_cast(f32x4, st[0]); d[1][1] = __builtin_bit_cast(f32x4, st[1]);
+        d[2][0] = __builtin_bit_cast(f32x4, st[2]); d[2][1] = __builtin_bit_cast(f32x4, st[3]);
+        {
+            // d0 = pixel 2tc-1 = the d2 of column pair tc-1 (two lanes down), d3 = pixel 2tc+2 = the d1 of column pair tc+1
+            const int lane = tid & 63, tc = (tid >> 1) & 15;
+            const int from_lo = ((lane - 2) & 63) * 4, from_hi = ((lane + 2) & 63) * 4;
+            // (inline asm: hipcc folded the per-element __builtin_amdgcn_ds_bpermute calls of one vector into a single exchange)
+            auto exch = [](int addr, const f32x4& v) __attribute__((always_inline)) {
+                f32x4 r;
+                asm volatile("ds_bpermute_b32 %0, %4, %5\n\tds_bpermute_b32 %1, %4, %6\n\tds_bpermute_b32 %2, %4, %7\n\tds_bpermute_b32 %3, %4, %8\n\t"
+                             "s_waitcnt lgkmcnt(0)"
+                             : "=&v"(r.x), "=&v"(r.y), "=&v"(r.z), "=&v"(r.w) : "v"(addr), "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+                return r;
+            };
+            WSU_STATIC_FOR(2, k, {                          // compile-time k: `st[4 + k]` in a plain unrolled loop pins st[] in scratch
+                const f32x4 halo = __builtin_bit_cast(f32x4, st[4 + k]);
+                const f32x4 n0 = exch(from_lo, d[2][k]);
+                d[0][k] = tc == 0 ? halo : n0;
+                const f32x4 n3 = exch(from_hi, d[1][k]);
+                d[3][k] = tc == 15 ? halo : n3;
+            });
+        }
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             f32x4 v0, v1;
@@ -663,13 +693,11 @@ __device__ __forceinline__ void wino_commit(char* smem, int tid, const WinoPlan&
     } else {
         u32x4* wdst = reinterpret_cast<u32x4*>(smem + WN_LDS_V);
         const int t = tid - WN_VTHREADS;
-#pragma unroll
-        for (int k = 0; k < WN_WVEC; ++k)
-            if (t + k * WN_WTHREADS < WN_WITEMS) wdst[t + k * WN_WTHREADS] = st[k];
+        WSU_STATIC_FOR(WN_WVEC, k, { if (t + k * WN_WTHREADS < WN_WITEMS) wdst[t + k * WN_WTHREADS] = st[k]; });
     }
 }
 
-__global__ __launch_bounds__(WN_NT, 4) void conv3x3_wino_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(WN_NT) __attribute__((amdgpu_waves_per_eu(3, 3))) void conv3x3_wino_kernel(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int MODE = WSU_MODE_BF16X3;
     const int tid = threadIdx.x;
@@ -683,7 +711,7 @@ __global__ __launch_bounds__(WN_NT, 4) void conv3x3_wino_kernel(const ConvArgs a
 
     WinoPlan pl;
     {
-        const int h = tid & 1, tc = (tid >> 1) & 15, row = tid >> 5;            // staging threads: tid < 576 -> row 0..17
+        const int h = tid & 1, tc = (tid >> 1) & 15, row = tid >> 5;            // staging threads: tid < 448 -> row 0..13
         int yy = y0 - 1 + row;
         bool ok = true;
         if (a.pad_zero) ok = yy >= 0 && yy < a.h; else yy = wsu_reflect(yy, a.h);
@@ -708,11 +736,15 @@ __global__ __launch_bounds__(WN_NT, 4) void conv3x3_wino_kernel(const ConvArgs a
         __syncthreads();
         if (!(a.ablate & 2) || c == 0) wino_commit(smem, tid, pl, st);
         __syncthreads();
-        if (c + 1 < a.nch && !(a.ablate & 1)) wino_load(a, cb, c + 1, tid, pl, st);
-        if (a.ablate & 4) continue;
+        const bool prefetch = c + 1 < a.nch && !(a.ablate & 1);
+        if (a.ablate & 4) { if (prefetch) wino_load(a, cb, c + 1, tid, pl, st); continue; }
         WSU_STATIC_FOR(3, dy, {
             WSU_STATIC_FOR(4, p, {
                 constexpr int tap = dy * 4 + p;
+                // next chunk's loads, one slot per MFMA step; only vector-memory instructions are pinned between the fences
+                __builtin_amdgcn_sched_barrier(0x38F);
+                if (prefetch) wino_load_slot<tap>(a, cb, c + 1, tid, pl, st);
+                __builtin_amdgcn_sched_barrier(0x38F);
                 const u32x4 ahi = *reinterpret_cast<const u32x4*>(ldsA + ((tap * 4 + hh) * 64) * 16);
                 const u32x4 alo = *reinterpret_cast<const u32x4*>(ldsA + ((tap * 4 + 2 + hh) * 64) * 16);
                 const u32x4 bhi = *reinterpret_cast<const u32x4*>(ldsB + hh * WN_PLANE + (p * WN_IH + dy) * (WN_TC * 16));
