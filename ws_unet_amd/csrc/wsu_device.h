@@ -50,14 +50,21 @@ __device__ __forceinline__ uint32_t wsu_pack_bf16x2(float a, float b) {
 }
 __device__ __forceinline__ float wsu_bf16_lo_residual(float a) { return a - (float)(__bf16)a; }
 
-// 8 fp32 -> 8 bf16 (hi) and 8 bf16 (lo = bf16(x - hi)), each as a 16-byte granule
+// 8 fp32 -> 8 bf16 (hi) and 8 bf16 (lo = bf16_rne(x - hi)), each as a 16-byte granule.  hi is rounded to nearest by integer
+// arithmetic on the fp32 word (add 0x8000, keep the upper half: ties go away from zero instead of to even, nothing else differs
+// from v_cvt_pk_bf16_f32) and two heads are packed by one v_perm: ~4 VALU instructions per value instead of the ~9 the
+// convert / widen / canonicalise sequence of `(float)(__bf16)x` compiled to (profiles/r01/conv3x3_ablation.md, instruction mix).
+// Inf / NaN inputs: the add can carry into the exponent of the largest finite values (-> inf), like any round-to-nearest does.
+__device__ __forceinline__ void wsu_split2(float a, float b, uint32_t& hi, uint32_t& lo) {
+    const uint32_t ra = __builtin_bit_cast(uint32_t, a) + 0x8000u, rb = __builtin_bit_cast(uint32_t, b) + 0x8000u;
+    hi = __builtin_amdgcn_perm(rb, ra, 0x07060302u);                      // (ra >> 16) | (rb & 0xFFFF0000)
+    lo = wsu_pack_bf16x2(a - __builtin_bit_cast(float, ra & 0xFFFF0000u), b - __builtin_bit_cast(float, rb & 0xFFFF0000u));
+}
 __device__ __forceinline__ void wsu_split8(const f32x4& a, const f32x4& b, u32x4& hi, u32x4& lo) {
-    hi.x = wsu_pack_bf16x2(a.x, a.y); hi.y = wsu_pack_bf16x2(a.z, a.w);
-    hi.z = wsu_pack_bf16x2(b.x, b.y); hi.w = wsu_pack_bf16x2(b.z, b.w);
-    lo.x = wsu_pack_bf16x2(wsu_bf16_lo_residual(a.x), wsu_bf16_lo_residual(a.y));
-    lo.y = wsu_pack_bf16x2(wsu_bf16_lo_residual(a.z), wsu_bf16_lo_residual(a.w));
-    lo.z = wsu_pack_bf16x2(wsu_bf16_lo_residual(b.x), wsu_bf16_lo_residual(b.y));
-    lo.w = wsu_pack_bf16x2(wsu_bf16_lo_residual(b.z), wsu_bf16_lo_residual(b.w));
+    uint32_t h0, h1, h2, h3, l0, l1, l2, l3;
+    wsu_split2(a.x, a.y, h0, l0); wsu_split2(a.z, a.w, h1, l1);
+    wsu_split2(b.x, b.y, h2, l2); wsu_split2(b.z, b.w, h3, l3);
+    hi = mk_u4(h0, h1, h2, h3); lo = mk_u4(l0, l1, l2, l3);
 }
 
 __device__ __forceinline__ float wsu_bf16_to_f32(uint16_t v) { return __builtin_bit_cast(float, (uint32_t)v << 16); }
