@@ -387,15 +387,28 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 
 // plain per-channel sum over pixels (bias gradient of the transposed conv: db[co] = sum dy[..., co])
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, float* __restrict__ part, long long npix, int c, int chunk) {
-    // grid = (nchunks, c/64); block: 64 channels x 4 pixel groups
-    const int ch = blockIdx.y * 64 + (threadIdx.x & 63);
+    // grid = (nchunks, c/64); block: 16 channel quads (16-byte loads) x 16 pixel lanes, 4 pixels in flight per lane
+    const int q = threadIdx.x & 15, ps = threadIdx.x >> 4;
+    const int ch0 = blockIdx.y * 64 + 4 * q;
     const long long p0 = (long long)blockIdx.x * chunk, p1 = min(p0 + chunk, npix);
-    float s = 0.f;
-    for (long long p = p0 + (threadIdx.x >> 6); p < p1; p += 4) s += x[p * c + ch];
-    __shared__ float red[256];
-    red[threadIdx.x] = s;
+    f32x4 s0 = mk_f4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
+    long long p = p0 + ps;
+    for (; p + 48 < p1; p += 64) {
+        s0 = s0 + *reinterpret_cast<const f32x4*>(x + p * c + ch0);
+        s1 = s1 + *reinterpret_cast<const f32x4*>(x + (p + 16) * c + ch0);
+        s2 = s2 + *reinterpret_cast<const f32x4*>(x + (p + 32) * c + ch0);
+        s3 = s3 + *reinterpret_cast<const f32x4*>(x + (p + 48) * c + ch0);
+    }
+    for (; p < p1; p += 16) s0 = s0 + *reinterpret_cast<const f32x4*>(x + p * c + ch0);
+    __shared__ float red[16][64];
+    *reinterpret_cast<f32x4*>(&red[ps][4 * q]) = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    if (threadIdx.x < 64) part[(size_t)blockIdx.x * c + ch] = (red[threadIdx.x] + red[threadIdx.x + 64]) + (red[threadIdx.x + 128] + red[threadIdx.x + 192]);
+    if (threadIdx.x < 64) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][threadIdx.x];
+        part[(size_t)blockIdx.x * c + blockIdx.y * 64 + threadIdx.x] = t;
+    }
 }
 __global__ void colsum_final_kernel(const float* __restrict__ part, float* __restrict__ out, int nchunks, int c) {
     const int ch = blockIdx.x * blockDim.x + threadIdx.x;
