@@ -263,3 +263,23 @@ def test_gpu_predictor_refuses_pickling_clearly():
     from ws_unet_amd.ws.estimate import UNetEstimator
     with pytest.raises(TypeError, match="cannot be pickled"):
         pickle.dumps(UNetEstimator(model=object()))
+
+
+def test_train_driver_argument_merge(tmp_path, monkeypatch):
+    """`python -m ws_unet_amd.train --config <published config.json> --dataset ...`: config keys are taken over, flags win."""
+    from ws_unet_amd import train as train_mod
+    cfg = {"network": "unet_2", "alpha": "0.400", "batch_size": 16, "loss": "l1ws", "learning_rate": 0.0001, "drop_rate": 0.0,
+           "stego_method": "LSBR", "tr_csv": "split_tr.csv", "va_csv": "split_va.csv", "num_epochs": 300, "patience": 10,
+           "dataset": "/gpfs/somewhere", "output_dir": "/gpfs/out", "print_freq": 50, "num_workers": 8, "covers_only": False}
+    f = tmp_path / "config.json"
+    f.write_text(json.dumps(cfg))
+    seen = {}
+    monkeypatch.setattr(train_mod, "train", lambda args: seen.update(args) or 0.0)
+    train_mod.main(["--config", str(f), "--dataset", str(tmp_path), "--output_dir", str(tmp_path / "runs"), "--num_epochs", "2",
+                    "--covers_only", "false", "--channel", "0"])
+    assert seen["dataset"] == str(tmp_path) and seen["output_dir"] == str(tmp_path / "runs") and seen["num_epochs"] == 2
+    assert seen["network"] == "unet_2" and seen["alpha"] == "0.400" and seen["batch_size"] == 16 and seen["stego_method"] == "LSBR"
+    assert "print_freq" not in seen and "num_workers" not in seen          # keys this driver has no use for are dropped
+    assert seen["covers_only"] is False and seen["channel"] == [0]
+    with pytest.raises(SystemExit):
+        train_mod.main([])                                                  # --dataset is mandatory
