@@ -32,7 +32,7 @@ sys.path.insert(0, str(ROOT))
 import numpy as np
 import torch
 
-PEAK = {"bf16x3": 2.5e15, "bf16": 2.5e15, "f32": 157.3e12}     # dense MFMA peaks, MI355X_MICROARCH.md
+PEAK = {"bf16x3": 2.5e15, "bf16x3s": 2.5e15, "bf16": 2.5e15, "f32": 157.3e12}     # dense MFMA peaks, MI355X_MICROARCH.md
 HBM_PEAK = 8.0e12
 
 
@@ -124,7 +124,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--mode", default=os.environ.get("WSU_BENCH_MODE", "bf16x3"), choices=["bf16x3", "bf16", "f32"])
+    ap.add_argument("--mode", default=os.environ.get("WSU_BENCH_MODE", "bf16x3"), choices=["bf16x3", "bf16x3s", "bf16", "f32"])
     ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -178,7 +178,9 @@ def main():
             "metric": "512x512 grayscale images/sec (UNet predict)", "value": value, "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"bf16x3": "bf16x3 (bf16 MFMA on split fp32 operands, fp32 accumulate)", "bf16": "bf16", "f32": "f32"}[args.mode],
+            "dtype": {"bf16x3": "bf16x3 (bf16 MFMA on split fp32 operands, fp32 accumulate)",
+                      "bf16x3s": "bf16x3 (bf16 MFMA on split fp32 operands, fp32 accumulate; activations stored as their hi/lo halves)",
+                      "bf16": "bf16", "f32": "f32"}[args.mode],
             "data": "synthetic",
             "config": {"workload": f"unet_2 forward-only predict, batch={args.batch}/GPU synthetic {args.size}x{args.size}x1 "
                                    "(BASELINE.json configs[1]), formula 'he' weights, inputs resident in HBM",

@@ -23,6 +23,11 @@
  *      WSU_MODE_BF16X3 = 1  fp32 storage, split-bf16 (hi*hi + hi*lo + lo*hi) on
  *                           v_mfma_f32_32x32x16_bf16, fp32 accumulate (~2^-17 rel. error)
  *      WSU_MODE_BF16   = 2  bf16 storage, bf16 MFMA, fp32 accumulate
+ *      WSU_MODE_BF16X3S = 3 the arithmetic of BF16X3 on activations stored ALREADY SPLIT by their producer: per pixel and 16-channel
+ *                           chunk  [bf16 hi of ch 0-7][hi 8-15][lo 0-7][lo 8-15]  (4 x 16 B = the fp32 chunk size, so tensors keep
+ *                           their fp32 allocation).  Staging becomes a plain copy; results are bitwise those of BF16X3.  Forward
+ *                           entry points only (wsu_conv3x3_fwd / _head_fwd / _fused_first_fwd, wsu_convt2x2_fwd); weights are packed
+ *                           as for BF16X3; no pool_idx, no zero padding.
  */
 #ifndef WSU_H
 #define WSU_H
@@ -36,7 +41,7 @@ extern "C" {
 
 #define WSU_VERSION 100
 
-enum { WSU_MODE_F32 = 0, WSU_MODE_BF16X3 = 1, WSU_MODE_BF16 = 2 };
+enum { WSU_MODE_F32 = 0, WSU_MODE_BF16X3 = 1, WSU_MODE_BF16 = 2, WSU_MODE_BF16X3S = 3 };
 
 enum {
     WSU_OK = 0,

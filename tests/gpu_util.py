@@ -55,3 +55,14 @@ def oracle_forward(x, nsteps, variant="he", intermediates=None):
 def err_stats(got: torch.Tensor, ref: torch.Tensor):
     d = (got.double() - ref.double()).abs()
     return {"max": d.max().item(), "mean": d.mean().item(), "refmax": ref.abs().max().item()}
+
+
+def unsplit(t_nhwc: torch.Tensor) -> torch.Tensor:
+    """'bf16x3s' storage -> fp32 values hi + lo (test-side restatement of the layout in include/wsu.h: per pixel and 16-channel
+    chunk  hi 0-7 | hi 8-15 | lo 0-7 | lo 8-15, bf16 each)."""
+    raw = t_nhwc.detach().cpu().contiguous().numpy().view(np.uint16)            # (N,H,W,2C) halves
+    n, h, w, c2 = raw.shape
+    c = c2 // 2
+    q = raw.reshape(n, h, w, c // 16, 2, 2, 8)                                   # chunk, (hi|lo), half, channel-in-half
+    f = (q.astype(np.uint32) << 16).view(np.float32)
+    return torch.from_numpy((f[..., 0, :, :] + f[..., 1, :, :]).reshape(n, h, w, c).copy())

@@ -73,6 +73,9 @@ struct ConvArgs {
     const float* head_w; const float* head_b; float* head_out; float* head_logit; int head_cout;    // fused first layer (e11, unet.py:141): the 64 input channels of THIS conv are computed while staging from a 1-plane image
     // (img: (N,1,H,W) fp32, w1: (64,1,3,3), b1: (64) or null); x1 is then null
     const float* img; const float* w1; const float* b1;
+    // API mode WSU_MODE_BF16X3S: activations stored already split (per pixel and 16-channel chunk: hi 0-7 | hi 8-15 | lo 0-7 | lo 8-15,
+    // 4 x 16 B = the fp32 chunk size).  The input side is the template flag PS (staging becomes a plain copy), the output side this flag.
+    int out_split;
 };
 
 template <int MODE> struct Epi {
@@ -84,13 +87,14 @@ template <int MODE> struct Epi {
 
 
 // Global -> registers for chunk c (input tile items + this workgroup's packed-weight slice).
-template <int MODE, int NW, bool F1 = false>
+template <int MODE, int NW, bool F1 = false, bool PS = false>
 __device__ __forceinline__ void stage_load(const ConvArgs& a, int cb, int c, int tid, const int (&pixidx)[Shape<NW>::IN_VEC],
                                            u32x4 (&st_in)[Shape<NW>::ST_IN], u32x4 (&st_w)[Shape<NW>::W_VEC]) {
     constexpr int NT = Shape<NW>::NT, W_VEC = Shape<NW>::W_VEC;
     constexpr int ESZ = Epi<MODE>::ESZ;
     constexpr int CK = (MODE == WSU_MODE_BF16) ? 32 : 16;
-    constexpr int NLOOP = (MODE == WSU_MODE_BF16X3) ? Shape<NW>::IN_VEC3 : Shape<NW>::IN_VEC;
+    constexpr bool SPLIT_HERE = MODE == WSU_MODE_BF16X3 && !PS;     // fp32 in HBM, split while committing (2 items of 32 B per pixel)
+    constexpr int NLOOP = SPLIT_HERE ? Shape<NW>::IN_VEC3 : Shape<NW>::IN_VEC;
     const char* src; int csrc, ch0;
     if (c < a.nch1) { src = a.x1; csrc = a.c1; ch0 = c * CK; }
     else            { src = a.x2; csrc = a.c2; ch0 = (c - a.nch1) * CK; }
@@ -98,7 +102,7 @@ __device__ __forceinline__ void stage_load(const ConvArgs& a, int cb, int c, int
 #pragma unroll
     for (int j = 0; j < NLOOP; ++j) {
         const int p = pixidx[j];
-        if constexpr (MODE == WSU_MODE_BF16X3) {
+        if constexpr (SPLIT_HERE) {
             const int sub = (tid + j * NT) & 1;
             u32x4 v0 = mk_u4(0, 0, 0, 0), v1 = v0;
             if (p >= 0) {
@@ -182,16 +186,17 @@ __device__ __forceinline__ void stage_commit_first(char* smem, int tid, int c, c
 }
 
 // Registers -> LDS (granule-planar input tile, linear weight tile); BF16X3 splits fp32 into bf16 hi/lo here.
-template <int MODE, int NW>
+template <int MODE, int NW, bool PS = false>
 __device__ __forceinline__ void stage_commit(char* smem, int tid, const int (&pixidx)[Shape<NW>::IN_VEC], const int (&ldsoff)[Shape<NW>::IN_VEC],
                                              const u32x4 (&st_in)[Shape<NW>::ST_IN], const u32x4 (&st_w)[Shape<NW>::W_VEC]) {
     constexpr int NT = Shape<NW>::NT, W_VEC = Shape<NW>::W_VEC;
     constexpr int PLANE_IN = Shape<NW>::PLANE_IN, LDS_IN = Shape<NW>::LDS_IN;
-    constexpr int NLOOP = (MODE == WSU_MODE_BF16X3) ? Shape<NW>::IN_VEC3 : Shape<NW>::IN_VEC;
+    constexpr bool SPLIT_HERE = MODE == WSU_MODE_BF16X3 && !PS;
+    constexpr int NLOOP = SPLIT_HERE ? Shape<NW>::IN_VEC3 : Shape<NW>::IN_VEC;
 #pragma unroll
     for (int j = 0; j < NLOOP; ++j) {
         if (pixidx[j] != -2) {
-            if constexpr (MODE == WSU_MODE_BF16X3) {
+            if constexpr (SPLIT_HERE) {
                 u32x4 hi, lo;
                 wsu_split8(__builtin_bit_cast(f32x4, st_in[2 * j]), __builtin_bit_cast(f32x4, st_in[2 * j + 1]), hi, lo);
                 *reinterpret_cast<u32x4*>(smem + ldsoff[j]) = hi;
@@ -250,6 +255,52 @@ __device__ __forceinline__ void tile_epilogue(const ConvArgs& a, char* smem, int
                     if (a.head_logit) a.head_logit[o] = z[co];
                     a.head_out[o] = 1.f / (1.f + expf(-z[co]));
                 }
+        }
+    }
+    if constexpr (MODE == WSU_MODE_BF16X3) {
+        if (a.out_split) {
+            // ---- pre-split stores (mode BF16X3S): per pixel and 16-channel chunk  hi 0-7 | hi 8-15 | lo 0-7 | lo 8-15; one item = 8 channels
+            if (ydst)
+                for (int i = tid; i < TH * TW * 8; i += NT) {
+                    const int px = i >> 3, g8 = i & 7;
+                    const int r = px / TW, c = px % TW;
+                    if (y0 + r < a.h && x0 + c < a.w) {
+                        const float* row = reinterpret_cast<const float*>(smem + px * STRIDE) + 8 * g8;
+                        u32x4 hi, lo;
+                        wsu_split8(*reinterpret_cast<const f32x4*>(row), *reinterpret_cast<const f32x4*>(row + 4), hi, lo);
+                        char* dst = ydst + (((size_t)(n * a.h + y0 + r) * a.w + x0 + c) * ych + ycoff) * 4 + (g8 >> 1) * 64 + (g8 & 1) * 16;
+                        *reinterpret_cast<u32x4*>(dst) = hi;
+                        *reinterpret_cast<u32x4*>(dst + 32) = lo;
+                    }
+                }
+            if (a.ypool) {
+                const int hp = a.h >> 1, wp2 = a.w >> 1;
+                for (int i = tid; i < (TH / 2) * (TW / 2) * 8; i += NT) {
+                    const int pp = i >> 3, g8 = i & 7;
+                    const int pr = pp / (TW / 2), pc = pp % (TW / 2);
+                    const int gy = (y0 >> 1) + pr, gx = (x0 >> 1) + pc;
+                    if (gy < hp && gx < wp2) {
+                        const float* b0 = reinterpret_cast<const float*>(smem + ((2 * pr) * TW + 2 * pc) * STRIDE) + 8 * g8;
+                        f32x4 m0 = *reinterpret_cast<const f32x4*>(b0), m1 = *reinterpret_cast<const f32x4*>(b0 + 4);
+#pragma unroll
+                        for (int wdx = 1; wdx < 4; ++wdx) {                // window order of the fp32 path (first max wins; NaN propagates)
+                            const float* bq = reinterpret_cast<const float*>(smem + ((2 * pr + (wdx >> 1)) * TW + 2 * pc + (wdx & 1)) * STRIDE) + 8 * g8;
+                            const f32x4 q0 = *reinterpret_cast<const f32x4*>(bq), q1 = *reinterpret_cast<const f32x4*>(bq + 4);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                if (q0[e] > m0[e] || q0[e] != q0[e]) m0[e] = q0[e];
+                                if (q1[e] > m1[e] || q1[e] != q1[e]) m1[e] = q1[e];
+                            }
+                        }
+                        u32x4 hi, lo;
+                        wsu_split8(m0, m1, hi, lo);
+                        char* dst = a.ypool + (((size_t)(n * hp + gy) * wp2 + gx) * a.cout + cglob) * 4 + (g8 >> 1) * 64 + (g8 & 1) * 16;
+                        *reinterpret_cast<u32x4*>(dst) = hi;
+                        *reinterpret_cast<u32x4*>(dst + 32) = lo;
+                    }
+                }
+            }
+            return;
         }
     }
     if (ydst)
@@ -338,7 +389,7 @@ __device__ __forceinline__ void tile_epilogue(const ConvArgs& a, char* smem, int
     }
 }
 
-template <int MODE, int NW, bool S16 = false, bool F1 = false>
+template <int MODE, int NW, bool S16 = false, bool F1 = false, bool PS = false>
 __global__ __launch_bounds__(NW * 64, NW >= 8 ? 4 : 2) void conv3x3_kernel(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int ESZ = Epi<MODE>::ESZ;
@@ -356,13 +407,14 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 4 : 2) void conv3x3_kernel(const
     // ---- per-thread staging plan (identical for every chunk) ---------------------------------------
     int pixidx[IN_VEC];      // linear pixel index (n*H + y)*W + x of the source, -1 = zero, -2 = no item
     int ldsoff[IN_VEC];
-    constexpr int NITEMS = (MODE == WSU_MODE_BF16X3) ? NPIX_IN * 2 : NPIX_IN * 4;
-    constexpr int NLOOP = (MODE == WSU_MODE_BF16X3) ? Shape<NW>::IN_VEC3 : IN_VEC;
+    constexpr bool SPLIT_HERE = MODE == WSU_MODE_BF16X3 && !PS;     // F1 computes its input and always splits here
+    constexpr int NITEMS = SPLIT_HERE ? NPIX_IN * 2 : NPIX_IN * 4;
+    constexpr int NLOOP = SPLIT_HERE ? Shape<NW>::IN_VEC3 : IN_VEC;
 #pragma unroll
     for (int j = 0; j < NLOOP; ++j) {
         const int i = tid + j * NT;
-        const int pix = (MODE == WSU_MODE_BF16X3) ? (i >> 1) : (i >> 2);
-        const int sub = (MODE == WSU_MODE_BF16X3) ? (i & 1) : (i & 3);
+        const int pix = SPLIT_HERE ? (i >> 1) : (i >> 2);
+        const int sub = SPLIT_HERE ? (i & 1) : (i & 3);
         const int r = pix / IW, c = pix - r * IW;
         int yy = y0 - 1 + r, xx = x0 - 1 + c;
         int p;
@@ -424,16 +476,16 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 4 : 2) void conv3x3_kernel(const
     }
     WSU_STAMP(0);
     if ((a.ablate & 512) && blockIdx.x < 2048 && threadIdx.x == 0) g_stamps[blockIdx.x * WSU_NSTAMP + 30] = __builtin_amdgcn_s_memrealtime();
-    stage_load<MODE, NW, F1>(a, cb, 0, tid, pixidx, st_in, st_w);
+    stage_load<MODE, NW, F1, PS>(a, cb, 0, tid, pixidx, st_in, st_w);
     WSU_STAMP(1);
     for (int c = 0; c < a.nch; ++c) {
         __syncthreads();
         if (c < 6) WSU_STAMP(2 + 4 * c);
         if constexpr (F1) stage_commit_first<MODE, NW>(smem, tid, c, pixidx, ldsoff, st_w);
-        else if (!(a.ablate & 2) || c == 0) stage_commit<MODE, NW>(smem, tid, pixidx, ldsoff, st_in, st_w);
+        else if (!(a.ablate & 2) || c == 0) stage_commit<MODE, NW, PS>(smem, tid, pixidx, ldsoff, st_in, st_w);
         __syncthreads();
         if (c < 6) WSU_STAMP(3 + 4 * c);
-        if (c + 1 < a.nch && !(a.ablate & 1)) stage_load<MODE, NW, F1>(a, cb, c + 1, tid, pixidx, st_in, st_w);
+        if (c + 1 < a.nch && !(a.ablate & 1)) stage_load<MODE, NW, F1, PS>(a, cb, c + 1, tid, pixidx, st_in, st_w);
         if (c < 6) WSU_STAMP(4 + 4 * c);
         if (a.ablate & 4) continue;                                     // no LDS fragment reads, no MFMA
         if constexpr (S16 && MODE == WSU_MODE_BF16) {
@@ -1181,7 +1233,7 @@ int launch_conv_pp(const ConvArgs& a, hipStream_t s) {
     return wsu_check_launch("conv3x3_pp_kernel");
 }
 
-template <int MODE, int NW, bool S16 = false, bool F1 = false>
+template <int MODE, int NW, bool S16 = false, bool F1 = false, bool PS = false>
 int launch_conv_nw(const ConvArgs& a_in, hipStream_t s) {
     constexpr int EPI_BYTES = Shape<NW>::TH * TW * Epi<MODE>::STRIDE;
     constexpr int MAIN_BYTES = Shape<NW>::LDS_MAIN + (F1 ? F1_BYTES(Shape<NW>::NPIX_IN) : 0);
@@ -1190,20 +1242,23 @@ int launch_conv_nw(const ConvArgs& a_in, hipStream_t s) {
     a.tiles_y = (a.h + Shape<NW>::TH - 1) / Shape<NW>::TH;
     static bool attr_done = false;     // benign race: idempotent
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<MODE, NW, S16, F1>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<MODE, NW, S16, F1, PS>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) { wsu_set_error("hipFuncSetAttribute(conv3x3): %s", hipGetErrorString(e)); return WSU_ERR_HIP; }
         attr_done = true;
     }
     const long long nblk = (long long)a.n * a.tiles_x * a.tiles_y * a.ncb;
     if (nblk <= 0 || nblk > 0x7FFFFFFFLL) { wsu_set_error("conv3x3: grid of %lld workgroups out of range", nblk); return WSU_ERR_ARG; }
-    hipLaunchKernelGGL((conv3x3_kernel<MODE, NW, S16, F1>), dim3((unsigned)nblk), dim3(NW * 64), lds, s, a);
+    hipLaunchKernelGGL((conv3x3_kernel<MODE, NW, S16, F1, PS>), dim3((unsigned)nblk), dim3(NW * 64), lds, s, a);
     return wsu_check_launch("conv3x3_kernel");
 }
 
 // WSU_CONV_WAVES=4|8 overrides the workgroup shape (tuning / A-B runs); default chosen per mode by measurement.
 template <int MODE>
-int launch_conv(const ConvArgs& a, hipStream_t s) {
+int launch_conv(const ConvArgs& a, hipStream_t s, bool in_split = false) {
+    if constexpr (MODE == WSU_MODE_BF16X3) {
+        if (in_split) return launch_conv_nw<MODE, 8, false, false, true>(a, s);      // pre-split input: the measured default shape only
+    }
     // Default = the per-tile kernel (v1): measured faster (bench conv3x3 15.8 ms vs 17.9 ms per batch-32 forward in bf16x3).
     // WSU_CONV_IMPL=pp selects the ping-pong kernel (kept for the next tuning round; profiles/r01/conv3x3_ablation.md).
     if (a.img) {                                                // fused first layer: the measured default shape of each mode
@@ -1321,7 +1376,11 @@ static int conv3x3_launch_full(const void* x1, const void* x2, const void* w_pac
                           int n, int h, int w, int c1, int c2, int cout,
                           int mode, int relu, int pad_zero, void* stream,
                           const float* first_img = nullptr, const float* first_w = nullptr, const float* first_b = nullptr) {
-    WSU_REQUIRE(mode >= 0 && mode <= 2, "conv3x3: bad mode %d", mode);
+    WSU_REQUIRE(mode >= 0 && mode <= 3, "conv3x3: bad mode %d", mode);
+    const bool presplit = mode == WSU_MODE_BF16X3S;             // split-bf16 arithmetic on activations stored already split
+    if (presplit) mode = WSU_MODE_BF16X3;
+    WSU_REQUIRE(!presplit || (!pool_idx && !relu_mask && !relu_mask2 && !y2 && !pad_zero),
+                "conv3x3: mode BF16X3S is a forward inference format (no pool_idx, ReLU masks, split outputs or zero padding)");
     const int ck = wsu_chunk_channels(mode);
     WSU_REQUIRE((x1 || first_img) && w_packed && (y || head_w), "conv3x3: null pointer");
     WSU_REQUIRE(!first_img || (first_w && !x1 && !x2 && c1 == 64 && c2 == 0 && !pad_zero && !relu_mask),
@@ -1346,12 +1405,13 @@ static int conv3x3_launch_full(const void* x1, const void* x2, const void* w_pac
     a.relu = relu; a.pad_zero = pad_zero;
     a.head_w = head_w; a.head_b = head_b; a.head_out = head_out; a.head_logit = head_logit; a.head_cout = head_cout;
     a.img = first_img; a.w1 = first_w; a.b1 = first_b;
+    a.out_split = presplit;
     static int ablate = -1;
     if (ablate < 0) { const char* e = getenv("WSU_CONV_ABLATE"); ablate = e ? atoi(e) : 0; }
     a.ablate = ablate;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (mode == WSU_MODE_F32) return launch_conv<WSU_MODE_F32>(a, s);
-    if (mode == WSU_MODE_BF16X3) return launch_conv<WSU_MODE_BF16X3>(a, s);
+    if (mode == WSU_MODE_BF16X3) return launch_conv<WSU_MODE_BF16X3>(a, s, presplit && !first_img);
     return launch_conv<WSU_MODE_BF16>(a, s);
 }
 

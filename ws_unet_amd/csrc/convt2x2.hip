@@ -23,10 +23,11 @@ constexpr int W_VEC = LDS_W / 16 / NT;                   // 4
 struct CtArgs {
     const char* x; const char* wp; const float* bias; char* y;
     int n, h, w, cin, cout, tiles_x, tiles_y, ncb, nch;
+    int out_split;                   // API mode WSU_MODE_BF16X3S: write the output already split (the input side is the template flag PS)
 };
 
 
-template <int MODE>
+template <int MODE, bool PS = false>
 __device__ __forceinline__ void ct_load(const CtArgs& a, int cb, int c, int tid, bool has_item, const char* xsrc,
                                         u32x4 (&st_in)[2], u32x4 (&st_w)[W_VEC]) {
     constexpr int ESZ = (MODE == WSU_MODE_BF16) ? 2 : 4;
@@ -35,17 +36,17 @@ __device__ __forceinline__ void ct_load(const CtArgs& a, int cb, int c, int tid,
     if (has_item) {
         const u32x4* g = reinterpret_cast<const u32x4*>(xsrc + (size_t)c * CK * ESZ);
         st_in[0] = g[0];
-        if constexpr (MODE == WSU_MODE_BF16X3) st_in[1] = g[1];
+        if constexpr (MODE == WSU_MODE_BF16X3 && !PS) st_in[1] = g[1];
     }
     const u32x4* wsrc = reinterpret_cast<const u32x4*>(a.wp + ((size_t)cb * a.nch + c) * LDS_W);
     WSU_STATIC_FOR(W_VEC, k, st_w[k] = wsrc[tid + k * NT];);
 }
 
-template <int MODE>
+template <int MODE, bool PS = false>
 __device__ __forceinline__ void ct_commit(char* smem, int tid, bool has_item, int ldsoff,
                                           const u32x4 (&st_in)[2], const u32x4 (&st_w)[W_VEC]) {
     if (has_item) {
-        if constexpr (MODE == WSU_MODE_BF16X3) {
+        if constexpr (MODE == WSU_MODE_BF16X3 && !PS) {
             u32x4 hi, lo;
             wsu_split8(__builtin_bit_cast(f32x4, st_in[0]), __builtin_bit_cast(f32x4, st_in[1]), hi, lo);
             *reinterpret_cast<u32x4*>(smem + ldsoff) = hi;
@@ -58,7 +59,7 @@ __device__ __forceinline__ void ct_commit(char* smem, int tid, bool has_item, in
     WSU_STATIC_FOR(W_VEC, k, wdst[tid + k * NT] = st_w[k];);
 }
 
-template <int MODE>
+template <int MODE, bool PS = false>
 __global__ __launch_bounds__(NT, 2) void convt2x2_kernel(const CtArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int ESZ = (MODE == WSU_MODE_BF16) ? 2 : 4;
@@ -75,9 +76,10 @@ __global__ __launch_bounds__(NT, 2) void convt2x2_kernel(const CtArgs a) {
     const int y0 = ty * TH, x0 = tx * TW;
 
     // staging plan: F32/BF16: 256 items (pixel, granule); BF16X3: 128 items (pixel, half) of 32 B
-    constexpr int NITEMS = (MODE == WSU_MODE_BF16X3) ? NPIX * 2 : NPIX * 4;
-    const int pix = (MODE == WSU_MODE_BF16X3) ? (tid >> 1) : (tid >> 2);
-    const int sub = (MODE == WSU_MODE_BF16X3) ? (tid & 1) : (tid & 3);
+    constexpr bool SPLIT_HERE = MODE == WSU_MODE_BF16X3 && !PS;       // PS: pre-split input, 4 granule items per pixel like F32 / BF16
+    constexpr int NITEMS = SPLIT_HERE ? NPIX * 2 : NPIX * 4;
+    const int pix = SPLIT_HERE ? (tid >> 1) : (tid >> 2);
+    const int sub = SPLIT_HERE ? (tid & 1) : (tid & 3);
     const int pr = (pix / TW) % TH, pc = pix % TW;
     const int yy = min(y0 + pr, a.h - 1), xx = min(x0 + pc, a.w - 1);   // clamp: out-of-image lanes are never stored
     const size_t pidx = (size_t)(n * a.h + yy) * a.w + xx;
@@ -85,7 +87,7 @@ __global__ __launch_bounds__(NT, 2) void convt2x2_kernel(const CtArgs a) {
     const int ldsoff = sub * PLANE_IN + (pix % NPIX) * 16;
 
     u32x4 st_in[2]; u32x4 st_w[W_VEC];
-    const char* xsrc = a.x + pidx * a.cin * ESZ + sub * ((MODE == WSU_MODE_BF16X3) ? 32 : 16);
+    const char* xsrc = a.x + pidx * a.cin * ESZ + sub * (SPLIT_HERE ? 32 : 16);
 
     const int wv = tid >> 6, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;   // wave = sub-position a*2+b
     f32x16 acc[2][2];
@@ -98,12 +100,12 @@ __global__ __launch_bounds__(NT, 2) void convt2x2_kernel(const CtArgs a) {
     const char* ldsA = smem + LDS_IN + ((wv * WSU_GRAN) * 64 + l31) * 16;      // + (g*64 + m*32)*16
     const char* ldsB = smem + l31 * 16;                                         // + g*PLANE_IN + q*32*16
 
-    ct_load<MODE>(a, cb, 0, tid, has_item, xsrc, st_in, st_w);
+    ct_load<MODE, PS>(a, cb, 0, tid, has_item, xsrc, st_in, st_w);
     for (int c = 0; c < a.nch; ++c) {
         __syncthreads();
-        ct_commit<MODE>(smem, tid, has_item, ldsoff, st_in, st_w);
+        ct_commit<MODE, PS>(smem, tid, has_item, ldsoff, st_in, st_w);
         __syncthreads();
-        if (c + 1 < a.nch) ct_load<MODE>(a, cb, c + 1, tid, has_item, xsrc, st_in, st_w);
+        if (c + 1 < a.nch) ct_load<MODE, PS>(a, cb, c + 1, tid, has_item, xsrc, st_in, st_w);
         if constexpr (MODE == WSU_MODE_BF16X3) {
             u32x4 ahi[2], alo[2], bhi[2], blo[2];
 #pragma unroll
@@ -163,6 +165,22 @@ __global__ __launch_bounds__(NT, 2) void convt2x2_kernel(const CtArgs a) {
     }
     __syncthreads();
     const int oh = 2 * a.h, ow = 2 * a.w;
+    if (MODE == WSU_MODE_BF16X3 && a.out_split) {
+        for (int i = tid; i < 4 * NPIX * 8; i += NT) {            // one item = 8 channels of one output pixel: hi piece + lo piece
+            const int opx = i >> 3, g8 = i & 7;
+            const int r = opx / (2 * TW), c = opx % (2 * TW);
+            const int oy = 2 * y0 + r, ox = 2 * x0 + c;
+            if (oy < oh && ox < ow) {
+                const float* row = reinterpret_cast<const float*>(smem + opx * STRIDE) + 8 * g8;
+                u32x4 hi, lo;
+                wsu_split8(*reinterpret_cast<const f32x4*>(row), *reinterpret_cast<const f32x4*>(row + 4), hi, lo);
+                char* dst = a.y + (((size_t)(n * oh + oy) * ow + ox) * a.cout + cb * WSU_COB) * 4 + (g8 >> 1) * 64 + (g8 & 1) * 16;
+                *reinterpret_cast<u32x4*>(dst) = hi;
+                *reinterpret_cast<u32x4*>(dst + 32) = lo;
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < 4 * NPIX * VPP / NT; ++k) {
         const int i = tid + k * NT;
@@ -176,21 +194,21 @@ __global__ __launch_bounds__(NT, 2) void convt2x2_kernel(const CtArgs a) {
     }
 }
 
-template <int MODE>
+template <int MODE, bool PS = false>
 int launch_ct(const CtArgs& a, hipStream_t s) {
     constexpr int ESZ = (MODE == WSU_MODE_BF16) ? 2 : 4;
     constexpr int EPI = 4 * NPIX * (WSU_COB * ESZ + 16);
     const int lds = EPI > LDS_MAIN ? EPI : LDS_MAIN;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&convt2x2_kernel<MODE>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&convt2x2_kernel<MODE, PS>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) { wsu_set_error("hipFuncSetAttribute(convt2x2): %s", hipGetErrorString(e)); return WSU_ERR_HIP; }
         attr_done = true;
     }
     const long long nblk = (long long)a.n * a.tiles_x * a.tiles_y * a.ncb;
     if (nblk <= 0 || nblk > 0x7FFFFFFFLL) { wsu_set_error("convt2x2: grid of %lld workgroups out of range", nblk); return WSU_ERR_ARG; }
-    hipLaunchKernelGGL(convt2x2_kernel<MODE>, dim3((unsigned)nblk), dim3(NT), lds, s, a);
+    hipLaunchKernelGGL((convt2x2_kernel<MODE, PS>), dim3((unsigned)nblk), dim3(NT), lds, s, a);
     return wsu_check_launch("convt2x2_kernel");
 }
 
@@ -245,7 +263,9 @@ int wsu_convt2x2_pack(const float* w_iohw, void* w_packed, int cin, int cout, in
 
 int wsu_convt2x2_fwd(const void* x, const void* w_packed, const float* bias, void* y,
                      int n, int h, int w, int cin, int cout, int mode, void* stream) {
-    WSU_REQUIRE(mode >= 0 && mode <= 2, "convt2x2: bad mode %d", mode);
+    WSU_REQUIRE(mode >= 0 && mode <= 3, "convt2x2: bad mode %d", mode);
+    const bool presplit = mode == WSU_MODE_BF16X3S;             // input and output stored already split (see wsu.h)
+    if (presplit) mode = WSU_MODE_BF16X3;
     WSU_REQUIRE(x && w_packed && y, "convt2x2: null pointer");
     WSU_REQUIRE(n > 0 && h > 0 && w > 0, "convt2x2: bad shape n=%d h=%d w=%d", n, h, w);
     WSU_REQUIRE(cin > 0 && cin % wsu_chunk_channels(mode) == 0, "convt2x2: cin=%d not a multiple of %d", cin, wsu_chunk_channels(mode));
@@ -256,8 +276,10 @@ int wsu_convt2x2_fwd(const void* x, const void* w_packed, const float* bias, voi
     a.n = n; a.h = h; a.w = w; a.cin = cin; a.cout = cout;
     a.tiles_x = (w + TW - 1) / TW; a.tiles_y = (h + TH - 1) / TH; a.ncb = cout / WSU_COB;
     a.nch = cin / wsu_chunk_channels(mode);
+    a.out_split = presplit;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (mode == WSU_MODE_F32) return launch_ct<WSU_MODE_F32>(a, s);
+    if (presplit) return launch_ct<WSU_MODE_BF16X3, true>(a, s);
     if (mode == WSU_MODE_BF16X3) return launch_ct<WSU_MODE_BF16X3>(a, s);
     return launch_ct<WSU_MODE_BF16>(a, s);
 }

@@ -12,6 +12,7 @@ Precision modes (``mode=`` or env ``WSU_MODE``):
   'f32'     exact fp32 MFMA                     -- parity anchor (also trains in exact fp32)
   'bf16x3'  split-bf16 MFMA, fp32 storage       -- default; meets the 1e-4 MAE gate (~2e-6)
   'bf16'    bf16 storage + MFMA                 -- fastest; MAE ~1e-3 on full-range weights
+  'bf16x3s' bf16x3 with producer-side split     -- bitwise the results of 'bf16x3'; activations stored as hi/lo halves
 """
 from __future__ import annotations
 
@@ -146,6 +147,9 @@ class UNet(nn.Module):
         t = keep if keep is not None else {}
         save = keep is not None
         e11 = self.e11
+        if m == ops.MODE_BF16X3S and (save or self.nsteps < 1 or not (self.fuse_first and self.fuse_head)
+                                     or e11.in_channels != 1 or e11.out_channels != 64 or self.outconv.out_channels > 4):
+            m = ops.MODE_BF16X3             # the pre-split format lives only between the fused first layer and the fused head
         # e11 is folded into e12's input staging unless its output is asked for (xe11 then never reaches HBM)
         fuse_first = self.fuse_first and not save and e11.in_channels == 1 and e11.out_channels == 64
         cur = None

@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import MODES, MODE_BF16, check
+from ._lib import MODES, MODE_BF16, MODE_BF16X3, MODE_BF16X3S, check
 
 
 def _stream() -> int:
@@ -66,7 +66,14 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
 
 
 def act_dtype(mode: int) -> torch.dtype:
+    """dtype of an activation tensor's allocation.  'bf16x3s' tensors are float32-shaped (4 bytes per element) but hold bf16 hi / lo
+    halves in the layout of include/wsu.h: only libwsu kernels read them."""
     return torch.bfloat16 if mode == MODE_BF16 else torch.float32
+
+
+def weight_mode(mode: int) -> int:
+    """The packed weights of 'bf16x3s' are the 'bf16x3' ones."""
+    return MODE_BF16X3 if mode == MODE_BF16X3S else mode
 
 
 def _dev_check(*ts: Optional[torch.Tensor]) -> None:
@@ -96,6 +103,7 @@ def pack_conv3x3(w: torch.Tensor, mode: int, dgrad: bool = False) -> torch.Tenso
     _dev_check(w)
     assert w.dtype == torch.float32 and w.dim() == 4 and w.shape[2:] == (3, 3)
     cout, cin = w.shape[:2]
+    mode = weight_mode(mode)
     out = torch.empty(lib.wsu_conv3x3_packed_bytes(cin, cout, mode), dtype=torch.uint8, device=w.device)
     fn = lib.wsu_conv3x3_pack_dgrad if dgrad else lib.wsu_conv3x3_pack
     check(fn(w.data_ptr(), out.data_ptr(), cin, cout, mode, _stream()), "wsu_conv3x3_pack")
@@ -109,6 +117,7 @@ def pack_convt2x2(w: torch.Tensor, mode: int) -> torch.Tensor:
     _dev_check(w)
     assert w.dtype == torch.float32 and w.dim() == 4 and w.shape[2:] == (2, 2)
     cin, cout = w.shape[:2]
+    mode = weight_mode(mode)
     out = torch.empty(lib.wsu_convt2x2_packed_bytes(cin, cout, mode), dtype=torch.uint8, device=w.device)
     check(lib.wsu_convt2x2_pack(w.data_ptr(), out.data_ptr(), cin, cout, mode, _stream()), "wsu_convt2x2_pack")
     return out
