@@ -105,7 +105,7 @@ def pmc_traffic(args, algorithmic_bytes_per_launch):
     wrap it), so the number comes from the committed summary of two `rocprofv3 --pmc` passes of THIS command (FETCH_SIZE and
     WRITE_SIZE separately, FETCH_SIZE doubled on gfx950; tools/pmc_traffic.py), and only when workload and mode match."""
     out = {"traffic": None, "algorithmic_bytes_per_launch": algorithmic_bytes_per_launch}
-    if (args.mode, args.batch, args.size) != ("bf16x3", 32, 512):
+    if (args.batch, args.size) != (32, 512):
         return out
     here = os.path.dirname(os.path.abspath(__file__))
     cands = sorted(glob.glob(os.path.join(here, "profiles", "r*", "pmc_conv3x3_traffic.json")))
@@ -113,6 +113,8 @@ def pmc_traffic(args, algorithmic_bytes_per_launch):
         return out
     with open(cands[-1]) as f:
         pmc = json.load(f)
+    if pmc.get("mode", "bf16x3") != args.mode:
+        return out
     out["traffic"] = pmc["traffic_bytes_per_launch"]
     out["traffic_unit"] = "HBM bytes per launch (PMC: 2 x FETCH_SIZE + WRITE_SIZE)"
     out["traffic_source"] = os.path.relpath(cands[-1], here)
@@ -124,7 +126,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--mode", default=os.environ.get("WSU_BENCH_MODE", "bf16x3"), choices=["bf16x3", "bf16x3s", "bf16", "f32"])
+    ap.add_argument("--mode", default=os.environ.get("WSU_BENCH_MODE", "bf16x3s"), choices=["bf16x3", "bf16x3s", "bf16", "f32"])
     ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -192,7 +194,7 @@ def main():
     # other precision modes, same run, fewer steps (rank 0 only, N = 1 only)
     if rank == 0 and world == 1 and not args.no_other_modes:
         other = {}
-        for md in [m for m in ("bf16", "f32", "bf16x3") if m != args.mode]:
+        for md in [m for m in ("bf16", "f32", "bf16x3", "bf16x3s") if m != args.mode]:
             mm = build_model(md, dev)
             st = max(2, args.steps // 3)
             d2, y2 = timed_steps(mm, x, st, 1, False)

@@ -10,9 +10,10 @@ CPU / eager fallback: calling the model with CPU tensors raises.
 
 Precision modes (``mode=`` or env ``WSU_MODE``):
   'f32'     exact fp32 MFMA                     -- parity anchor (also trains in exact fp32)
-  'bf16x3'  split-bf16 MFMA, fp32 storage       -- default; meets the 1e-4 MAE gate (~2e-6)
+  'bf16x3'  split-bf16 MFMA, fp32 storage       -- meets the 1e-4 MAE gate (~2e-6)
   'bf16'    bf16 storage + MFMA                 -- fastest; MAE ~1e-3 on full-range weights
-  'bf16x3s' bf16x3 with producer-side split     -- bitwise the results of 'bf16x3'; activations stored as hi/lo halves
+  'bf16x3s' bf16x3 with producer-side split     -- default; bitwise the results of 'bf16x3', activations stored as hi/lo halves
+                                                   between the fused first layer and the fused head (keep= / autograd use 'bf16x3')
 """
 from __future__ import annotations
 
@@ -75,7 +76,7 @@ class UNet(nn.Module):
         if nsteps > 4:
             raise NotImplementedError("the reference defines at most 4 pooling steps (unet.py:85-132)")
         self.nsteps = nsteps
-        self.mode = mode or os.environ.get("WSU_MODE", "bf16x3")
+        self.mode = mode or os.environ.get("WSU_MODE", "bf16x3s")
         self.fuse_head = os.environ.get("WSU_FUSE_HEAD", "1") != "0"  # fold outconv + sigmoid into the last 3x3 conv
         self.fuse_first = os.environ.get("WSU_FUSE_FIRST", "1") != "0"  # fold e11 into e12's input staging
         # arithmetic of the autograd path: exact fp32 MFMA for an 'f32' model, split-bf16 (fp32 storage and accumulation,
