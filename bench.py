@@ -32,7 +32,7 @@ sys.path.insert(0, str(ROOT))
 import numpy as np
 import torch
 
-PEAK = {"bf16x3": 2.5e15, "bf16x3s": 2.5e15, "bf16": 2.5e15, "f32": 157.3e12}     # dense MFMA peaks, MI355X_MICROARCH.md
+PEAK = {"bf16x3": 2.5e15, "bf16x3s": 2.5e15, "f16f8": 2.5e15, "bf16": 2.5e15, "f32": 157.3e12}     # dense MFMA peaks, MI355X_MICROARCH.md
 HBM_PEAK = 8.0e12
 
 
@@ -126,7 +126,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--mode", default=os.environ.get("WSU_BENCH_MODE", "bf16x3s"), choices=["bf16x3", "bf16x3s", "bf16", "f32"])
+    ap.add_argument("--mode", default=os.environ.get("WSU_BENCH_MODE", "bf16x3s"), choices=["bf16x3", "bf16x3s", "f16f8", "bf16", "f32"])
     ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -182,6 +182,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"bf16x3": "bf16x3 (bf16 MFMA on split fp32 operands, fp32 accumulate)",
                       "bf16x3s": "bf16x3 (bf16 MFMA on split fp32 operands, fp32 accumulate; activations stored as their hi/lo halves)",
+                      "f16f8": "f16f8 (f16 MFMA on the f16 halves + block-scaled fp8 MFMA on the residual cross terms, fp32 accumulate)",
                       "bf16": "bf16", "f32": "f32"}[args.mode],
             "data": "synthetic",
             "config": {"workload": f"unet_2 forward-only predict, batch={args.batch}/GPU synthetic {args.size}x{args.size}x1 "
@@ -194,7 +195,7 @@ def main():
     # other precision modes, same run, fewer steps (rank 0 only, N = 1 only)
     if rank == 0 and world == 1 and not args.no_other_modes:
         other = {}
-        for md in [m for m in ("bf16", "f32", "bf16x3", "bf16x3s") if m != args.mode]:
+        for md in [m for m in ("bf16", "f32", "bf16x3", "bf16x3s", "f16f8") if m != args.mode]:
             mm = build_model(md, dev)
             st = max(2, args.steps // 3)
             d2, y2 = timed_steps(mm, x, st, 1, False)

@@ -28,6 +28,14 @@
  *                           their fp32 allocation).  Staging becomes a plain copy; results are bitwise those of BF16X3.  Forward
  *                           entry points only (wsu_conv3x3_fwd / _head_fwd / _fused_first_fwd, wsu_convt2x2_fwd); weights are packed
  *                           as for BF16X3; no pool_idx, no zero padding.
+ *      WSU_MODE_F16F8 = 4   two-level split on the f16 and block-scaled fp8 matrix pipes (forward inference format like BF16X3S):
+ *                           w*x ~ f16(w)*f16(x) + e4m3(w)*e4m3(x - f16(x)) + e4m3(w - f16(w))*e4m3(x), fp32 accumulate.  The first
+ *                           product is exact (v_mfma_f32_32x32x16_f16), the two cross terms share one
+ *                           v_mfma_scale_f32_32x32x64_f8f6f4 (2x the bf16 rate; its two 32-element scale blocks carry 2^-12-sized
+ *                           residuals at full e4m3 precision): ~2^-15 relative error per product at 2/3 of BF16X3's matrix cycles.
+ *                           Activations per pixel and 16-channel chunk: [f16 ch 0-7][f16 ch 8-15][e4m3((x - f16 x) * 2^12) ch 0-15]
+ *                           [e4m3(x / 4) ch 0-15] (4 x 16 B = the fp32 chunk size); weights packed by the pack entry points with
+ *                           this mode.  Values beyond +-448 lose the residual term (plain f16 accuracy), beyond +-65504 saturate.
  */
 #ifndef WSU_H
 #define WSU_H
@@ -41,7 +49,7 @@ extern "C" {
 
 #define WSU_VERSION 100
 
-enum { WSU_MODE_F32 = 0, WSU_MODE_BF16X3 = 1, WSU_MODE_BF16 = 2, WSU_MODE_BF16X3S = 3 };
+enum { WSU_MODE_F32 = 0, WSU_MODE_BF16X3 = 1, WSU_MODE_BF16 = 2, WSU_MODE_BF16X3S = 3, WSU_MODE_F16F8 = 4 };
 
 enum {
     WSU_OK = 0,

@@ -1,0 +1,111 @@
+"""GPU tests of mode 'f16f8' (f16 products + block-scaled fp8 cross terms, include/wsu.h): storage format, kernel chain and whole
+networks against the split-bf16 path, the exact fp32 mode and the CPU oracle.  Tolerances: the mode carries ~2^-15 relative error per
+product (bf16x3: ~2^-17); whole-network outputs stay 20x inside the 1e-4 MAE gate of BASELINE.json."""
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import DEV, images01, gpu_model, oracle_forward, unsplit_f16f8
+from ws_unet_amd import formula, ops
+
+pytestmark = pytest.mark.gpu
+X3, F8 = ops.mode_id("bf16x3"), ops.mode_id("f16f8")
+
+
+def _w(key, shape, scale):
+    return torch.from_numpy(formula.formula_tensor(key, shape, scale)).to(DEV)
+
+
+@pytest.mark.parametrize("hw", [(16, 32), (24, 40), (8, 8), (36, 70)])
+def test_kernel_chain_against_split_bf16(hw):
+    """fused first layer -> conv (+pool) -> conv -> transposed conv -> concat conv -> conv + head: every intermediate decodes (f16 part +
+    residual) to the fp32-storage tensor of the bf16x3 chain within the mode's error, its e4m3 copy within e4m3's 2^-4, and the head
+    output agrees to 1e-5."""
+    h, w = hw
+    x = images01(2, h, w, seed=3)[1].to(DEV)
+    w1, b1 = _w(f"ps/w1/{hw}", (64, 1, 3, 3), 0.5), _w(f"ps/b1/{hw}", (64,), 0.1)
+    w2, b2 = _w(f"ps/w2/{hw}", (64, 64, 3, 3), 0.06), _w(f"ps/b2/{hw}", (64,), 0.1)
+    w3, b3 = _w(f"ps/w3/{hw}", (128, 64, 3, 3), 0.06), _w(f"ps/b3/{hw}", (128,), 0.1)
+    wu, bu = _w(f"ps/wu/{hw}", (128, 64, 2, 2), 0.09), _w(f"ps/bu/{hw}", (64,), 0.1)
+    w4, b4 = _w(f"ps/w4/{hw}", (64, 128, 3, 3), 0.04), _w(f"ps/b4/{hw}", (64,), 0.1)
+    w5, b5 = _w(f"ps/w5/{hw}", (64, 64, 3, 3), 0.06), _w(f"ps/b5/{hw}", (64,), 0.1)
+    hw_, hb = _w(f"ps/hw/{hw}", (1, 64, 1, 1), 0.3), _w(f"ps/hb/{hw}", (1,), 0.1)
+    outs = {}
+    for m in (X3, F8):
+        y12, yp = ops.conv3x3_fused_first(x, w1, b1, ops.pack_conv3x3(w2, ops.first_layer_weight_mode(m)), b2, 64, m, pool=True)
+        y21 = ops.conv3x3(yp, None, ops.pack_conv3x3(w3, m), b3, 128, m)
+        yu = ops.convt2x2(y21, ops.pack_convt2x2(wu, m), bu, 64, m)
+        yd = ops.conv3x3(yu, y12, ops.pack_conv3x3(w4, m), b4, 64, m)
+        out, logit = ops.conv3x3_head(yd, None, ops.pack_conv3x3(w5, m), b5, hw_, hb, m, want_logit=True)
+        outs[m] = (y12, yp, y21, yu, yd, out, logit)
+    for a, b in zip(outs[X3][:5], outs[F8][:5]):
+        ref = a.cpu()
+        got, x8 = unsplit_f16f8(b)
+        scale = max(ref.abs().max().item(), 1e-30)
+        assert (got - ref).abs().max().item() <= 2e-4 * scale
+        # the e4m3 copy of every value: 4 significant bits (normal range), absolute 2^-10 * 4 below it
+        assert ((x8 - ref).abs() <= ref.abs() * 2.0 ** -4 + 2.0 ** -8 + 2e-4 * scale).all()
+    assert (outs[X3][5] - outs[F8][5]).abs().max().item() <= 1e-5
+    assert (outs[X3][6] - outs[F8][6]).abs().max().item() <= 1e-4 * max(outs[X3][6].abs().max().item(), 1.0)
+    with pytest.raises(Exception, match="F16F8"):
+        ops.conv3x3(outs[F8][0], None, ops.pack_conv3x3(w2, F8), b2, 64, F8, pool=True, pool_idx=True)
+
+
+def test_stored_halves_are_the_documented_encoding():
+    """hi = f16 round-to-nearest of the value, residual = e4m3 of (value - hi) * 2^12: re-deriving them from the decoded value
+    reproduces what the kernel stored (checked on the fused first layer's output, whose fp32 values the bf16x3 path also has)."""
+    x = images01(1, 16, 32, seed=5)[1].to(DEV)
+    w1, b1 = _w("enc/w1", (64, 1, 3, 3), 0.5), _w("enc/b1", (64,), 0.1)
+    w2, b2 = _w("enc/w2", (64, 64, 3, 3), 0.06), _w("enc/b2", (64,), 0.1)
+    y = ops.conv3x3_fused_first(x, w1, b1, ops.pack_conv3x3(w2, ops.first_layer_weight_mode(F8)), b2, 64, F8)
+    yref = ops.conv3x3_fused_first(x, w1, b1, ops.pack_conv3x3(w2, X3), b2, 64, X3).cpu()
+    raw = y.cpu().numpy().view(np.uint8).reshape(1, 16, 32, 4, 64)
+    hi = raw[..., :32].copy().view(np.float16).astype(np.float32).reshape(1, 16, 32, 64)
+    # the first layer of an f16f8 network runs the bf16x3 arithmetic and only stores in the f16f8 format: hi is exactly f16(value)
+    assert np.array_equal(hi, yref.numpy().astype(np.float16).astype(np.float32))
+    got, _ = unsplit_f16f8(y)
+    assert (got - yref).abs().max().item() <= 2.0 ** -15 * yref.abs().max().item()
+
+
+@pytest.mark.parametrize("ns", [1, 2, 3])
+def test_whole_network(ns):
+    _, x = images01(2, 64, 64, seed=13)
+    m = gpu_model(ns, "he", "f16f8")
+    with torch.no_grad():
+        y = m(x.to(DEV))
+        y32 = gpu_model(ns, "he", "f32")(x.to(DEV))
+        keep = {}
+        y3 = m.forward_features(x.to(DEV), keep=keep)              # keep= runs the bf16x3 path in fp32 storage
+    d = (y - y32).abs()
+    assert d.mean().item() <= 2e-5 and d.max().item() <= 1.5e-4      # measured 4e-6 / 4e-5 (unet_2), 9e-6 / 5.4e-5 (unet_3)
+    assert "xe11" in keep and (y3 - y32).abs().max().item() <= 4e-5
+    assert (y.cpu() - oracle_forward(x, ns)).abs().mean().item() <= 2e-5
+    assert m.train_mode == "bf16x3"                                 # training is unaffected (fp32 storage)
+
+
+def test_f16f8_512(golden):
+    g = golden["unet_fwd_512"]
+    _, x = images01(1, 512, 512, seed=7)
+    with torch.no_grad():
+        y = gpu_model(2, "he", "f16f8")(x.to(DEV))
+    crop = y[0, 0].cpu().numpy()[224:288, 224:288]
+    d = np.abs(crop - g["f512_he_crop"])
+    assert d.mean() <= 2e-5 and d.max() <= 1.5e-4
+
+
+def test_large_values_degrade_gracefully():
+    """Activations beyond e4m3's scaled range (|x| > 448) lose only the residual term: the result keeps plain-f16 accuracy (2^-11
+    relative) instead of overflowing to NaN."""
+    h, w = 16, 32
+    x = (images01(1, h, w, seed=2)[1] * 3000.0).to(DEV)           # first-layer outputs in the thousands
+    w1, b1 = _w("big/w1", (64, 1, 3, 3), 0.5), _w("big/b1", (64,), 0.1)
+    w2, b2 = _w("big/w2", (64, 64, 3, 3), 0.06), _w("big/b2", (64,), 0.1)
+    w3, b3 = _w("big/w3", (64, 64, 3, 3), 0.06), _w("big/b3", (64,), 0.1)
+    res = {}
+    for m in (X3, F8):
+        y = ops.conv3x3_fused_first(x, w1, b1, ops.pack_conv3x3(w2, ops.first_layer_weight_mode(m)), b2, 64, m)
+        res[m] = ops.conv3x3(y, None, ops.pack_conv3x3(w3, m), b3, 64, m)
+    ref = res[X3].cpu()
+    got, _ = unsplit_f16f8(res[F8])
+    assert torch.isfinite(got).all()
+    assert (got - ref).abs().max().item() <= 2.0 ** -9 * ref.abs().max().item()

@@ -74,7 +74,8 @@ struct ConvArgs {
     // (img: (N,1,H,W) fp32, w1: (64,1,3,3), b1: (64) or null); x1 is then null
     const float* img; const float* w1; const float* b1;
     // API mode WSU_MODE_BF16X3S: activations stored already split (per pixel and 16-channel chunk: hi 0-7 | hi 8-15 | lo 0-7 | lo 8-15,
-    // 4 x 16 B = the fp32 chunk size).  The input side is the template flag PS (staging becomes a plain copy), the output side this flag.
+    // 4 x 16 B = the fp32 chunk size).  The input side is the template flag PS (staging becomes a plain copy), the output side this flag
+    // (1; 2 = store in the F16F8 format from a BF16X3 kernel: the fused first layer of an F16F8 network).
     int out_split;
 };
 
@@ -212,6 +213,50 @@ __device__ __forceinline__ void stage_commit(char* smem, int tid, const int (&pi
         if (W_ITEMS % NT == 0 || tid + k * NT < W_ITEMS) wdst[tid + k * NT] = st_w[k];
 }
 
+// F16F8 stores from the fp32 [pixel][channel] LDS tile: one item = one pixel x one 16-channel chunk = 4 x 16 B
+// (f16 0-7 | f16 8-15 | residuals | e4m3 copies), full-resolution output and / or the fused 2x2 max-pool.
+template <int NT, int TH, int STRIDE>
+__device__ __forceinline__ void store_f16f8(const ConvArgs& a, const char* smem, int tid, int n, int y0, int x0, int cglob, char* ydst, int ych, int ycoff) {
+        if (ydst)
+            for (int i = tid; i < TH * TW * 4; i += NT) {
+                const int px = i >> 2, j = i & 3;
+                const int r = px / TW, c = px % TW;
+                if (y0 + r < a.h && x0 + c < a.w) {
+                    const f32x4* row = reinterpret_cast<const f32x4*>(smem + px * STRIDE + j * 64);
+                    u32x4 hi0, hi1, lo8, x8;
+                    wsu_split16_f16f8(row[0], row[1], row[2], row[3], hi0, hi1, lo8, x8);
+                    u32x4* dst = reinterpret_cast<u32x4*>(ydst + (((size_t)(n * a.h + y0 + r) * a.w + x0 + c) * ych + ycoff) * 4 + j * 64);
+                    dst[0] = hi0; dst[1] = hi1; dst[2] = lo8; dst[3] = x8;
+                }
+            }
+        if (a.ypool) {
+            const int hp = a.h >> 1, wp2 = a.w >> 1;
+            for (int i = tid; i < (TH / 2) * (TW / 2) * 4; i += NT) {
+                const int pp = i >> 2, j = i & 3;
+                const int pr = pp / (TW / 2), pc = pp % (TW / 2);
+                const int gy = (y0 >> 1) + pr, gx = (x0 >> 1) + pc;
+                if (gy < hp && gx < wp2) {
+                    const f32x4* b0 = reinterpret_cast<const f32x4*>(smem + ((2 * pr) * TW + 2 * pc) * STRIDE + j * 64);
+                    f32x4 m[4] = {b0[0], b0[1], b0[2], b0[3]};
+#pragma unroll
+                    for (int wdx = 1; wdx < 4; ++wdx) {                    // window order of the fp32 path (first max wins; NaN propagates)
+                        const f32x4* bq = reinterpret_cast<const f32x4*>(smem + ((2 * pr + (wdx >> 1)) * TW + 2 * pc + (wdx & 1)) * STRIDE + j * 64);
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) {
+                            const f32x4 q = bq[v];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) if (q[e] > m[v][e] || q[e] != q[e]) m[v][e] = q[e];
+                        }
+                    }
+                    u32x4 hi0, hi1, lo8, x8;
+                    wsu_split16_f16f8(m[0], m[1], m[2], m[3], hi0, hi1, lo8, x8);
+                    u32x4* dst = reinterpret_cast<u32x4*>(a.ypool + (((size_t)(n * hp + gy) * wp2 + gx) * a.cout + cglob) * 4 + j * 64);
+                    dst[0] = hi0; dst[1] = hi1; dst[2] = lo8; dst[3] = x8;
+                }
+            }
+        }
+}
+
 // Everything behind the [pixel][channel] LDS tile (TH x 32 pixels, Epi<MODE>::STRIDE bytes per pixel): fused 1x1 head, coalesced
 // NHWC stores with the optional ReLU mask, fused 2x2 max-pool with first-max-wins argmax.  Shared by the direct and the Winograd kernel.
 template <int MODE, int NT, int TH>
@@ -257,7 +302,9 @@ __device__ __forceinline__ void tile_epilogue(const ConvArgs& a, char* smem, int
                 }
         }
     }
+    if constexpr (MODE == WSU_MODE_F16F8) { store_f16f8<NT, TH, STRIDE>(a, smem, tid, n, y0, x0, cglob, ydst, ych, ycoff); return; }
     if constexpr (MODE == WSU_MODE_BF16X3) {
+        if (a.out_split == 2) { store_f16f8<NT, TH, STRIDE>(a, smem, tid, n, y0, x0, cglob, ydst, ych, ycoff); return; }   // first layer of an F16F8 network
         if (a.out_split) {
             // ---- pre-split stores (mode BF16X3S): per pixel and 16-channel chunk  hi 0-7 | hi 8-15 | lo 0-7 | lo 8-15; one item = 8 channels
             if (ydst)
@@ -408,6 +455,7 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 4 : 2) void conv3x3_kernel(const
     int pixidx[IN_VEC];      // linear pixel index (n*H + y)*W + x of the source, -1 = zero, -2 = no item
     int ldsoff[IN_VEC];
     constexpr bool SPLIT_HERE = MODE == WSU_MODE_BF16X3 && !PS;     // F1 computes its input and always splits here
+    static_assert(MODE != WSU_MODE_F16F8 || (PS && !F1 && NW == 8 && !S16), "F16F8: stored-split input, 8-wave shape (its first layer runs BF16X3)");
     constexpr int NITEMS = SPLIT_HERE ? NPIX_IN * 2 : NPIX_IN * 4;
     constexpr int NLOOP = SPLIT_HERE ? Shape<NW>::IN_VEC3 : IN_VEC;
 #pragma unroll
@@ -538,6 +586,40 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 4 : 2) void conv3x3_kernel(const
                 type2(std::integral_constant<int, 2 * tp>{});
                 type1(std::integral_constant<int, 2 * tp>{});
                 if constexpr (2 * tp + 1 < 9) type1(std::integral_constant<int, 2 * tp + 1>{});
+            });
+        } else if constexpr (MODE == WSU_MODE_F16F8) {
+            // per tap: f16(w) * f16(x) on v_mfma_f32_32x32x16_f16; per PAIR of taps: both cross terms of both taps in one block-scaled
+            // fp8 instruction (block 0 = planes 2 of A and B, block 1 = planes 3; inside a block lanes 0-31 carry the 16 channels of the
+            // pair's first tap and lanes 32-63 those of its second).  Tap 8 has no partner: its upper lanes pass zeros.
+            const int sc_a = hh ? WSU_F8_SCALE_WLO : WSU_F8_SCALE_W, sc_b = hh ? WSU_F8_SCALE_X : WSU_F8_SCALE_XLO;
+            WSU_STATIC_FOR(5, tp, {
+                constexpr int t0 = 2 * tp, t1 = (2 * tp + 1 < 9) ? 2 * tp + 1 : 2 * tp;
+                constexpr bool single = 2 * tp + 1 >= 9;
+                {
+                    const int aoff = ((hh ? t1 : t0) * 4 + 2) * 64 * 16;
+                    const int boff = 2 * PLANE_IN + (hh ? ((t1 / 3) * IW + t1 % 3) : ((t0 / 3) * IW + t0 % 3)) * 16;
+                    u32x4 a0 = *reinterpret_cast<const u32x4*>(ldsA + aoff), a1 = *reinterpret_cast<const u32x4*>(ldsA + aoff + 64 * 16);
+                    u32x4 b0[2], b1[2];
+_Pragma("unroll")
+                    for (int q = 0; q < 2; ++q) {
+                        b0[q] = *reinterpret_cast<const u32x4*>(ldsB + boff + q * IW * 16);
+                        b1[q] = *reinterpret_cast<const u32x4*>(ldsB + boff + PLANE_IN + q * IW * 16);
+                    }
+                    if (single && hh) { a0 = mk_u4(0, 0, 0, 0); a1 = a0; b0[0] = a0; b0[1] = a0; b1[0] = a0; b1[1] = a0; }
+_Pragma("unroll")
+                    for (int q = 0; q < 2; ++q) wsu_mfma_f8x2(a0, a1, b0[q], b1[q], sc_a, sc_b, acc[0][q]);
+                }
+                __builtin_amdgcn_sched_barrier(0);          // keep the operand reads of later taps behind these instructions (128-VGPR budget)
+                WSU_STATIC_FOR(single ? 1 : 2, k, {
+                    constexpr int tap = t0 + k, dy = tap / 3, dx = tap % 3;
+                    const u32x4 ah = *reinterpret_cast<const u32x4*>(ldsA + ((tap * 4 + hh) * 64) * 16);
+                    u32x4 bh[2];
+_Pragma("unroll")
+                    for (int q = 0; q < 2; ++q) bh[q] = *reinterpret_cast<const u32x4*>(ldsB + hh * PLANE_IN + ((q + dy) * IW + dx) * 16);
+_Pragma("unroll")
+                    for (int q = 0; q < 2; ++q) wsu_mfma_f16(ah, bh[q], acc[0][q]);
+                });
+                __builtin_amdgcn_sched_barrier(0);
             });
         } else
         WSU_STATIC_FOR(9, tap, {
@@ -1259,6 +1341,9 @@ int launch_conv(const ConvArgs& a, hipStream_t s, bool in_split = false) {
     if constexpr (MODE == WSU_MODE_BF16X3) {
         if (in_split) return launch_conv_nw<MODE, 8, false, false, true>(a, s);      // pre-split input: the measured default shape only
     }
+    if constexpr (MODE == WSU_MODE_F16F8) {
+        return launch_conv_nw<MODE, 8, false, false, true>(a, s);
+    } else {
     // Default = the per-tile kernel (v1): measured faster (bench conv3x3 15.8 ms vs 17.9 ms per batch-32 forward in bf16x3).
     // WSU_CONV_IMPL=pp selects the ping-pong kernel (kept for the next tuning round; profiles/r01/conv3x3_ablation.md).
     if (a.img) {                                                // fused first layer: the measured default shape of each mode
@@ -1285,6 +1370,7 @@ int launch_conv(const ConvArgs& a, hipStream_t s, bool in_split = false) {
         if (s16) return nw == 4 ? launch_conv_nw<MODE, 4, true>(a, s) : launch_conv_nw<MODE, 8, true>(a, s);
     }
     return nw == 4 ? launch_conv_nw<MODE, 4>(a, s) : launch_conv_nw<MODE, 8>(a, s);
+    }
 }
 
 // ---- weight packing: OIHW fp32 -> [cob][chunk][tap][granule][co 64][16 B] -----------------------------
@@ -1325,15 +1411,40 @@ __global__ void pack_conv3x3_kernel(const float* __restrict__ w, char* __restric
     }
 }
 
+// F16F8: one thread per (cob, chunk, tap, co) row of 16 channels -> [f16 0-7][f16 8-15][e4m3(w * 2^6)][e4m3((w - f16 w) * 2^18)]
+__global__ void pack_conv3x3_f16f8_kernel(const float* __restrict__ w, char* __restrict__ dst, int cin, int cout) {
+    const int nch = cin / 16;
+    const long long total = (long long)(cout / WSU_COB) * nch * 9 * WSU_COB;
+    for (long long d = (long long)blockIdx.x * blockDim.x + threadIdx.x; d < total; d += (long long)gridDim.x * blockDim.x) {
+        long long t = d;
+        const int co = t % WSU_COB; t /= WSU_COB;
+        const int tap = t % 9; t /= 9;
+        const int c = t % nch; t /= nch;
+        const int cb = (int)t;
+        f32x4 q[4];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) q[e >> 2][e & 3] = w[(((size_t)(cb * WSU_COB + co)) * cin + c * 16 + e) * 9 + tap];
+        uint32_t h[8], l[4], x[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) wsu_split4_f16f8(q[k], WSU_F8_WLO_MUL, WSU_F8_W_MUL, h[2 * k], h[2 * k + 1], l[k], x[k]);
+        char* base = dst + (((size_t)cb * nch + c) * 9 + tap) * (WSU_GRAN * WSU_COB * 16) + co * 16;
+        *reinterpret_cast<u32x4*>(base) = mk_u4(h[0], h[1], h[2], h[3]);
+        *reinterpret_cast<u32x4*>(base + WSU_COB * 16) = mk_u4(h[4], h[5], h[6], h[7]);
+        *reinterpret_cast<u32x4*>(base + 2 * WSU_COB * 16) = mk_u4(x[0], x[1], x[2], x[3]);        // plane 2: e4m3(w), meets the residuals of x
+        *reinterpret_cast<u32x4*>(base + 3 * WSU_COB * 16) = mk_u4(l[0], l[1], l[2], l[3]);        // plane 3: residuals of w, meet e4m3(x)
+    }
+}
+
 int pack_impl(const float* w, void* dst, int cin, int cout, int mode, int tf, void* stream) {
     const int kin = tf ? cout : cin, mout = tf ? cin : cout;
     WSU_REQUIRE(w && dst, "conv3x3_pack: null pointer");
-    WSU_REQUIRE(mode >= 0 && mode <= 2, "conv3x3_pack: bad mode %d", mode);
+    WSU_REQUIRE((mode >= 0 && mode <= 2) || (mode == WSU_MODE_F16F8 && !tf), "conv3x3_pack: bad mode %d", mode);
     WSU_REQUIRE(kin > 0 && kin % wsu_chunk_channels(mode) == 0, "conv3x3_pack: reduction channels %d not a multiple of %d", kin, wsu_chunk_channels(mode));
     WSU_REQUIRE(mout > 0 && mout % WSU_COB == 0, "conv3x3_pack: output channels %d not a multiple of %d", mout, WSU_COB);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int blocks = 1024;
-    if (mode == WSU_MODE_F32) hipLaunchKernelGGL(pack_conv3x3_kernel<WSU_MODE_F32>, dim3(blocks), dim3(256), 0, s, w, (char*)dst, cin, cout, tf);
+    if (mode == WSU_MODE_F16F8) hipLaunchKernelGGL(pack_conv3x3_f16f8_kernel, dim3(blocks), dim3(256), 0, s, w, (char*)dst, cin, cout);
+    else if (mode == WSU_MODE_F32) hipLaunchKernelGGL(pack_conv3x3_kernel<WSU_MODE_F32>, dim3(blocks), dim3(256), 0, s, w, (char*)dst, cin, cout, tf);
     else if (mode == WSU_MODE_BF16X3) hipLaunchKernelGGL(pack_conv3x3_kernel<WSU_MODE_BF16X3>, dim3(blocks), dim3(256), 0, s, w, (char*)dst, cin, cout, tf);
     else hipLaunchKernelGGL(pack_conv3x3_kernel<WSU_MODE_BF16>, dim3(blocks), dim3(256), 0, s, w, (char*)dst, cin, cout, tf);
     return wsu_check_launch("pack_conv3x3_kernel");
@@ -1350,8 +1461,8 @@ int wsu_debug_read_stamps(unsigned long long* host_dst, int nblocks) {
 }
 
 size_t wsu_conv3x3_packed_bytes(int cin, int cout, int mode) {
-    if (cin <= 0 || cout <= 0 || mode < 0 || mode > 2) return 0;
-    const size_t per_elem = mode == WSU_MODE_BF16 ? 2 : 4;    // BF16X3 stores hi + lo bf16 = 4 bytes
+    if (cin <= 0 || cout <= 0 || mode < 0 || (mode > 2 && mode != WSU_MODE_F16F8)) return 0;
+    const size_t per_elem = mode == WSU_MODE_BF16 ? 2 : 4;    // BF16X3 stores hi + lo bf16, F16F8 f16 + two e4m3 = 4 bytes
     return (size_t)cin * cout * 9 * per_elem;
 }
 
@@ -1376,11 +1487,15 @@ static int conv3x3_launch_full(const void* x1, const void* x2, const void* w_pac
                           int n, int h, int w, int c1, int c2, int cout,
                           int mode, int relu, int pad_zero, void* stream,
                           const float* first_img = nullptr, const float* first_w = nullptr, const float* first_b = nullptr) {
-    WSU_REQUIRE(mode >= 0 && mode <= 3, "conv3x3: bad mode %d", mode);
+    WSU_REQUIRE(mode >= 0 && mode <= 4, "conv3x3: bad mode %d", mode);
     const bool presplit = mode == WSU_MODE_BF16X3S;             // split-bf16 arithmetic on activations stored already split
     if (presplit) mode = WSU_MODE_BF16X3;
-    WSU_REQUIRE(!presplit || (!pool_idx && !relu_mask && !relu_mask2 && !y2 && !pad_zero),
-                "conv3x3: mode BF16X3S is a forward inference format (no pool_idx, ReLU masks, split outputs or zero padding)");
+    // The fused first layer of an F16F8 network computes its 64 input channels while staging: that kernel is VALU-bound on the f16/e4m3
+    // encoding (measured 2.41 vs 2.04 ms), so it keeps the BF16X3 arithmetic (weights packed for BF16X3) and only STORES in the F16F8 format.
+    const bool first_f16f8 = mode == WSU_MODE_F16F8 && first_img;
+    if (first_f16f8) mode = WSU_MODE_BF16X3;
+    WSU_REQUIRE(!(presplit || first_f16f8 || mode == WSU_MODE_F16F8) || (!pool_idx && !relu_mask && !relu_mask2 && !y2 && !pad_zero),
+                "conv3x3: modes BF16X3S / F16F8 are forward inference formats (no pool_idx, ReLU masks, split outputs or zero padding)");
     const int ck = wsu_chunk_channels(mode);
     WSU_REQUIRE((x1 || first_img) && w_packed && (y || head_w), "conv3x3: null pointer");
     WSU_REQUIRE(!first_img || (first_w && !x1 && !x2 && c1 == 64 && c2 == 0 && !pad_zero && !relu_mask),
@@ -1405,13 +1520,14 @@ static int conv3x3_launch_full(const void* x1, const void* x2, const void* w_pac
     a.relu = relu; a.pad_zero = pad_zero;
     a.head_w = head_w; a.head_b = head_b; a.head_out = head_out; a.head_logit = head_logit; a.head_cout = head_cout;
     a.img = first_img; a.w1 = first_w; a.b1 = first_b;
-    a.out_split = presplit;
+    a.out_split = first_f16f8 ? 2 : presplit;
     static int ablate = -1;
     if (ablate < 0) { const char* e = getenv("WSU_CONV_ABLATE"); ablate = e ? atoi(e) : 0; }
     a.ablate = ablate;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (mode == WSU_MODE_F32) return launch_conv<WSU_MODE_F32>(a, s);
     if (mode == WSU_MODE_BF16X3) return launch_conv<WSU_MODE_BF16X3>(a, s, presplit && !first_img);
+    if (mode == WSU_MODE_F16F8) return launch_conv<WSU_MODE_F16F8>(a, s);
     return launch_conv<WSU_MODE_BF16>(a, s);
 }
 

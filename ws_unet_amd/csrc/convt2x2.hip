@@ -100,13 +100,49 @@ __global__ __launch_bounds__(NT, 2) void convt2x2_kernel(const CtArgs a) {
     const char* ldsA = smem + LDS_IN + ((wv * WSU_GRAN) * 64 + l31) * 16;      // + (g*64 + m*32)*16
     const char* ldsB = smem + l31 * 16;                                         // + g*PLANE_IN + q*32*16
 
+    u32x4 f8a0[2], f8a1[2], f8b0[2], f8b1[2];                 // F16F8: fp8 operands of this lane half's chunk, held across two chunks
+#pragma unroll
+    for (int m = 0; m < 2; ++m) { f8a0[m] = mk_u4(0, 0, 0, 0); f8a1[m] = f8a0[m]; f8b0[m] = f8a0[m]; f8b1[m] = f8a0[m]; }
     ct_load<MODE, PS>(a, cb, 0, tid, has_item, xsrc, st_in, st_w);
     for (int c = 0; c < a.nch; ++c) {
         __syncthreads();
         ct_commit<MODE, PS>(smem, tid, has_item, ldsoff, st_in, st_w);
         __syncthreads();
         if (c + 1 < a.nch) ct_load<MODE, PS>(a, cb, c + 1, tid, has_item, xsrc, st_in, st_w);
-        if constexpr (MODE == WSU_MODE_BF16X3) {
+        if constexpr (MODE == WSU_MODE_F16F8) {
+            // f16(w) * f16(x) per 16-channel chunk; the two cross terms of TWO chunks share one block-scaled fp8 instruction (a scale block
+            // is 32 k: lanes 0-31 carry the even chunk's 16 channels, lanes 32-63 the odd chunk's).  Each lane half reads its operands
+            // while its chunk is in LDS and holds them in registers; the instruction is issued on odd chunks (cin % 32 == 0, checked).
+            static_assert(PS, "F16F8 activations are stored split");
+            if ((c & 1) == hh) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    f8a0[m] = *reinterpret_cast<const u32x4*>(ldsA + (2 * 64 + m * 32) * 16);
+                    f8a1[m] = *reinterpret_cast<const u32x4*>(ldsA + (3 * 64 + m * 32) * 16);
+                }
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    f8b0[q] = *reinterpret_cast<const u32x4*>(ldsB + 2 * PLANE_IN + q * TW * 16);
+                    f8b1[q] = *reinterpret_cast<const u32x4*>(ldsB + 3 * PLANE_IN + q * TW * 16);
+                }
+            }
+            u32x4 ah[2], bh[2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) ah[m] = *reinterpret_cast<const u32x4*>(ldsA + (hh * 64 + m * 32) * 16);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) bh[q] = *reinterpret_cast<const u32x4*>(ldsB + hh * PLANE_IN + q * TW * 16);
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) wsu_mfma_f16(ah[m], bh[q], acc[m][q]);
+            if (c & 1) {
+                const int sc_a = hh ? WSU_F8_SCALE_WLO : WSU_F8_SCALE_W, sc_b = hh ? WSU_F8_SCALE_X : WSU_F8_SCALE_XLO;
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) wsu_mfma_f8x2(f8a0[m], f8a1[m], f8b0[q], f8b1[q], sc_a, sc_b, acc[m][q]);
+            }
+        } else if constexpr (MODE == WSU_MODE_BF16X3) {
             u32x4 ahi[2], alo[2], bhi[2], blo[2];
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
@@ -165,6 +201,21 @@ __global__ __launch_bounds__(NT, 2) void convt2x2_kernel(const CtArgs a) {
     }
     __syncthreads();
     const int oh = 2 * a.h, ow = 2 * a.w;
+    if constexpr (MODE == WSU_MODE_F16F8) {
+        for (int i = tid; i < 4 * NPIX * 4; i += NT) {            // one item = one output pixel x one 16-channel chunk (4 x 16 B)
+            const int opx = i >> 2, j = i & 3;
+            const int r = opx / (2 * TW), c = opx % (2 * TW);
+            const int oy = 2 * y0 + r, ox = 2 * x0 + c;
+            if (oy < oh && ox < ow) {
+                const f32x4* row = reinterpret_cast<const f32x4*>(smem + opx * STRIDE + j * 64);
+                u32x4 hi0, hi1, lo8, x8;
+                wsu_split16_f16f8(row[0], row[1], row[2], row[3], hi0, hi1, lo8, x8);
+                u32x4* dst = reinterpret_cast<u32x4*>(a.y + (((size_t)(n * oh + oy) * ow + ox) * a.cout + cb * WSU_COB) * 4 + j * 64);
+                dst[0] = hi0; dst[1] = hi1; dst[2] = lo8; dst[3] = x8;
+            }
+        }
+        return;
+    }
     if (MODE == WSU_MODE_BF16X3 && a.out_split) {
         for (int i = tid; i < 4 * NPIX * 8; i += NT) {            // one item = 8 channels of one output pixel: hi piece + lo piece
             const int opx = i >> 3, g8 = i & 7;
@@ -240,22 +291,47 @@ __global__ void pack_convt_kernel(const float* __restrict__ w, char* __restrict_
     }
 }
 
+// F16F8: one thread per (cob, chunk, sub, co) row of 16 input channels -> [f16 0-7][f16 8-15][e4m3(w * 2^6)][e4m3((w - f16 w) * 2^18)]
+__global__ void pack_convt_f16f8_kernel(const float* __restrict__ w, char* __restrict__ dst, int cin, int cout) {
+    const int nch = cin / 16;
+    const long long total = (long long)(cout / WSU_COB) * nch * 4 * WSU_COB;
+    for (long long d = (long long)blockIdx.x * blockDim.x + threadIdx.x; d < total; d += (long long)gridDim.x * blockDim.x) {
+        long long t = d;
+        const int co = t % WSU_COB; t /= WSU_COB;
+        const int sub = t % 4; t /= 4;
+        const int c = t % nch; t /= nch;
+        const int cb = (int)t;
+        f32x4 q[4];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) q[e >> 2][e & 3] = w[((size_t)(c * 16 + e) * cout + cb * WSU_COB + co) * 4 + sub];
+        uint32_t h[8], l[4], x[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) wsu_split4_f16f8(q[k], WSU_F8_WLO_MUL, WSU_F8_W_MUL, h[2 * k], h[2 * k + 1], l[k], x[k]);
+        char* base = dst + (((size_t)cb * nch + c) * 4 + sub) * (WSU_GRAN * WSU_COB * 16) + co * 16;
+        *reinterpret_cast<u32x4*>(base) = mk_u4(h[0], h[1], h[2], h[3]);
+        *reinterpret_cast<u32x4*>(base + WSU_COB * 16) = mk_u4(h[4], h[5], h[6], h[7]);
+        *reinterpret_cast<u32x4*>(base + 2 * WSU_COB * 16) = mk_u4(x[0], x[1], x[2], x[3]);
+        *reinterpret_cast<u32x4*>(base + 3 * WSU_COB * 16) = mk_u4(l[0], l[1], l[2], l[3]);
+    }
+}
+
 }  // namespace
 
 extern "C" {
 
 size_t wsu_convt2x2_packed_bytes(int cin, int cout, int mode) {
-    if (cin <= 0 || cout <= 0 || mode < 0 || mode > 2) return 0;
+    if (cin <= 0 || cout <= 0 || mode < 0 || (mode > 2 && mode != WSU_MODE_F16F8)) return 0;
     return (size_t)cin * cout * 4 * (mode == WSU_MODE_BF16 ? 2 : 4);
 }
 
 int wsu_convt2x2_pack(const float* w_iohw, void* w_packed, int cin, int cout, int mode, void* stream) {
     WSU_REQUIRE(w_iohw && w_packed, "convt2x2_pack: null pointer");
-    WSU_REQUIRE(mode >= 0 && mode <= 2, "convt2x2_pack: bad mode %d", mode);
+    WSU_REQUIRE((mode >= 0 && mode <= 2) || mode == WSU_MODE_F16F8, "convt2x2_pack: bad mode %d", mode);
     WSU_REQUIRE(cin > 0 && cin % wsu_chunk_channels(mode) == 0, "convt2x2_pack: cin=%d not a multiple of %d", cin, wsu_chunk_channels(mode));
     WSU_REQUIRE(cout > 0 && cout % WSU_COB == 0, "convt2x2_pack: cout=%d not a multiple of %d", cout, WSU_COB);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (mode == WSU_MODE_F32) hipLaunchKernelGGL(pack_convt_kernel<WSU_MODE_F32>, dim3(512), dim3(256), 0, s, w_iohw, (char*)w_packed, cin, cout);
+    if (mode == WSU_MODE_F16F8) hipLaunchKernelGGL(pack_convt_f16f8_kernel, dim3(512), dim3(256), 0, s, w_iohw, (char*)w_packed, cin, cout);
+    else if (mode == WSU_MODE_F32) hipLaunchKernelGGL(pack_convt_kernel<WSU_MODE_F32>, dim3(512), dim3(256), 0, s, w_iohw, (char*)w_packed, cin, cout);
     else if (mode == WSU_MODE_BF16X3) hipLaunchKernelGGL(pack_convt_kernel<WSU_MODE_BF16X3>, dim3(512), dim3(256), 0, s, w_iohw, (char*)w_packed, cin, cout);
     else hipLaunchKernelGGL(pack_convt_kernel<WSU_MODE_BF16>, dim3(512), dim3(256), 0, s, w_iohw, (char*)w_packed, cin, cout);
     return wsu_check_launch("pack_convt_kernel");
@@ -263,12 +339,13 @@ int wsu_convt2x2_pack(const float* w_iohw, void* w_packed, int cin, int cout, in
 
 int wsu_convt2x2_fwd(const void* x, const void* w_packed, const float* bias, void* y,
                      int n, int h, int w, int cin, int cout, int mode, void* stream) {
-    WSU_REQUIRE(mode >= 0 && mode <= 3, "convt2x2: bad mode %d", mode);
+    WSU_REQUIRE(mode >= 0 && mode <= 4, "convt2x2: bad mode %d", mode);
     const bool presplit = mode == WSU_MODE_BF16X3S;             // input and output stored already split (see wsu.h)
     if (presplit) mode = WSU_MODE_BF16X3;
     WSU_REQUIRE(x && w_packed && y, "convt2x2: null pointer");
     WSU_REQUIRE(n > 0 && h > 0 && w > 0, "convt2x2: bad shape n=%d h=%d w=%d", n, h, w);
     WSU_REQUIRE(cin > 0 && cin % wsu_chunk_channels(mode) == 0, "convt2x2: cin=%d not a multiple of %d", cin, wsu_chunk_channels(mode));
+    WSU_REQUIRE(mode != WSU_MODE_F16F8 || cin % 32 == 0, "convt2x2: mode F16F8 pairs 16-channel chunks, cin=%d must be a multiple of 32", cin);
     WSU_REQUIRE(cout > 0 && cout % WSU_COB == 0, "convt2x2: cout=%d not a multiple of %d", cout, WSU_COB);
     WSU_REQUIRE((long long)n * h * w * 4 < 0x7FFFFFFFLL, "convt2x2: output pixel count overflows int32");
     CtArgs a;
@@ -280,6 +357,7 @@ int wsu_convt2x2_fwd(const void* x, const void* w_packed, const float* bias, voi
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (mode == WSU_MODE_F32) return launch_ct<WSU_MODE_F32>(a, s);
     if (presplit) return launch_ct<WSU_MODE_BF16X3, true>(a, s);
+    if (mode == WSU_MODE_F16F8) return launch_ct<WSU_MODE_F16F8, true>(a, s);
     if (mode == WSU_MODE_BF16X3) return launch_ct<WSU_MODE_BF16X3>(a, s);
     return launch_ct<WSU_MODE_BF16>(a, s);
 }

@@ -32,6 +32,7 @@ int wsu_check_launch(const char* what);
 //   F32    : 16 channels, granule g = channels 4g..4g+3 (fp32)
 //   BF16   : 32 channels, granule g = channels 8g..8g+7 (bf16)
 //   BF16X3 : 16 channels, granules 0,1 = bf16 hi of channels 0..7 / 8..15, granules 2,3 = bf16 lo
+//   F16F8  : 16 channels, granules 0,1 = f16 of channels 0..7 / 8..15, granule 2 = e4m3 residuals, granule 3 = e4m3 copies (below)
 #define WSU_GRAN 4
 #define WSU_COB 64            // output channels per workgroup
 __host__ __device__ inline int wsu_chunk_channels(int mode) { return mode == WSU_MODE_BF16 ? 32 : 16; }
@@ -65,6 +66,63 @@ __device__ __forceinline__ void wsu_split8(const f32x4& a, const f32x4& b, u32x4
     wsu_split2(a.x, a.y, h0, l0); wsu_split2(a.z, a.w, h1, l1);
     wsu_split2(b.x, b.y, h2, l2); wsu_split2(b.z, b.w, h3, l3);
     hi = mk_u4(h0, h1, h2, h3); lo = mk_u4(l0, l1, l2, l3);
+}
+
+// ---- mode F16F8 (include/wsu.h): x = f16(x) + residual; the residual and an e4m3 copy of x feed the block-scaled fp8 MFMA ------
+// Fixed power-of-two scales (E8M0 bytes handed to v_mfma_scale_*: 127 + log2 of the factor that undoes the storage scaling):
+//   activations  x_lo8 = e4m3((x - f16 x) * 2^12) -> 115      x8 = e4m3(x * 2^-2)  -> 129
+//   weights      w8    = e4m3(w * 2^6)            -> 121      w_lo8 = e4m3((w - f16 w) * 2^18) -> 109
+// A residual is at most 2^-12 of its value, so the four encodings are in e4m3's normal range (2^-6 .. 448, 4 significant bits) for
+// |x| in ~[2^-6, 448] and |w| in ~[2^-12, 7]; smaller values keep an absolute error below 2^-22 (x) / 2^-28 (w), larger ones saturate.
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+#define WSU_F8_XLO_MUL 4096.f
+#define WSU_F8_X_MUL 0.25f
+#define WSU_F8_W_MUL 64.f
+#define WSU_F8_WLO_MUL 262144.f
+#define WSU_F8_SCALE_XLO 115
+#define WSU_F8_SCALE_X 129
+#define WSU_F8_SCALE_W 121
+#define WSU_F8_SCALE_WLO 109
+__device__ __forceinline__ float wsu_clamp_f8(float v) { return __builtin_amdgcn_fmed3f(v, -448.f, 448.f); }   // cvt_pk_fp8 overflows to NaN
+__device__ __forceinline__ uint32_t wsu_pack_fp8x4(float a, float b, float c, float d) {
+    int v = __builtin_amdgcn_cvt_pk_fp8_f32(wsu_clamp_f8(a), wsu_clamp_f8(b), 0, false);
+    return (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(wsu_clamp_f8(c), wsu_clamp_f8(d), v, true);
+}
+// 4 values -> 2 dwords of f16 (round to nearest even), 1 dword of residuals, 1 dword of e4m3 copies
+__device__ __forceinline__ void wsu_split4_f16f8(const f32x4& v, float mul_lo, float mul_x, uint32_t& h01, uint32_t& h23, uint32_t& lo, uint32_t& x8) {
+    float c[4], r[4]; uint16_t hb[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        c[e] = __builtin_amdgcn_fmed3f(v[e], -65504.f, 65504.f);
+        const _Float16 h = (_Float16)c[e];
+        hb[e] = __builtin_bit_cast(uint16_t, h);
+        r[e] = (c[e] - (float)h) * mul_lo;
+    }
+    h01 = (uint32_t)hb[0] | ((uint32_t)hb[1] << 16); h23 = (uint32_t)hb[2] | ((uint32_t)hb[3] << 16);
+    lo = wsu_pack_fp8x4(r[0], r[1], r[2], r[3]);
+    x8 = wsu_pack_fp8x4(c[0] * mul_x, c[1] * mul_x, c[2] * mul_x, c[3] * mul_x);
+}
+// 16 channels of one pixel -> the 4 x 16 B of an F16F8 chunk
+__device__ __forceinline__ void wsu_split16_f16f8(const f32x4& q0, const f32x4& q1, const f32x4& q2, const f32x4& q3,
+                                                  u32x4& hi0, u32x4& hi1, u32x4& lo8, u32x4& x8) {
+    uint32_t a0, a1, a2, a3, a4, a5, a6, a7, l0, l1, l2, l3, x0, x1, x2, x3;
+    wsu_split4_f16f8(q0, WSU_F8_XLO_MUL, WSU_F8_X_MUL, a0, a1, l0, x0); wsu_split4_f16f8(q1, WSU_F8_XLO_MUL, WSU_F8_X_MUL, a2, a3, l1, x1);
+    wsu_split4_f16f8(q2, WSU_F8_XLO_MUL, WSU_F8_X_MUL, a4, a5, l2, x2); wsu_split4_f16f8(q3, WSU_F8_XLO_MUL, WSU_F8_X_MUL, a6, a7, l3, x3);
+    hi0 = mk_u4(a0, a1, a2, a3); hi1 = mk_u4(a4, a5, a6, a7); lo8 = mk_u4(l0, l1, l2, l3); x8 = mk_u4(x0, x1, x2, x3);
+}
+// hi*hi on the f16 pipe; (a8, b8) = {block 0: e4m3(w) x residual(x), block 1: residual(w) x e4m3(x)} on the block-scaled fp8 pipe.
+// Operand layout of the scaled instruction (tools/mfma_scale_layout_probe.hip): registers 0-3 of every lane are scale block 0, registers
+// 4-7 block 1; inside a block lanes 0-31 hold k = 0..15 and lanes 32-63 k = 16..31; block b is scaled by byte 0 of the scale registers of
+// lanes 32b .. 32b+31 -> a lane passes (hh ? block-1 scale : block-0 scale).
+__device__ __forceinline__ void wsu_mfma_f16(const u32x4& a, const u32x4& b, f32x16& acc) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
+}
+__device__ __forceinline__ void wsu_mfma_f8x2(const u32x4& a_blk0, const u32x4& a_blk1, const u32x4& b_blk0, const u32x4& b_blk1,
+                                              int scale_a, int scale_b, f32x16& acc) {
+    i32x8 a = {(int)a_blk0.x, (int)a_blk0.y, (int)a_blk0.z, (int)a_blk0.w, (int)a_blk1.x, (int)a_blk1.y, (int)a_blk1.z, (int)a_blk1.w};
+    i32x8 b = {(int)b_blk0.x, (int)b_blk0.y, (int)b_blk0.z, (int)b_blk0.w, (int)b_blk1.x, (int)b_blk1.y, (int)b_blk1.z, (int)b_blk1.w};
+    acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, acc, 0, 0, 0, scale_a, 0, scale_b);
 }
 
 __device__ __forceinline__ float wsu_bf16_to_f32(uint16_t v) { return __builtin_bit_cast(float, (uint32_t)v << 16); }

@@ -14,6 +14,9 @@ Precision modes (``mode=`` or env ``WSU_MODE``):
   'bf16'    bf16 storage + MFMA                 -- fastest; MAE ~1e-3 on full-range weights
   'bf16x3s' bf16x3 with producer-side split     -- default; bitwise the results of 'bf16x3', activations stored as hi/lo halves
                                                    between the fused first layer and the fused head (keep= / autograd use 'bf16x3')
+  'f16f8'   f16 products + fp8 cross terms      -- opt-in: f16(w)*f16(x) exactly, the two residual cross terms on the block-scaled fp8
+                                                   matrix pipe (2/3 of bf16x3's matrix cycles, ~2^-15 relative error per product);
+                                                   same storage discipline as 'bf16x3s'
 """
 from __future__ import annotations
 
@@ -148,9 +151,9 @@ class UNet(nn.Module):
         t = keep if keep is not None else {}
         save = keep is not None
         e11 = self.e11
-        if m == ops.MODE_BF16X3S and (save or self.nsteps < 1 or not (self.fuse_first and self.fuse_head)
+        if m in (ops.MODE_BF16X3S, ops.MODE_F16F8) and (save or self.nsteps < 1 or not (self.fuse_first and self.fuse_head)
                                      or e11.in_channels != 1 or e11.out_channels != 64 or self.outconv.out_channels > 4):
-            m = ops.MODE_BF16X3             # the pre-split format lives only between the fused first layer and the fused head
+            m = ops.MODE_BF16X3             # the split formats live only between the fused first layer and the fused head
         # e11 is folded into e12's input staging unless its output is asked for (xe11 then never reaches HBM)
         fuse_first = self.fuse_first and not save and e11.in_channels == 1 and e11.out_channels == 64
         cur = None
@@ -164,7 +167,7 @@ class UNet(nn.Module):
             a, b = ENC[lvl]
             if lvl == 0 and fuse_first:
                 lb = self.e12
-                res = ops.conv3x3_fused_first(x, e11.weight, e11.bias.detach(), self._packed("e12", m, "conv"), lb.bias.detach(),
+                res = ops.conv3x3_fused_first(x, e11.weight, e11.bias.detach(), self._packed("e12", ops.first_layer_weight_mode(m), "conv"), lb.bias.detach(),
                                               lb.out_channels, m, pool=self.nsteps > 0)
                 if self.nsteps > 0:
                     skips.append(res[0])

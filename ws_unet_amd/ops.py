@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import MODES, MODE_BF16, MODE_BF16X3, MODE_BF16X3S, check
+from ._lib import MODES, MODE_BF16, MODE_BF16X3, MODE_BF16X3S, MODE_F16F8, check
 
 
 def _stream() -> int:
@@ -66,14 +66,20 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
 
 
 def act_dtype(mode: int) -> torch.dtype:
-    """dtype of an activation tensor's allocation.  'bf16x3s' tensors are float32-shaped (4 bytes per element) but hold bf16 hi / lo
-    halves in the layout of include/wsu.h: only libwsu kernels read them."""
+    """dtype of an activation tensor's allocation.  'bf16x3s' / 'f16f8' tensors are float32-shaped (4 bytes per element) but hold the
+    split encodings of include/wsu.h (bf16 hi / lo halves; f16 + two e4m3 bytes): only libwsu kernels read them."""
     return torch.bfloat16 if mode == MODE_BF16 else torch.float32
 
 
 def weight_mode(mode: int) -> int:
-    """The packed weights of 'bf16x3s' are the 'bf16x3' ones."""
+    """The packed weights of 'bf16x3s' are the 'bf16x3' ones ('f16f8' has its own packing)."""
     return MODE_BF16X3 if mode == MODE_BF16X3S else mode
+
+
+def first_layer_weight_mode(mode: int) -> int:
+    """Packing of the 3x3 weights handed to conv3x3_fused_first: the fused first layer of an 'f16f8' network keeps the bf16x3 arithmetic
+    (it is bound by computing and encoding its own input, not by the matrix pipe) and only stores in the f16f8 format."""
+    return MODE_BF16X3 if mode == MODE_F16F8 else weight_mode(mode)
 
 
 def _dev_check(*ts: Optional[torch.Tensor]) -> None:
