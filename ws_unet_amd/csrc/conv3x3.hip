@@ -592,33 +592,39 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 4 : 2) void conv3x3_kernel(const
             // fp8 instruction (block 0 = planes 2 of A and B, block 1 = planes 3; inside a block lanes 0-31 carry the 16 channels of the
             // pair's first tap and lanes 32-63 those of its second).  Tap 8 has no partner: its upper lanes pass zeros.
             const int sc_a = hh ? WSU_F8_SCALE_WLO : WSU_F8_SCALE_W, sc_b = hh ? WSU_F8_SCALE_X : WSU_F8_SCALE_XLO;
-            WSU_STATIC_FOR(5, tp, {
+            auto cross = [&](auto tp_c) __attribute__((always_inline)) {
+                constexpr int tp = decltype(tp_c)::value;
                 constexpr int t0 = 2 * tp, t1 = (2 * tp + 1 < 9) ? 2 * tp + 1 : 2 * tp;
                 constexpr bool single = 2 * tp + 1 >= 9;
-                {
-                    const int aoff = ((hh ? t1 : t0) * 4 + 2) * 64 * 16;
-                    const int boff = 2 * PLANE_IN + (hh ? ((t1 / 3) * IW + t1 % 3) : ((t0 / 3) * IW + t0 % 3)) * 16;
-                    u32x4 a0 = *reinterpret_cast<const u32x4*>(ldsA + aoff), a1 = *reinterpret_cast<const u32x4*>(ldsA + aoff + 64 * 16);
-                    u32x4 b0[2], b1[2];
+                const int aoff = ((hh ? t1 : t0) * 4 + 2) * 64 * 16;
+                const int boff = 2 * PLANE_IN + (hh ? ((t1 / 3) * IW + t1 % 3) : ((t0 / 3) * IW + t0 % 3)) * 16;
+                u32x4 a0 = *reinterpret_cast<const u32x4*>(ldsA + aoff), a1 = *reinterpret_cast<const u32x4*>(ldsA + aoff + 64 * 16);
+                u32x4 b0[2], b1[2];
 _Pragma("unroll")
-                    for (int q = 0; q < 2; ++q) {
-                        b0[q] = *reinterpret_cast<const u32x4*>(ldsB + boff + q * IW * 16);
-                        b1[q] = *reinterpret_cast<const u32x4*>(ldsB + boff + PLANE_IN + q * IW * 16);
-                    }
-                    if (single && hh) { a0 = mk_u4(0, 0, 0, 0); a1 = a0; b0[0] = a0; b0[1] = a0; b1[0] = a0; b1[1] = a0; }
-_Pragma("unroll")
-                    for (int q = 0; q < 2; ++q) wsu_mfma_f8x2(a0, a1, b0[q], b1[q], sc_a, sc_b, acc[0][q]);
+                for (int q = 0; q < 2; ++q) {
+                    b0[q] = *reinterpret_cast<const u32x4*>(ldsB + boff + q * IW * 16);
+                    b1[q] = *reinterpret_cast<const u32x4*>(ldsB + boff + PLANE_IN + q * IW * 16);
                 }
-                __builtin_amdgcn_sched_barrier(0);          // keep the operand reads of later taps behind these instructions (128-VGPR budget)
-                WSU_STATIC_FOR(single ? 1 : 2, k, {
-                    constexpr int tap = t0 + k, dy = tap / 3, dx = tap % 3;
-                    const u32x4 ah = *reinterpret_cast<const u32x4*>(ldsA + ((tap * 4 + hh) * 64) * 16);
-                    u32x4 bh[2];
+                if (single && hh) { a0 = mk_u4(0, 0, 0, 0); a1 = a0; b0[0] = a0; b0[1] = a0; b1[0] = a0; b1[1] = a0; }
 _Pragma("unroll")
-                    for (int q = 0; q < 2; ++q) bh[q] = *reinterpret_cast<const u32x4*>(ldsB + hh * PLANE_IN + ((q + dy) * IW + dx) * 16);
+                for (int q = 0; q < 2; ++q) wsu_mfma_f8x2(a0, a1, b0[q], b1[q], sc_a, sc_b, acc[0][q]);
+            };
+            auto main_term = [&](auto tap_c) __attribute__((always_inline)) {
+                constexpr int tap = decltype(tap_c)::value, dy = tap / 3, dx = tap % 3;
+                const u32x4 ah = *reinterpret_cast<const u32x4*>(ldsA + ((tap * 4 + hh) * 64) * 16);
+                u32x4 bh[2];
 _Pragma("unroll")
-                    for (int q = 0; q < 2; ++q) wsu_mfma_f16(ah, bh[q], acc[0][q]);
-                });
+                for (int q = 0; q < 2; ++q) bh[q] = *reinterpret_cast<const u32x4*>(ldsB + hh * PLANE_IN + ((q + dy) * IW + dx) * 16);
+_Pragma("unroll")
+                for (int q = 0; q < 2; ++q) wsu_mfma_f16(ah, bh[q], acc[0][q]);
+            };
+            // scheduling fences keep the operand reads of later taps behind these instructions (128-VGPR budget: without them the
+            // compiler hoists the reads and spills staging registers)
+            WSU_STATIC_FOR(5, tp, {
+                cross(std::integral_constant<int, tp>{});
+                __builtin_amdgcn_sched_barrier(0);
+                main_term(std::integral_constant<int, 2 * tp>{});
+                if constexpr (2 * tp + 1 < 9) main_term(std::integral_constant<int, 2 * tp + 1>{});
                 __builtin_amdgcn_sched_barrier(0);
             });
         } else
