@@ -35,7 +35,8 @@
  *                           residuals at full e4m3 precision): ~2^-15 relative error per product at 2/3 of BF16X3's matrix cycles.
  *                           Activations per pixel and 16-channel chunk: [f16 ch 0-7][f16 ch 8-15][e4m3((x - f16 x) * 2^12) ch 0-15]
  *                           [e4m3(x / 4) ch 0-15] (4 x 16 B = the fp32 chunk size); weights packed by the pack entry points with
- *                           this mode.  Values beyond +-448 lose the residual term (plain f16 accuracy), beyond +-65504 saturate.
+ *                           this mode.  Values beyond +-448 lose the residual term (plain f16 accuracy); beyond +-65504 the f16 part overflows
+ *                           like any f16 pipeline (use BF16X3S for such networks).
  */
 #ifndef WSU_H
 #define WSU_H

@@ -213,48 +213,70 @@ __device__ __forceinline__ void stage_commit(char* smem, int tid, const int (&pi
         if (W_ITEMS % NT == 0 || tid + k * NT < W_ITEMS) wdst[tid + k * NT] = st_w[k];
 }
 
-// F16F8 stores from the fp32 [pixel][channel] LDS tile: one item = one pixel x one 16-channel chunk = 4 x 16 B
-// (f16 0-7 | f16 8-15 | residuals | e4m3 copies), full-resolution output and / or the fused 2x2 max-pool.
+// F16F8 stores from the fp32 [pixel][channel] LDS tile.  The 4 x 16 B of a (pixel, 16-channel chunk) are produced by one thread, so
+// storing them directly would put 16 B into every 64 B per instruction (half-empty write requests: measured +11 % on the store-heavy
+// first layer).  Instead the tile is encoded IN PLACE (the encoded chunk has the size of its fp32 source) and then copied out with 16
+// consecutive lanes per pixel: every store instruction writes whole 256-byte pixel rows.  The fused 2x2 max-pool reads the fp32
+// tile first and stores its (4x smaller) output directly.
 template <int NT, int TH, int STRIDE>
-__device__ __forceinline__ void store_f16f8(const ConvArgs& a, const char* smem, int tid, int n, int y0, int x0, int cglob, char* ydst, int ych, int ycoff) {
-        if (ydst)
-            for (int i = tid; i < TH * TW * 4; i += NT) {
-                const int px = i >> 2, j = i & 3;
-                const int r = px / TW, c = px % TW;
-                if (y0 + r < a.h && x0 + c < a.w) {
-                    const f32x4* row = reinterpret_cast<const f32x4*>(smem + px * STRIDE + j * 64);
-                    u32x4 hi0, hi1, lo8, x8;
-                    wsu_split16_f16f8(row[0], row[1], row[2], row[3], hi0, hi1, lo8, x8);
-                    u32x4* dst = reinterpret_cast<u32x4*>(ydst + (((size_t)(n * a.h + y0 + r) * a.w + x0 + c) * ych + ycoff) * 4 + j * 64);
-                    dst[0] = hi0; dst[1] = hi1; dst[2] = lo8; dst[3] = x8;
-                }
-            }
-        if (a.ypool) {
-            const int hp = a.h >> 1, wp2 = a.w >> 1;
-            for (int i = tid; i < (TH / 2) * (TW / 2) * 4; i += NT) {
-                const int pp = i >> 2, j = i & 3;
-                const int pr = pp / (TW / 2), pc = pp % (TW / 2);
-                const int gy = (y0 >> 1) + pr, gx = (x0 >> 1) + pc;
-                if (gy < hp && gx < wp2) {
-                    const f32x4* b0 = reinterpret_cast<const f32x4*>(smem + ((2 * pr) * TW + 2 * pc) * STRIDE + j * 64);
-                    f32x4 m[4] = {b0[0], b0[1], b0[2], b0[3]};
+__device__ __forceinline__ void store_f16f8(const ConvArgs& a, char* smem, int tid, int n, int y0, int x0, int cglob, char* ydst, int ych, int ycoff) {
+    // fused 2x2 max-pool: one (pooled pixel, chunk) item per thread, encoded into registers now, staged and stored after the main tile
+    static_assert((TH / 2) * (TW / 2) * 4 <= NT, "one pooled item per thread");
+    u32x4 p_hi0, p_hi1, p_lo8, p_x8;
+    const bool pool_item = a.ypool && tid < (TH / 2) * (TW / 2) * 4;
+    if (pool_item) {
+        const int pp = tid >> 2, j = tid & 3;
+        const int pr = pp / (TW / 2), pc = pp % (TW / 2);
+        const f32x4* b0 = reinterpret_cast<const f32x4*>(smem + ((2 * pr) * TW + 2 * pc) * STRIDE + j * 64);
+        f32x4 m0 = b0[0], m1 = b0[1], m2 = b0[2], m3 = b0[3];
 #pragma unroll
-                    for (int wdx = 1; wdx < 4; ++wdx) {                    // window order of the fp32 path (first max wins; NaN propagates)
-                        const f32x4* bq = reinterpret_cast<const f32x4*>(smem + ((2 * pr + (wdx >> 1)) * TW + 2 * pc + (wdx & 1)) * STRIDE + j * 64);
+        for (int wdx = 1; wdx < 4; ++wdx) {                            // window order of the fp32 path (first max wins; NaN propagates)
+            const f32x4* bq = reinterpret_cast<const f32x4*>(smem + ((2 * pr + (wdx >> 1)) * TW + 2 * pc + (wdx & 1)) * STRIDE + j * 64);
+            const f32x4 q0 = bq[0], q1 = bq[1], q2 = bq[2], q3 = bq[3];
 #pragma unroll
-                        for (int v = 0; v < 4; ++v) {
-                            const f32x4 q = bq[v];
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) if (q[e] > m[v][e] || q[e] != q[e]) m[v][e] = q[e];
-                        }
-                    }
-                    u32x4 hi0, hi1, lo8, x8;
-                    wsu_split16_f16f8(m[0], m[1], m[2], m[3], hi0, hi1, lo8, x8);
-                    u32x4* dst = reinterpret_cast<u32x4*>(a.ypool + (((size_t)(n * hp + gy) * wp2 + gx) * a.cout + cglob) * 4 + j * 64);
-                    dst[0] = hi0; dst[1] = hi1; dst[2] = lo8; dst[3] = x8;
-                }
+            for (int e = 0; e < 4; ++e) {
+                if (q0[e] > m0[e] || q0[e] != q0[e]) m0[e] = q0[e];
+                if (q1[e] > m1[e] || q1[e] != q1[e]) m1[e] = q1[e];
+                if (q2[e] > m2[e] || q2[e] != q2[e]) m2[e] = q2[e];
+                if (q3[e] > m3[e] || q3[e] != q3[e]) m3[e] = q3[e];
             }
         }
+        wsu_split16_f16f8(m0, m1, m2, m3, p_hi0, p_hi1, p_lo8, p_x8);
+    }
+    if (ydst) {
+        __syncthreads();                                               // pool / head readers of the fp32 tile are done
+        for (int i = tid; i < TH * TW * 4; i += NT) {
+            u32x4* row = reinterpret_cast<u32x4*>(smem + (i >> 2) * STRIDE + (i & 3) * 64);
+            u32x4 hi0, hi1, lo8, x8;
+            wsu_split16_f16f8(__builtin_bit_cast(f32x4, row[0]), __builtin_bit_cast(f32x4, row[1]), __builtin_bit_cast(f32x4, row[2]),
+                              __builtin_bit_cast(f32x4, row[3]), hi0, hi1, lo8, x8);
+            row[0] = hi0; row[1] = hi1; row[2] = lo8; row[3] = x8;
+        }
+        __syncthreads();
+        for (int i = tid; i < TH * TW * 16; i += NT) {
+            const int px = i >> 4, piece = i & 15;
+            const int r = px / TW, c = px % TW;
+            if (y0 + r < a.h && x0 + c < a.w)
+                *reinterpret_cast<u32x4*>(ydst + (((size_t)(n * a.h + y0 + r) * a.w + x0 + c) * ych + ycoff) * 4 + piece * 16) =
+                    *reinterpret_cast<const u32x4*>(smem + px * STRIDE + piece * 16);
+        }
+    }
+    if (a.ypool) {
+        __syncthreads();                                               // the tile has been read out (or was never needed): reuse its first rows
+        if (pool_item) {
+            u32x4* row = reinterpret_cast<u32x4*>(smem + (tid >> 2) * STRIDE + (tid & 3) * 64);
+            row[0] = p_hi0; row[1] = p_hi1; row[2] = p_lo8; row[3] = p_x8;
+        }
+        __syncthreads();
+        const int hp = a.h >> 1, wp2 = a.w >> 1;
+        for (int i = tid; i < (TH / 2) * (TW / 2) * 16; i += NT) {
+            const int pp = i >> 4, piece = i & 15;
+            const int gy = (y0 >> 1) + pp / (TW / 2), gx = (x0 >> 1) + pp % (TW / 2);
+            if (gy < hp && gx < wp2)
+                *reinterpret_cast<u32x4*>(a.ypool + (((size_t)(n * hp + gy) * wp2 + gx) * a.cout + cglob) * 4 + piece * 16) =
+                    *reinterpret_cast<const u32x4*>(smem + pp * STRIDE + piece * 16);
+        }
+    }
 }
 
 // Everything behind the [pixel][channel] LDS tile (TH x 32 pixels, Epi<MODE>::STRIDE bytes per pixel): fused 1x1 head, coalesced
@@ -1432,7 +1454,7 @@ __global__ void pack_conv3x3_f16f8_kernel(const float* __restrict__ w, char* __r
         for (int e = 0; e < 16; ++e) q[e >> 2][e & 3] = w[(((size_t)(cb * WSU_COB + co)) * cin + c * 16 + e) * 9 + tap];
         uint32_t h[8], l[4], x[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) wsu_split4_f16f8(q[k], WSU_F8_WLO_MUL, WSU_F8_W_MUL, h[2 * k], h[2 * k + 1], l[k], x[k]);
+        for (int k = 0; k < 4; ++k) wsu_split4_f16f8(q[k], WSU_F8_WLO_DIV, WSU_F8_W_DIV, h[2 * k], h[2 * k + 1], l[k], x[k]);
         char* base = dst + (((size_t)cb * nch + c) * 9 + tap) * (WSU_GRAN * WSU_COB * 16) + co * 16;
         *reinterpret_cast<u32x4*>(base) = mk_u4(h[0], h[1], h[2], h[3]);
         *reinterpret_cast<u32x4*>(base + WSU_COB * 16) = mk_u4(h[4], h[5], h[6], h[7]);

@@ -202,17 +202,23 @@ __global__ __launch_bounds__(NT, 2) void convt2x2_kernel(const CtArgs a) {
     __syncthreads();
     const int oh = 2 * a.h, ow = 2 * a.w;
     if constexpr (MODE == WSU_MODE_F16F8) {
-        for (int i = tid; i < 4 * NPIX * 4; i += NT) {            // one item = one output pixel x one 16-channel chunk (4 x 16 B)
-            const int opx = i >> 2, j = i & 3;
+        // encode the tile in place (a 16-channel chunk keeps its 64 bytes), then copy out with 16 consecutive lanes per output pixel so
+        // that every store instruction writes whole 256-byte pixel rows (see store_f16f8 in conv3x3.hip)
+        for (int i = tid; i < 4 * NPIX * 4; i += NT) {
+            u32x4* row = reinterpret_cast<u32x4*>(smem + (i >> 2) * STRIDE + (i & 3) * 64);
+            u32x4 hi0, hi1, lo8, x8;
+            wsu_split16_f16f8(__builtin_bit_cast(f32x4, row[0]), __builtin_bit_cast(f32x4, row[1]), __builtin_bit_cast(f32x4, row[2]),
+                              __builtin_bit_cast(f32x4, row[3]), hi0, hi1, lo8, x8);
+            row[0] = hi0; row[1] = hi1; row[2] = lo8; row[3] = x8;
+        }
+        __syncthreads();
+        for (int i = tid; i < 4 * NPIX * 16; i += NT) {
+            const int opx = i >> 4, piece = i & 15;
             const int r = opx / (2 * TW), c = opx % (2 * TW);
             const int oy = 2 * y0 + r, ox = 2 * x0 + c;
-            if (oy < oh && ox < ow) {
-                const f32x4* row = reinterpret_cast<const f32x4*>(smem + opx * STRIDE + j * 64);
-                u32x4 hi0, hi1, lo8, x8;
-                wsu_split16_f16f8(row[0], row[1], row[2], row[3], hi0, hi1, lo8, x8);
-                u32x4* dst = reinterpret_cast<u32x4*>(a.y + (((size_t)(n * oh + oy) * ow + ox) * a.cout + cb * WSU_COB) * 4 + j * 64);
-                dst[0] = hi0; dst[1] = hi1; dst[2] = lo8; dst[3] = x8;
-            }
+            if (oy < oh && ox < ow)
+                *reinterpret_cast<u32x4*>(a.y + (((size_t)(n * oh + oy) * ow + ox) * a.cout + cb * WSU_COB) * 4 + piece * 16) =
+                    *reinterpret_cast<const u32x4*>(smem + opx * STRIDE + piece * 16);
         }
         return;
     }
@@ -306,7 +312,7 @@ __global__ void pack_convt_f16f8_kernel(const float* __restrict__ w, char* __res
         for (int e = 0; e < 16; ++e) q[e >> 2][e & 3] = w[((size_t)(c * 16 + e) * cout + cb * WSU_COB + co) * 4 + sub];
         uint32_t h[8], l[4], x[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) wsu_split4_f16f8(q[k], WSU_F8_WLO_MUL, WSU_F8_W_MUL, h[2 * k], h[2 * k + 1], l[k], x[k]);
+        for (int k = 0; k < 4; ++k) wsu_split4_f16f8(q[k], WSU_F8_WLO_DIV, WSU_F8_W_DIV, h[2 * k], h[2 * k + 1], l[k], x[k]);
         char* base = dst + (((size_t)cb * nch + c) * 4 + sub) * (WSU_GRAN * WSU_COB * 16) + co * 16;
         *reinterpret_cast<u32x4*>(base) = mk_u4(h[0], h[1], h[2], h[3]);
         *reinterpret_cast<u32x4*>(base + WSU_COB * 16) = mk_u4(h[4], h[5], h[6], h[7]);

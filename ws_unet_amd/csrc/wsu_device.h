@@ -73,42 +73,45 @@ __device__ __forceinline__ void wsu_split8(const f32x4& a, const f32x4& b, u32x4
 //   activations  x_lo8 = e4m3((x - f16 x) * 2^12) -> 115      x8 = e4m3(x * 2^-2)  -> 129
 //   weights      w8    = e4m3(w * 2^6)            -> 121      w_lo8 = e4m3((w - f16 w) * 2^18) -> 109
 // A residual is at most 2^-12 of its value, so the four encodings are in e4m3's normal range (2^-6 .. 448, 4 significant bits) for
-// |x| in ~[2^-6, 448] and |w| in ~[2^-12, 7]; smaller values keep an absolute error below 2^-22 (x) / 2^-28 (w), larger ones saturate.
+// |x| in ~[2^-6, 448] and |w| in ~[2^-12, 7]; smaller values keep an absolute error below 2^-22 (x) / 2^-28 (w), larger ones saturate
+// their e4m3 encodings (the product then has plain f16 accuracy).
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(8))) int i32x8;
-#define WSU_F8_XLO_MUL 4096.f
-#define WSU_F8_X_MUL 0.25f
-#define WSU_F8_W_MUL 64.f
-#define WSU_F8_WLO_MUL 262144.f
+// divisors handed to v_cvt_scalef32_pk_fp8_f32 (it converts src / scale; tools/split_probe.hip)
+#define WSU_F8_XLO_DIV 0x1p-12f
+#define WSU_F8_X_DIV 4.f
+#define WSU_F8_W_DIV 0x1p-6f
+#define WSU_F8_WLO_DIV 0x1p-18f
 #define WSU_F8_SCALE_XLO 115
 #define WSU_F8_SCALE_X 129
 #define WSU_F8_SCALE_W 121
 #define WSU_F8_SCALE_WLO 109
-__device__ __forceinline__ float wsu_clamp_f8(float v) { return __builtin_amdgcn_fmed3f(v, -448.f, 448.f); }   // cvt_pk_fp8 overflows to NaN
-__device__ __forceinline__ uint32_t wsu_pack_fp8x4(float a, float b, float c, float d) {
-    int v = __builtin_amdgcn_cvt_pk_fp8_f32(wsu_clamp_f8(a), wsu_clamp_f8(b), 0, false);
-    return (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(wsu_clamp_f8(c), wsu_clamp_f8(d), v, true);
-}
-// 4 values -> 2 dwords of f16 (round to nearest even), 1 dword of residuals, 1 dword of e4m3 copies
-__device__ __forceinline__ void wsu_split4_f16f8(const f32x4& v, float mul_lo, float mul_x, uint32_t& h01, uint32_t& h23, uint32_t& lo, uint32_t& x8) {
-    float c[4], r[4]; uint16_t hb[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        c[e] = __builtin_amdgcn_fmed3f(v[e], -65504.f, 65504.f);
-        const _Float16 h = (_Float16)c[e];
-        hb[e] = __builtin_bit_cast(uint16_t, h);
-        r[e] = (c[e] - (float)h) * mul_lo;
-    }
-    h01 = (uint32_t)hb[0] | ((uint32_t)hb[1] << 16); h23 = (uint32_t)hb[2] | ((uint32_t)hb[3] << 16);
-    lo = wsu_pack_fp8x4(r[0], r[1], r[2], r[3]);
-    x8 = wsu_pack_fp8x4(c[0] * mul_x, c[1] * mul_x, c[2] * mul_x, c[3] * mul_x);
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+typedef __attribute__((ext_vector_type(2))) short i16x2;
+// 4 values -> 2 dwords of f16 (round to nearest even), 1 dword of residuals, 1 dword of e4m3 copies: 5.5 VALU instructions per value
+// (v_cvt_pk_f16_f32, widen + subtract, two v_med3 -- the fp8 conversions overflow to NaN instead of saturating, also with
+// MODE.FP16_OVFL set (tools/split_probe.hip) -- and the scaling conversions).  |v| > 65504 overflows the f16 part like any f16 pipeline.
+__device__ __forceinline__ void wsu_split4_f16f8(const f32x4& v, float div_lo, float div_x, uint32_t& h01, uint32_t& h23, uint32_t& lo, uint32_t& x8) {
+    const f32x2 a = {v[0], v[1]}, b = {v[2], v[3]};
+    const f16x2 ha = __builtin_convertvector(a, f16x2), hb = __builtin_convertvector(b, f16x2);
+    h01 = __builtin_bit_cast(uint32_t, ha); h23 = __builtin_bit_cast(uint32_t, hb);
+    const float lim_lo = 448.f * div_lo, lim_x = 448.f * div_x;
+    const float r0 = __builtin_amdgcn_fmed3f(v[0] - (float)ha[0], -lim_lo, lim_lo), r1 = __builtin_amdgcn_fmed3f(v[1] - (float)ha[1], -lim_lo, lim_lo);
+    const float r2 = __builtin_amdgcn_fmed3f(v[2] - (float)hb[0], -lim_lo, lim_lo), r3 = __builtin_amdgcn_fmed3f(v[3] - (float)hb[1], -lim_lo, lim_lo);
+    i16x2 l = {0, 0}, x = {0, 0};
+    l = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(l, r0, r1, div_lo, false);
+    l = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(l, r2, r3, div_lo, true);
+    x = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(x, __builtin_amdgcn_fmed3f(v[0], -lim_x, lim_x), __builtin_amdgcn_fmed3f(v[1], -lim_x, lim_x), div_x, false);
+    x = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(x, __builtin_amdgcn_fmed3f(v[2], -lim_x, lim_x), __builtin_amdgcn_fmed3f(v[3], -lim_x, lim_x), div_x, true);
+    lo = __builtin_bit_cast(uint32_t, l); x8 = __builtin_bit_cast(uint32_t, x);
 }
 // 16 channels of one pixel -> the 4 x 16 B of an F16F8 chunk
 __device__ __forceinline__ void wsu_split16_f16f8(const f32x4& q0, const f32x4& q1, const f32x4& q2, const f32x4& q3,
                                                   u32x4& hi0, u32x4& hi1, u32x4& lo8, u32x4& x8) {
     uint32_t a0, a1, a2, a3, a4, a5, a6, a7, l0, l1, l2, l3, x0, x1, x2, x3;
-    wsu_split4_f16f8(q0, WSU_F8_XLO_MUL, WSU_F8_X_MUL, a0, a1, l0, x0); wsu_split4_f16f8(q1, WSU_F8_XLO_MUL, WSU_F8_X_MUL, a2, a3, l1, x1);
-    wsu_split4_f16f8(q2, WSU_F8_XLO_MUL, WSU_F8_X_MUL, a4, a5, l2, x2); wsu_split4_f16f8(q3, WSU_F8_XLO_MUL, WSU_F8_X_MUL, a6, a7, l3, x3);
+    wsu_split4_f16f8(q0, WSU_F8_XLO_DIV, WSU_F8_X_DIV, a0, a1, l0, x0); wsu_split4_f16f8(q1, WSU_F8_XLO_DIV, WSU_F8_X_DIV, a2, a3, l1, x1);
+    wsu_split4_f16f8(q2, WSU_F8_XLO_DIV, WSU_F8_X_DIV, a4, a5, l2, x2); wsu_split4_f16f8(q3, WSU_F8_XLO_DIV, WSU_F8_X_DIV, a6, a7, l3, x3);
     hi0 = mk_u4(a0, a1, a2, a3); hi1 = mk_u4(a4, a5, a6, a7); lo8 = mk_u4(l0, l1, l2, l3); x8 = mk_u4(x0, x1, x2, x3);
 }
 // hi*hi on the f16 pipe; (a8, b8) = {block 0: e4m3(w) x residual(x), block 1: residual(w) x e4m3(x)} on the block-scaled fp8 pipe.
