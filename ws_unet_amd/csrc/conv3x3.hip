@@ -74,8 +74,7 @@ struct ConvArgs {
     // (img: (N,1,H,W) fp32, w1: (64,1,3,3), b1: (64) or null); x1 is then null
     const float* img; const float* w1; const float* b1;
     // API mode WSU_MODE_BF16X3S: activations stored already split (per pixel and 16-channel chunk: hi 0-7 | hi 8-15 | lo 0-7 | lo 8-15,
-    // 4 x 16 B = the fp32 chunk size).  The input side is the template flag PS (staging becomes a plain copy), the output side this flag
-    // (1; 2 = store in the F16F8 format from a BF16X3 kernel: the fused first layer of an F16F8 network).
+    // 4 x 16 B = the fp32 chunk size).  The input side is the template flag PS (staging becomes a plain copy), the output side this flag.
     int out_split;
 };
 
@@ -126,27 +125,45 @@ __device__ __forceinline__ void stage_load(const ConvArgs& a, int cb, int c, int
 
 // ---- fused first layer: LDS extras behind the main region -------------------------------------------------------
 //   P  [input-tile pixel][12]  the 3x3 image neighbourhood (reflect) of the e11 output pixel that this tile position maps to
-//   W1 [64 channels][12]       e11 taps (9 used), B1 [64]
+//   W1T [9 taps][64 channels]  e11 taps, tap-major for the packed FMAs of e11_oct (the region keeps its 64 x 48 bytes), B1 [64]
 constexpr int F1_W1_OFF(int npix) { return npix * 48; }
 constexpr int F1_B1_OFF(int npix) { return npix * 48 + 64 * 48; }
 constexpr int F1_BYTES(int npix) { return npix * 48 + 64 * 48 + 256; }
 
-// relu(b + sum_t x_t * w_t) for channels ch..ch+3, taps in the order of conv3x3_first_kernel (bitwise the same values)
-__device__ __forceinline__ f32x4 e11_quad(const float* P12, const float* W1, const float* B1, int ch) {
+// relu(b + sum_t x_t * w_t) for channels ch..ch+7 (ch..ch+3), taps in the order of conv3x3_first_kernel (bitwise the same values).
+// Two channels per v_pk_fma_f32: the weights sit tap-major in LDS (W1T [9 taps][64 ch]) so that a channel pair is one aligned register
+// pair, and the pixel value is broadcast by op_sel -- 36 + 8 VALU instructions per 8 channels instead of 80 (the fused first layer is
+// bound by this computation, not by its matrix work).
+__device__ __forceinline__ void e11_oct(const float* P12, const float* W1T, const float* B1, int ch, f32x4& r0, f32x4& r1) {
     const f32x4 p0 = *reinterpret_cast<const f32x4*>(P12), p1 = *reinterpret_cast<const f32x4*>(P12 + 4), p2 = *reinterpret_cast<const f32x4*>(P12 + 8);
-    const f32x4 b = *reinterpret_cast<const f32x4*>(B1 + ch);
-    f32x4 r;
+    const float p[9] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w, p2.x};
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(B1 + ch), b1 = *reinterpret_cast<const f32x4*>(B1 + ch + 4);
+    f32x2 a0 = {b0.x, b0.y}, a1 = {b0.z, b0.w}, a2 = {b1.x, b1.y}, a3 = {b1.z, b1.w};
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const float* wr = W1 + (ch + k) * 12;
-        const f32x4 w0 = *reinterpret_cast<const f32x4*>(wr), w1 = *reinterpret_cast<const f32x4*>(wr + 4), w2 = *reinterpret_cast<const f32x4*>(wr + 8);
-        float acc = b[k];
-        acc = fmaf(p0.x, w0.x, acc); acc = fmaf(p0.y, w0.y, acc); acc = fmaf(p0.z, w0.z, acc); acc = fmaf(p0.w, w0.w, acc);
-        acc = fmaf(p1.x, w1.x, acc); acc = fmaf(p1.y, w1.y, acc); acc = fmaf(p1.z, w1.z, acc); acc = fmaf(p1.w, w1.w, acc);
-        acc = fmaf(p2.x, w2.x, acc);
-        r[k] = fmaxf(acc, 0.f);
+    for (int t = 0; t < 9; ++t) {
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(W1T + t * 64 + ch), w1 = *reinterpret_cast<const f32x4*>(W1T + t * 64 + ch + 4);
+        const f32x2 pp = {p[t], p[t]};
+        a0 = __builtin_elementwise_fma(pp, (f32x2){w0.x, w0.y}, a0);
+        a1 = __builtin_elementwise_fma(pp, (f32x2){w0.z, w0.w}, a1);
+        a2 = __builtin_elementwise_fma(pp, (f32x2){w1.x, w1.y}, a2);
+        a3 = __builtin_elementwise_fma(pp, (f32x2){w1.z, w1.w}, a3);
     }
-    return r;
+    r0 = mk_f4(fmaxf(a0.x, 0.f), fmaxf(a0.y, 0.f), fmaxf(a1.x, 0.f), fmaxf(a1.y, 0.f));
+    r1 = mk_f4(fmaxf(a2.x, 0.f), fmaxf(a2.y, 0.f), fmaxf(a3.x, 0.f), fmaxf(a3.y, 0.f));
+}
+__device__ __forceinline__ f32x4 e11_quad(const float* P12, const float* W1T, const float* B1, int ch) {
+    const f32x4 p0 = *reinterpret_cast<const f32x4*>(P12), p1 = *reinterpret_cast<const f32x4*>(P12 + 4), p2 = *reinterpret_cast<const f32x4*>(P12 + 8);
+    const float p[9] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w, p2.x};
+    const f32x4 b = *reinterpret_cast<const f32x4*>(B1 + ch);
+    f32x2 a0 = {b.x, b.y}, a1 = {b.z, b.w};
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(W1T + t * 64 + ch);
+        const f32x2 pp = {p[t], p[t]};
+        a0 = __builtin_elementwise_fma(pp, (f32x2){w.x, w.y}, a0);
+        a1 = __builtin_elementwise_fma(pp, (f32x2){w.z, w.w}, a1);
+    }
+    return mk_f4(fmaxf(a0.x, 0.f), fmaxf(a0.y, 0.f), fmaxf(a1.x, 0.f), fmaxf(a1.y, 0.f));
 }
 
 // Chunk c of the virtual 64-channel input, computed into the granule-planar tile (same LDS contents as staging e11's output)
@@ -155,7 +172,7 @@ __device__ __forceinline__ void stage_commit_first(char* smem, int tid, int c, c
                                                    const u32x4 (&st_w)[Shape<NW>::W_VEC]) {
     constexpr int NT = Shape<NW>::NT, W_VEC = Shape<NW>::W_VEC;
     constexpr int PLANE_IN = Shape<NW>::PLANE_IN, LDS_IN = Shape<NW>::LDS_IN, NPIX_IN = Shape<NW>::NPIX_IN;
-    constexpr int NLOOP = (MODE == WSU_MODE_BF16X3) ? Shape<NW>::IN_VEC3 : Shape<NW>::IN_VEC;
+    constexpr int NLOOP = (MODE == WSU_MODE_BF16X3 || MODE == WSU_MODE_F16F8) ? Shape<NW>::IN_VEC3 : Shape<NW>::IN_VEC;
     const float* P = reinterpret_cast<const float*>(smem + Shape<NW>::LDS_MAIN);
     const float* W1 = reinterpret_cast<const float*>(smem + Shape<NW>::LDS_MAIN + F1_W1_OFF(NPIX_IN));
     const float* B1 = reinterpret_cast<const float*>(smem + Shape<NW>::LDS_MAIN + F1_B1_OFF(NPIX_IN));
@@ -165,16 +182,27 @@ __device__ __forceinline__ void stage_commit_first(char* smem, int tid, int c, c
             const int i = tid + j * NT;
             if constexpr (MODE == WSU_MODE_BF16X3) {
                 const int pix = i >> 1, ch0 = c * 16 + (i & 1) * 8;
-                u32x4 hi, lo;
-                wsu_split8(e11_quad(P + pix * 12, W1, B1, ch0), e11_quad(P + pix * 12, W1, B1, ch0 + 4), hi, lo);
+                u32x4 hi, lo; f32x4 q0, q1;
+                e11_oct(P + pix * 12, W1, B1, ch0, q0, q1);
+                wsu_split8(q0, q1, hi, lo);
                 *reinterpret_cast<u32x4*>(smem + ldsoff[j]) = hi;
                 *reinterpret_cast<u32x4*>(smem + ldsoff[j] + 2 * PLANE_IN) = lo;
+            } else if constexpr (MODE == WSU_MODE_F16F8) {
+                const int pix = i >> 1, half = i & 1, ch0 = c * 16 + half * 8;
+                uint32_t h0, h1, h2, h3, l0, l1, x0, x1; f32x4 q0, q1;
+                e11_oct(P + pix * 12, W1, B1, ch0, q0, q1);
+                wsu_split4_f16f8(q0, WSU_F8_XLO_DIV, WSU_F8_X_DIV, h0, h1, l0, x0);
+                wsu_split4_f16f8(q1, WSU_F8_XLO_DIV, WSU_F8_X_DIV, h2, h3, l1, x1);
+                *reinterpret_cast<u32x4*>(smem + ldsoff[j]) = mk_u4(h0, h1, h2, h3);                            // plane `half`
+                *reinterpret_cast<u32x2*>(smem + 2 * PLANE_IN + pix * 16 + half * 8) = mk_u2(l0, l1);
+                *reinterpret_cast<u32x2*>(smem + 3 * PLANE_IN + pix * 16 + half * 8) = mk_u2(x0, x1);
             } else if constexpr (MODE == WSU_MODE_F32) {
                 const int pix = i >> 2, ch0 = c * 16 + (i & 3) * 4;
                 *reinterpret_cast<f32x4*>(smem + ldsoff[j]) = e11_quad(P + pix * 12, W1, B1, ch0);
             } else {
                 const int pix = i >> 2, ch0 = c * 32 + (i & 3) * 8;
-                const f32x4 q0 = e11_quad(P + pix * 12, W1, B1, ch0), q1 = e11_quad(P + pix * 12, W1, B1, ch0 + 4);
+                f32x4 q0, q1;
+                e11_oct(P + pix * 12, W1, B1, ch0, q0, q1);
                 *reinterpret_cast<u32x4*>(smem + ldsoff[j]) = mk_u4(wsu_pack_bf16x2(q0.x, q0.y), wsu_pack_bf16x2(q0.z, q0.w),
                                                                    wsu_pack_bf16x2(q1.x, q1.y), wsu_pack_bf16x2(q1.z, q1.w));
             }
@@ -326,7 +354,6 @@ __device__ __forceinline__ void tile_epilogue(const ConvArgs& a, char* smem, int
     }
     if constexpr (MODE == WSU_MODE_F16F8) { store_f16f8<NT, TH, STRIDE>(a, smem, tid, n, y0, x0, cglob, ydst, ych, ycoff); return; }
     if constexpr (MODE == WSU_MODE_BF16X3) {
-        if (a.out_split == 2) { store_f16f8<NT, TH, STRIDE>(a, smem, tid, n, y0, x0, cglob, ydst, ych, ycoff); return; }   // first layer of an F16F8 network
         if (a.out_split) {
             // ---- pre-split stores (mode BF16X3S): per pixel and 16-channel chunk  hi 0-7 | hi 8-15 | lo 0-7 | lo 8-15; one item = 8 channels
             if (ydst)
@@ -476,8 +503,8 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 4 : 2) void conv3x3_kernel(const
     // ---- per-thread staging plan (identical for every chunk) ---------------------------------------
     int pixidx[IN_VEC];      // linear pixel index (n*H + y)*W + x of the source, -1 = zero, -2 = no item
     int ldsoff[IN_VEC];
-    constexpr bool SPLIT_HERE = MODE == WSU_MODE_BF16X3 && !PS;     // F1 computes its input and always splits here
-    static_assert(MODE != WSU_MODE_F16F8 || (PS && !F1 && NW == 8 && !S16), "F16F8: stored-split input, 8-wave shape (its first layer runs BF16X3)");
+    constexpr bool SPLIT_HERE = (MODE == WSU_MODE_BF16X3 || MODE == WSU_MODE_F16F8) && !PS;     // F1 computes its input and always splits here
+    static_assert(MODE != WSU_MODE_F16F8 || ((PS != F1) && NW == 8 && !S16), "F16F8: stored-split or self-computed input, 8-wave shape");
     constexpr int NITEMS = SPLIT_HERE ? NPIX_IN * 2 : NPIX_IN * 4;
     constexpr int NLOOP = SPLIT_HERE ? Shape<NW>::IN_VEC3 : IN_VEC;
 #pragma unroll
@@ -541,7 +568,7 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 4 : 2) void conv3x3_kernel(const
             }
             P[i] = v;
         }
-        for (int i = tid; i < 64 * 12; i += NT) { const int ch = i / 12, t = i - ch * 12; W1[i] = t < 9 ? a.w1[ch * 9 + t] : 0.f; }
+        for (int i = tid; i < 9 * 64; i += NT) { const int t = i >> 6, ch = i & 63; W1[i] = a.w1[ch * 9 + t]; }      // tap-major (e11_oct)
         if (tid < 64) B1[tid] = a.b1 ? a.b1[tid] : 0.f;
     }
     WSU_STAMP(0);
@@ -1370,7 +1397,7 @@ int launch_conv(const ConvArgs& a, hipStream_t s, bool in_split = false) {
         if (in_split) return launch_conv_nw<MODE, 8, false, false, true>(a, s);      // pre-split input: the measured default shape only
     }
     if constexpr (MODE == WSU_MODE_F16F8) {
-        return launch_conv_nw<MODE, 8, false, false, true>(a, s);
+        return a.img ? launch_conv_nw<MODE, 8, false, true, false>(a, s) : launch_conv_nw<MODE, 8, false, false, true>(a, s);
     } else {
     // Default = the per-tile kernel (v1): measured faster (bench conv3x3 15.8 ms vs 17.9 ms per batch-32 forward in bf16x3).
     // WSU_CONV_IMPL=pp selects the ping-pong kernel (kept for the next tuning round; profiles/r01/conv3x3_ablation.md).
@@ -1518,11 +1545,7 @@ static int conv3x3_launch_full(const void* x1, const void* x2, const void* w_pac
     WSU_REQUIRE(mode >= 0 && mode <= 4, "conv3x3: bad mode %d", mode);
     const bool presplit = mode == WSU_MODE_BF16X3S;             // split-bf16 arithmetic on activations stored already split
     if (presplit) mode = WSU_MODE_BF16X3;
-    // The fused first layer of an F16F8 network computes its 64 input channels while staging: that kernel is VALU-bound on the f16/e4m3
-    // encoding (measured 2.41 vs 2.04 ms), so it keeps the BF16X3 arithmetic (weights packed for BF16X3) and only STORES in the F16F8 format.
-    const bool first_f16f8 = mode == WSU_MODE_F16F8 && first_img;
-    if (first_f16f8) mode = WSU_MODE_BF16X3;
-    WSU_REQUIRE(!(presplit || first_f16f8 || mode == WSU_MODE_F16F8) || (!pool_idx && !relu_mask && !relu_mask2 && !y2 && !pad_zero),
+    WSU_REQUIRE(!(presplit || mode == WSU_MODE_F16F8) || (!pool_idx && !relu_mask && !relu_mask2 && !y2 && !pad_zero),
                 "conv3x3: modes BF16X3S / F16F8 are forward inference formats (no pool_idx, ReLU masks, split outputs or zero padding)");
     const int ck = wsu_chunk_channels(mode);
     WSU_REQUIRE((x1 || first_img) && w_packed && (y || head_w), "conv3x3: null pointer");
@@ -1548,7 +1571,7 @@ static int conv3x3_launch_full(const void* x1, const void* x2, const void* w_pac
     a.relu = relu; a.pad_zero = pad_zero;
     a.head_w = head_w; a.head_b = head_b; a.head_out = head_out; a.head_logit = head_logit; a.head_cout = head_cout;
     a.img = first_img; a.w1 = first_w; a.b1 = first_b;
-    a.out_split = first_f16f8 ? 2 : presplit;
+    a.out_split = presplit;
     static int ablate = -1;
     if (ablate < 0) { const char* e = getenv("WSU_CONV_ABLATE"); ablate = e ? atoi(e) : 0; }
     a.ablate = ablate;

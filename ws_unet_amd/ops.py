@@ -77,9 +77,8 @@ def weight_mode(mode: int) -> int:
 
 
 def first_layer_weight_mode(mode: int) -> int:
-    """Packing of the 3x3 weights handed to conv3x3_fused_first: the fused first layer of an 'f16f8' network keeps the bf16x3 arithmetic
-    (it is bound by computing and encoding its own input, not by the matrix pipe) and only stores in the f16f8 format."""
-    return MODE_BF16X3 if mode == MODE_F16F8 else weight_mode(mode)
+    """Packing of the 3x3 weights handed to conv3x3_fused_first (the layer's own mode; kept as the one place that decides it)."""
+    return weight_mode(mode)
 
 
 def _dev_check(*ts: Optional[torch.Tensor]) -> None:
