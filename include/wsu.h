@@ -33,9 +33,10 @@
  *                           product is exact (v_mfma_f32_32x32x16_f16), the two cross terms share one
  *                           v_mfma_scale_f32_32x32x64_f8f6f4 (2x the bf16 rate; its two 32-element scale blocks carry 2^-12-sized
  *                           residuals at full e4m3 precision): ~2^-15 relative error per product at 2/3 of BF16X3's matrix cycles.
- *                           Activations per pixel and 16-channel chunk: [f16 ch 0-7][f16 ch 8-15][e4m3((x - f16 x) * 2^12) ch 0-15]
- *                           [e4m3(x / 4) ch 0-15] (4 x 16 B = the fp32 chunk size); weights packed by the pack entry points with
- *                           this mode.  Values beyond +-448 lose the residual term (plain f16 accuracy); beyond +-65504 the f16 part overflows
+ *                           Activations take 3 bytes per element: per pixel and 16-channel chunk [f16 ch 0-7][f16 ch 8-15]
+ *                           [e4m3((x - f16 x) * 2^12) ch 0-15] = 48 bytes, pixel stride C * 3 bytes (the e4m3 copy e4m3(x / 4) that
+ *                           the second cross term needs is derived from the f16 part while staging); weights packed by the pack
+ *                           entry points with this mode (4 bytes per weight).  Values beyond +-448 lose the residual term (plain f16 accuracy); beyond +-65504 the f16 part overflows
  *                           like any f16 pipeline (use BF16X3S for such networks).
  */
 #ifndef WSU_H
@@ -62,7 +63,7 @@ enum {
 int wsu_version(void);
 const char* wsu_last_error(void);
 
-/* Bytes per activation element for a mode (4, 4, 2). */
+/* Bytes per activation element for a mode (4, 4, 2, 4, 3). */
 int wsu_act_elem_size(int mode);
 
 /* ---- weight packing (done once per weight update; replaces nothing in the reference:

@@ -75,15 +75,13 @@ def _e4m3_table() -> np.ndarray:
     return np.where(v & 0x80, -mag, mag).astype(np.float32)
 
 
-def unsplit_f16f8(t_nhwc: torch.Tensor):
-    """'f16f8' storage -> (f16 part + residual part, e4m3 copy) as fp32 (test-side restatement of include/wsu.h: per pixel and
-    16-channel chunk  f16 ch 0-7 | f16 ch 8-15 | e4m3((x - f16 x) * 2^12) ch 0-15 | e4m3(x / 4) ch 0-15)."""
-    raw = t_nhwc.detach().cpu().contiguous().numpy().view(np.uint8)             # (N,H,W,4C) bytes
-    n, h, w, c4 = raw.shape
-    c = c4 // 4
-    q = raw.reshape(n, h, w, c // 16, 64)
+def unsplit_f16f8(t_nhwc: torch.Tensor) -> torch.Tensor:
+    """'f16f8' storage -> f16 part + residual part as fp32 (test-side restatement of include/wsu.h: 3 bytes per element; per pixel and
+    16-channel chunk  f16 ch 0-7 | f16 ch 8-15 | e4m3((x - f16 x) * 2^12) ch 0-15  = 48 bytes)."""
+    raw = t_nhwc.detach().cpu().contiguous().numpy().view(np.uint8)             # (N,H,W,3C) bytes
+    n, h, w, c3 = raw.shape
+    c = c3 // 3
+    q = raw.reshape(n, h, w, c // 16, 48)
     hi = q[..., :32].copy().view(np.float16).astype(np.float32)                 # (..., 16)
-    tab = _e4m3_table()
-    lo = tab[q[..., 32:48]] * 2.0 ** -12
-    x8 = tab[q[..., 48:64]] * 4.0
-    return torch.from_numpy((hi + lo).reshape(n, h, w, c).copy()), torch.from_numpy(x8.reshape(n, h, w, c).copy())
+    lo = _e4m3_table()[q[..., 32:48]] * 2.0 ** -12
+    return torch.from_numpy((hi + lo).reshape(n, h, w, c).copy())

@@ -19,8 +19,7 @@ def _w(key, shape, scale):
 @pytest.mark.parametrize("hw", [(16, 32), (24, 40), (8, 8), (36, 70)])
 def test_kernel_chain_against_split_bf16(hw):
     """fused first layer -> conv (+pool) -> conv -> transposed conv -> concat conv -> conv + head: every intermediate decodes (f16 part +
-    residual) to the fp32-storage tensor of the bf16x3 chain within the mode's error, its e4m3 copy within e4m3's 2^-4, and the head
-    output agrees to 1e-5."""
+    residual) to the fp32-storage tensor of the bf16x3 chain within the mode's error, and the head output agrees to 1e-5."""
     h, w = hw
     x = images01(2, h, w, seed=3)[1].to(DEV)
     w1, b1 = _w(f"ps/w1/{hw}", (64, 1, 3, 3), 0.5), _w(f"ps/b1/{hw}", (64,), 0.1)
@@ -40,11 +39,10 @@ def test_kernel_chain_against_split_bf16(hw):
         outs[m] = (y12, yp, y21, yu, yd, out, logit)
     for a, b in zip(outs[X3][:5], outs[F8][:5]):
         ref = a.cpu()
-        got, x8 = unsplit_f16f8(b)
+        got = unsplit_f16f8(b)
+        assert b.shape[3] * 4 == ref.shape[3] * 3                      # 3 bytes per element
         scale = max(ref.abs().max().item(), 1e-30)
         assert (got - ref).abs().max().item() <= 2e-4 * scale
-        # the e4m3 copy of every value: 4 significant bits (normal range), absolute 2^-10 * 4 below it
-        assert ((x8 - ref).abs() <= ref.abs() * 2.0 ** -4 + 2.0 ** -8 + 2e-4 * scale).all()
     assert (outs[X3][5] - outs[F8][5]).abs().max().item() <= 1e-5
     assert (outs[X3][6] - outs[F8][6]).abs().max().item() <= 1e-4 * max(outs[X3][6].abs().max().item(), 1.0)
     with pytest.raises(Exception, match="F16F8"):
@@ -52,21 +50,20 @@ def test_kernel_chain_against_split_bf16(hw):
 
 
 def test_stored_halves_are_the_documented_encoding():
-    """f16 part + e4m3 residual * 2^-12 reproduces the layer's fp32 result to ~2^-16, the residual stays within half an f16 ulp of its
-    f16 part (it is a rounding residual, not a second value), and the e4m3 copy is the value / 4 to 4 significant bits."""
+    """f16 part + e4m3 residual * 2^-12 reproduces the layer's fp32 result to ~2^-16 and the residual stays within half an f16 ulp of its
+    f16 part (it is a rounding residual, not a second value)."""
     x = images01(1, 16, 32, seed=5)[1].to(DEV)
     w1, b1 = _w("enc/w1", (64, 1, 3, 3), 0.5), _w("enc/b1", (64,), 0.1)
     w2, b2 = _w("enc/w2", (64, 64, 3, 3), 0.06), _w("enc/b2", (64,), 0.1)
     y = ops.conv3x3_fused_first(x, w1, b1, ops.pack_conv3x3(w2, F8), b2, 64, F8)
     yref = ops.conv3x3_fused_first(x, w1, b1, ops.pack_conv3x3(w2, X3), b2, 64, X3).cpu()
-    raw = y.cpu().numpy().view(np.uint8).reshape(1, 16, 32, 4, 64)
+    raw = y.cpu().numpy().view(np.uint8).reshape(1, 16, 32, 4, 48)
     hi = raw[..., :32].copy().view(np.float16).astype(np.float32).reshape(1, 16, 32, 64)
-    got, x8 = unsplit_f16f8(y)
+    got = unsplit_f16f8(y)
     scale = yref.abs().max().item()
     assert (got - yref).abs().max().item() <= 2e-4 * scale                      # the two arithmetics agree to the mode's error
     half_ulp = np.maximum(np.abs(hi) * 2.0 ** -11, 2.0 ** -25)
     assert (np.abs(got.numpy() - hi) <= half_ulp * 1.07).all()
-    assert ((x8 - got).abs() <= got.abs() * 2.0 ** -4 + 2.0 ** -8).all()
 
 
 @pytest.mark.parametrize("ns", [1, 2, 3])
@@ -108,6 +105,6 @@ def test_large_values_degrade_gracefully():
         y = ops.conv3x3_fused_first(x, w1, b1, ops.pack_conv3x3(w2, m), b2, 64, m)
         res[m] = ops.conv3x3(y, None, ops.pack_conv3x3(w3, m), b3, 64, m)
     ref = res[X3].cpu()
-    got, _ = unsplit_f16f8(res[F8])
+    got = unsplit_f16f8(res[F8])
     assert torch.isfinite(got).all()
     assert (got - ref).abs().max().item() <= 2.0 ** -9 * ref.abs().max().item()

@@ -52,6 +52,7 @@ template <int NW> struct Shape {
     static constexpr int W_VEC = (W_ITEMS + NT - 1) / NT;
     static constexpr int IN_VEC = (IN_ITEMS + NT - 1) / NT;
     static constexpr int IN_VEC3 = (NPIX_IN * 2 + NT - 1) / NT;   // BF16X3 items of 32 B
+    static constexpr int IN_VEC48 = (NPIX_IN * 3 + NT - 1) / NT;  // F16F8: a stored chunk is 3 x 16 B (the 4th granule plane is derived)
     static constexpr int ST_IN = IN_VEC > 2 * IN_VEC3 ? IN_VEC : 2 * IN_VEC3;
 };
 
@@ -94,7 +95,7 @@ __device__ __forceinline__ void stage_load(const ConvArgs& a, int cb, int c, int
     constexpr int ESZ = Epi<MODE>::ESZ;
     constexpr int CK = (MODE == WSU_MODE_BF16) ? 32 : 16;
     constexpr bool SPLIT_HERE = MODE == WSU_MODE_BF16X3 && !PS;     // fp32 in HBM, split while committing (2 items of 32 B per pixel)
-    constexpr int NLOOP = SPLIT_HERE ? Shape<NW>::IN_VEC3 : Shape<NW>::IN_VEC;
+    constexpr int NLOOP = SPLIT_HERE ? Shape<NW>::IN_VEC3 : (MODE == WSU_MODE_F16F8 ? Shape<NW>::IN_VEC48 : Shape<NW>::IN_VEC);
     const char* src; int csrc, ch0;
     if (c < a.nch1) { src = a.x1; csrc = a.c1; ch0 = c * CK; }
     else            { src = a.x2; csrc = a.c2; ch0 = (c - a.nch1) * CK; }
@@ -110,6 +111,11 @@ __device__ __forceinline__ void stage_load(const ConvArgs& a, int cb, int c, int
                 v0 = g[0]; v1 = g[1];
             }
             st_in[2 * j] = v0; st_in[2 * j + 1] = v1;
+        } else if constexpr (MODE == WSU_MODE_F16F8) {
+            const int sub = (tid + j * NT) % 3;                  // 48 stored bytes per pixel and chunk: f16 0-7 | f16 8-15 | residuals
+            u32x4 v = mk_u4(0, 0, 0, 0);
+            if (p >= 0) v = *reinterpret_cast<const u32x4*>(src + ((size_t)p * csrc + ch0) * 3 + sub * 16);
+            st_in[j] = v;
         } else {
             const int sub = (tid + j * NT) & 3;
             u32x4 v = mk_u4(0, 0, 0, 0);
@@ -221,7 +227,7 @@ __device__ __forceinline__ void stage_commit(char* smem, int tid, const int (&pi
     constexpr int NT = Shape<NW>::NT, W_VEC = Shape<NW>::W_VEC;
     constexpr int PLANE_IN = Shape<NW>::PLANE_IN, LDS_IN = Shape<NW>::LDS_IN;
     constexpr bool SPLIT_HERE = MODE == WSU_MODE_BF16X3 && !PS;
-    constexpr int NLOOP = SPLIT_HERE ? Shape<NW>::IN_VEC3 : Shape<NW>::IN_VEC;
+    constexpr int NLOOP = SPLIT_HERE ? Shape<NW>::IN_VEC3 : (MODE == WSU_MODE_F16F8 ? Shape<NW>::IN_VEC48 : Shape<NW>::IN_VEC);
 #pragma unroll
     for (int j = 0; j < NLOOP; ++j) {
         if (pixidx[j] != -2) {
@@ -230,6 +236,12 @@ __device__ __forceinline__ void stage_commit(char* smem, int tid, const int (&pi
                 wsu_split8(__builtin_bit_cast(f32x4, st_in[2 * j]), __builtin_bit_cast(f32x4, st_in[2 * j + 1]), hi, lo);
                 *reinterpret_cast<u32x4*>(smem + ldsoff[j]) = hi;
                 *reinterpret_cast<u32x4*>(smem + ldsoff[j] + 2 * PLANE_IN) = lo;
+            } else if constexpr (MODE == WSU_MODE_F16F8) {
+                *reinterpret_cast<u32x4*>(smem + ldsoff[j]) = st_in[j];
+                if (ldsoff[j] < 2 * PLANE_IN) {                  // an f16 piece: its 8 e4m3 copies go to half of the pixel's slot in plane 3
+                    const int half = ldsoff[j] >= PLANE_IN ? 1 : 0;
+                    *reinterpret_cast<u32x2*>(smem + 3 * PLANE_IN + (ldsoff[j] - half * PLANE_IN) + half * 8) = wsu_f16x8_to_fp8(st_in[j]);
+                }
             } else {
                 *reinterpret_cast<u32x4*>(smem + ldsoff[j]) = st_in[j];
             }
@@ -241,16 +253,16 @@ __device__ __forceinline__ void stage_commit(char* smem, int tid, const int (&pi
         if (W_ITEMS % NT == 0 || tid + k * NT < W_ITEMS) wdst[tid + k * NT] = st_w[k];
 }
 
-// F16F8 stores from the fp32 [pixel][channel] LDS tile.  The 4 x 16 B of a (pixel, 16-channel chunk) are produced by one thread, so
+// F16F8 stores from the fp32 [pixel][channel] LDS tile.  The 3 x 16 B of a (pixel, 16-channel chunk) are produced by one thread, so
 // storing them directly would put 16 B into every 64 B per instruction (half-empty write requests: measured +11 % on the store-heavy
-// first layer).  Instead the tile is encoded IN PLACE (the encoded chunk has the size of its fp32 source) and then copied out with 16
-// consecutive lanes per pixel: every store instruction writes whole 256-byte pixel rows.  The fused 2x2 max-pool reads the fp32
+// first layer).  Instead the tile is encoded IN PLACE (an encoded chunk fits in its fp32 source) and then copied out with 12
+// consecutive lanes per pixel: every store instruction writes whole 192-byte pixel rows.  The fused 2x2 max-pool reads the fp32
 // tile first and stores its (4x smaller) output directly.
 template <int NT, int TH, int STRIDE>
 __device__ __forceinline__ void store_f16f8(const ConvArgs& a, char* smem, int tid, int n, int y0, int x0, int cglob, char* ydst, int ych, int ycoff) {
     // fused 2x2 max-pool: one (pooled pixel, chunk) item per thread, encoded into registers now, staged and stored after the main tile
     static_assert((TH / 2) * (TW / 2) * 4 <= NT, "one pooled item per thread");
-    u32x4 p_hi0, p_hi1, p_lo8, p_x8;
+    u32x4 p_hi0, p_hi1, p_lo8;
     const bool pool_item = a.ypool && tid < (TH / 2) * (TW / 2) * 4;
     if (pool_item) {
         const int pp = tid >> 2, j = tid & 3;
@@ -269,40 +281,41 @@ __device__ __forceinline__ void store_f16f8(const ConvArgs& a, char* smem, int t
                 if (q3[e] > m3[e] || q3[e] != q3[e]) m3[e] = q3[e];
             }
         }
-        wsu_split16_f16f8(m0, m1, m2, m3, p_hi0, p_hi1, p_lo8, p_x8);
+        wsu_split16_f16f8(m0, m1, m2, m3, p_hi0, p_hi1, p_lo8);
     }
+    // piece p (0..11) of a pixel's 192 stored bytes = chunk p / 3, 16-byte piece p % 3; in the LDS tile a chunk keeps its 64-byte slot
     if (ydst) {
         __syncthreads();                                               // pool / head readers of the fp32 tile are done
         for (int i = tid; i < TH * TW * 4; i += NT) {
             u32x4* row = reinterpret_cast<u32x4*>(smem + (i >> 2) * STRIDE + (i & 3) * 64);
-            u32x4 hi0, hi1, lo8, x8;
+            u32x4 hi0, hi1, lo8;
             wsu_split16_f16f8(__builtin_bit_cast(f32x4, row[0]), __builtin_bit_cast(f32x4, row[1]), __builtin_bit_cast(f32x4, row[2]),
-                              __builtin_bit_cast(f32x4, row[3]), hi0, hi1, lo8, x8);
-            row[0] = hi0; row[1] = hi1; row[2] = lo8; row[3] = x8;
+                              __builtin_bit_cast(f32x4, row[3]), hi0, hi1, lo8);
+            row[0] = hi0; row[1] = hi1; row[2] = lo8;
         }
         __syncthreads();
-        for (int i = tid; i < TH * TW * 16; i += NT) {
-            const int px = i >> 4, piece = i & 15;
+        for (int i = tid; i < TH * TW * 12; i += NT) {
+            const int px = i / 12, piece = i - 12 * px;
             const int r = px / TW, c = px % TW;
             if (y0 + r < a.h && x0 + c < a.w)
-                *reinterpret_cast<u32x4*>(ydst + (((size_t)(n * a.h + y0 + r) * a.w + x0 + c) * ych + ycoff) * 4 + piece * 16) =
-                    *reinterpret_cast<const u32x4*>(smem + px * STRIDE + piece * 16);
+                *reinterpret_cast<u32x4*>(ydst + (((size_t)(n * a.h + y0 + r) * a.w + x0 + c) * ych + ycoff) * 3 + piece * 16) =
+                    *reinterpret_cast<const u32x4*>(smem + px * STRIDE + (piece / 3) * 64 + (piece % 3) * 16);
         }
     }
     if (a.ypool) {
         __syncthreads();                                               // the tile has been read out (or was never needed): reuse its first rows
         if (pool_item) {
             u32x4* row = reinterpret_cast<u32x4*>(smem + (tid >> 2) * STRIDE + (tid & 3) * 64);
-            row[0] = p_hi0; row[1] = p_hi1; row[2] = p_lo8; row[3] = p_x8;
+            row[0] = p_hi0; row[1] = p_hi1; row[2] = p_lo8;
         }
         __syncthreads();
         const int hp = a.h >> 1, wp2 = a.w >> 1;
-        for (int i = tid; i < (TH / 2) * (TW / 2) * 16; i += NT) {
-            const int pp = i >> 4, piece = i & 15;
+        for (int i = tid; i < (TH / 2) * (TW / 2) * 12; i += NT) {
+            const int pp = i / 12, piece = i - 12 * pp;
             const int gy = (y0 >> 1) + pp / (TW / 2), gx = (x0 >> 1) + pp % (TW / 2);
             if (gy < hp && gx < wp2)
-                *reinterpret_cast<u32x4*>(a.ypool + (((size_t)(n * hp + gy) * wp2 + gx) * a.cout + cglob) * 4 + piece * 16) =
-                    *reinterpret_cast<const u32x4*>(smem + pp * STRIDE + piece * 16);
+                *reinterpret_cast<u32x4*>(a.ypool + (((size_t)(n * hp + gy) * wp2 + gx) * a.cout + cglob) * 3 + piece * 16) =
+                    *reinterpret_cast<const u32x4*>(smem + pp * STRIDE + (piece / 3) * 64 + (piece % 3) * 16);
         }
     }
 }
@@ -504,14 +517,15 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 4 : 2) void conv3x3_kernel(const
     int pixidx[IN_VEC];      // linear pixel index (n*H + y)*W + x of the source, -1 = zero, -2 = no item
     int ldsoff[IN_VEC];
     constexpr bool SPLIT_HERE = (MODE == WSU_MODE_BF16X3 || MODE == WSU_MODE_F16F8) && !PS;     // F1 computes its input and always splits here
-    static_assert(MODE != WSU_MODE_F16F8 || ((PS != F1) && NW == 8 && !S16), "F16F8: stored-split or self-computed input, 8-wave shape");
-    constexpr int NITEMS = SPLIT_HERE ? NPIX_IN * 2 : NPIX_IN * 4;
-    constexpr int NLOOP = SPLIT_HERE ? Shape<NW>::IN_VEC3 : IN_VEC;
+    static_assert(MODE != WSU_MODE_F16F8 || ((PS != F1) && (NW == 8 || NW == 4) && !S16), "F16F8: stored-split or self-computed input");
+    constexpr bool STORED48 = MODE == WSU_MODE_F16F8 && PS;         // 3 stored pieces of 16 B per pixel and chunk
+    constexpr int NITEMS = SPLIT_HERE ? NPIX_IN * 2 : (STORED48 ? NPIX_IN * 3 : NPIX_IN * 4);
+    constexpr int NLOOP = SPLIT_HERE ? Shape<NW>::IN_VEC3 : (STORED48 ? Shape<NW>::IN_VEC48 : IN_VEC);
 #pragma unroll
     for (int j = 0; j < NLOOP; ++j) {
         const int i = tid + j * NT;
-        const int pix = SPLIT_HERE ? (i >> 1) : (i >> 2);
-        const int sub = SPLIT_HERE ? (i & 1) : (i & 3);
+        const int pix = SPLIT_HERE ? (i >> 1) : (STORED48 ? i / 3 : (i >> 2));
+        const int sub = SPLIT_HERE ? (i & 1) : (STORED48 ? i - 3 * pix : (i & 3));
         const int r = pix / IW, c = pix - r * IW;
         int yy = y0 - 1 + r, xx = x0 - 1 + c;
         int p;
@@ -647,25 +661,39 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 4 : 2) void conv3x3_kernel(const
                 constexpr bool single = 2 * tp + 1 >= 9;
                 const int aoff = ((hh ? t1 : t0) * 4 + 2) * 64 * 16;
                 const int boff = 2 * PLANE_IN + (hh ? ((t1 / 3) * IW + t1 % 3) : ((t0 / 3) * IW + t0 % 3)) * 16;
-                u32x4 a0 = *reinterpret_cast<const u32x4*>(ldsA + aoff), a1 = *reinterpret_cast<const u32x4*>(ldsA + aoff + 64 * 16);
-                u32x4 b0[2], b1[2];
+                u32x4 a0[MT], a1[MT], b0[2], b1[2];
+_Pragma("unroll")
+                for (int m = 0; m < MT; ++m) {
+                    a0[m] = *reinterpret_cast<const u32x4*>(ldsA + aoff + m * 32 * 16);
+                    a1[m] = *reinterpret_cast<const u32x4*>(ldsA + aoff + 64 * 16 + m * 32 * 16);
+                }
 _Pragma("unroll")
                 for (int q = 0; q < 2; ++q) {
                     b0[q] = *reinterpret_cast<const u32x4*>(ldsB + boff + q * IW * 16);
                     b1[q] = *reinterpret_cast<const u32x4*>(ldsB + boff + PLANE_IN + q * IW * 16);
                 }
-                if (single && hh) { a0 = mk_u4(0, 0, 0, 0); a1 = a0; b0[0] = a0; b0[1] = a0; b1[0] = a0; b1[1] = a0; }
+                if (single && hh) {
+                    const u32x4 z = mk_u4(0, 0, 0, 0);
 _Pragma("unroll")
-                for (int q = 0; q < 2; ++q) wsu_mfma_f8x2(a0, a1, b0[q], b1[q], sc_a, sc_b, acc[0][q]);
+                    for (int m = 0; m < MT; ++m) { a0[m] = z; a1[m] = z; }
+                    b0[0] = z; b0[1] = z; b1[0] = z; b1[1] = z;
+                }
+_Pragma("unroll")
+                for (int m = 0; m < MT; ++m)
+_Pragma("unroll")
+                    for (int q = 0; q < 2; ++q) wsu_mfma_f8x2(a0[m], a1[m], b0[q], b1[q], sc_a, sc_b, acc[m][q]);
             };
             auto main_term = [&](auto tap_c) __attribute__((always_inline)) {
                 constexpr int tap = decltype(tap_c)::value, dy = tap / 3, dx = tap % 3;
-                const u32x4 ah = *reinterpret_cast<const u32x4*>(ldsA + ((tap * 4 + hh) * 64) * 16);
-                u32x4 bh[2];
+                u32x4 ah[MT], bh[2];
+_Pragma("unroll")
+                for (int m = 0; m < MT; ++m) ah[m] = *reinterpret_cast<const u32x4*>(ldsA + ((tap * 4 + hh) * 64 + m * 32) * 16);
 _Pragma("unroll")
                 for (int q = 0; q < 2; ++q) bh[q] = *reinterpret_cast<const u32x4*>(ldsB + hh * PLANE_IN + ((q + dy) * IW + dx) * 16);
 _Pragma("unroll")
-                for (int q = 0; q < 2; ++q) wsu_mfma_f16(ah, bh[q], acc[0][q]);
+                for (int m = 0; m < MT; ++m)
+_Pragma("unroll")
+                    for (int q = 0; q < 2; ++q) wsu_mfma_f16(ah[m], bh[q], acc[m][q]);
             };
             // scheduling fences keep the operand reads of later taps behind these instructions (128-VGPR budget: without them the
             // compiler hoists the reads and spills staging registers)
@@ -1397,7 +1425,10 @@ int launch_conv(const ConvArgs& a, hipStream_t s, bool in_split = false) {
         if (in_split) return launch_conv_nw<MODE, 8, false, false, true>(a, s);      // pre-split input: the measured default shape only
     }
     if constexpr (MODE == WSU_MODE_F16F8) {
-        return a.img ? launch_conv_nw<MODE, 8, false, true, false>(a, s) : launch_conv_nw<MODE, 8, false, false, true>(a, s);
+        if (a.img) return launch_conv_nw<MODE, 8, false, true, false>(a, s);
+        static int nw4 = -1;                                        // WSU_CONV_WAVES=4: 64 co x 64 px per wave (fewer LDS fragment reads per MFMA)
+        if (nw4 < 0) { const char* e = getenv("WSU_CONV_WAVES"); nw4 = (e && atoi(e) == 4) ? 1 : 0; }
+        return nw4 ? launch_conv_nw<MODE, 4, false, false, true>(a, s) : launch_conv_nw<MODE, 8, false, false, true>(a, s);
     } else {
     // Default = the per-tile kernel (v1): measured faster (bench conv3x3 15.8 ms vs 17.9 ms per batch-32 forward in bf16x3).
     // WSU_CONV_IMPL=pp selects the ping-pong kernel (kept for the next tuning round; profiles/r01/conv3x3_ablation.md).

@@ -34,7 +34,7 @@ __device__ __forceinline__ void ct_load(const CtArgs& a, int cb, int c, int tid,
     constexpr int CK = (MODE == WSU_MODE_BF16) ? 32 : 16;
     st_in[0] = mk_u4(0, 0, 0, 0); st_in[1] = st_in[0];
     if (has_item) {
-        const u32x4* g = reinterpret_cast<const u32x4*>(xsrc + (size_t)c * CK * ESZ);
+        const u32x4* g = reinterpret_cast<const u32x4*>(xsrc + (size_t)c * (MODE == WSU_MODE_F16F8 ? 48 : CK * ESZ));
         st_in[0] = g[0];
         if constexpr (MODE == WSU_MODE_BF16X3 && !PS) st_in[1] = g[1];
     }
@@ -53,6 +53,12 @@ __device__ __forceinline__ void ct_commit(char* smem, int tid, bool has_item, in
             *reinterpret_cast<u32x4*>(smem + ldsoff + 2 * PLANE_IN) = lo;
         } else {
             *reinterpret_cast<u32x4*>(smem + ldsoff) = st_in[0];
+            if constexpr (MODE == WSU_MODE_F16F8) {               // an f16 piece: its 8 e4m3 copies fill half of the pixel's slot in plane 3
+                if (ldsoff < 2 * PLANE_IN) {
+                    const int half = ldsoff >= PLANE_IN ? 1 : 0;
+                    *reinterpret_cast<u32x2*>(smem + 3 * PLANE_IN + (ldsoff - half * PLANE_IN) + half * 8) = wsu_f16x8_to_fp8(st_in[0]);
+                }
+            }
         }
     }
     u32x4* wdst = reinterpret_cast<u32x4*>(smem + LDS_IN);
@@ -77,9 +83,10 @@ __global__ __launch_bounds__(NT, 2) void convt2x2_kernel(const CtArgs a) {
 
     // staging plan: F32/BF16: 256 items (pixel, granule); BF16X3: 128 items (pixel, half) of 32 B
     constexpr bool SPLIT_HERE = MODE == WSU_MODE_BF16X3 && !PS;       // PS: pre-split input, 4 granule items per pixel like F32 / BF16
-    constexpr int NITEMS = SPLIT_HERE ? NPIX * 2 : NPIX * 4;
-    const int pix = SPLIT_HERE ? (tid >> 1) : (tid >> 2);
-    const int sub = SPLIT_HERE ? (tid & 1) : (tid & 3);
+    constexpr bool STORED48 = MODE == WSU_MODE_F16F8;                  // 3 stored pieces of 16 B per pixel and chunk (plane 3 is derived)
+    constexpr int NITEMS = SPLIT_HERE ? NPIX * 2 : (STORED48 ? NPIX * 3 : NPIX * 4);
+    const int pix = SPLIT_HERE ? (tid >> 1) : (STORED48 ? tid / 3 : (tid >> 2));
+    const int sub = SPLIT_HERE ? (tid & 1) : (STORED48 ? tid - 3 * pix : (tid & 3));
     const int pr = (pix / TW) % TH, pc = pix % TW;
     const int yy = min(y0 + pr, a.h - 1), xx = min(x0 + pc, a.w - 1);   // clamp: out-of-image lanes are never stored
     const size_t pidx = (size_t)(n * a.h + yy) * a.w + xx;
@@ -87,7 +94,7 @@ __global__ __launch_bounds__(NT, 2) void convt2x2_kernel(const CtArgs a) {
     const int ldsoff = sub * PLANE_IN + (pix % NPIX) * 16;
 
     u32x4 st_in[2]; u32x4 st_w[W_VEC];
-    const char* xsrc = a.x + pidx * a.cin * ESZ + sub * (SPLIT_HERE ? 32 : 16);
+    const char* xsrc = a.x + pidx * a.cin * (STORED48 ? 3 : ESZ) + sub * (SPLIT_HERE ? 32 : 16);
 
     const int wv = tid >> 6, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;   // wave = sub-position a*2+b
     f32x16 acc[2][2];
@@ -202,23 +209,23 @@ __global__ __launch_bounds__(NT, 2) void convt2x2_kernel(const CtArgs a) {
     __syncthreads();
     const int oh = 2 * a.h, ow = 2 * a.w;
     if constexpr (MODE == WSU_MODE_F16F8) {
-        // encode the tile in place (a 16-channel chunk keeps its 64 bytes), then copy out with 16 consecutive lanes per output pixel so
-        // that every store instruction writes whole 256-byte pixel rows (see store_f16f8 in conv3x3.hip)
+        // encode the tile in place (a 16-channel chunk keeps its 64-byte slot, 48 bytes used), then copy out with 12 consecutive lanes per
+        // output pixel so that every store instruction writes whole 192-byte pixel rows (see store_f16f8 in conv3x3.hip)
         for (int i = tid; i < 4 * NPIX * 4; i += NT) {
             u32x4* row = reinterpret_cast<u32x4*>(smem + (i >> 2) * STRIDE + (i & 3) * 64);
-            u32x4 hi0, hi1, lo8, x8;
+            u32x4 hi0, hi1, lo8;
             wsu_split16_f16f8(__builtin_bit_cast(f32x4, row[0]), __builtin_bit_cast(f32x4, row[1]), __builtin_bit_cast(f32x4, row[2]),
-                              __builtin_bit_cast(f32x4, row[3]), hi0, hi1, lo8, x8);
-            row[0] = hi0; row[1] = hi1; row[2] = lo8; row[3] = x8;
+                              __builtin_bit_cast(f32x4, row[3]), hi0, hi1, lo8);
+            row[0] = hi0; row[1] = hi1; row[2] = lo8;
         }
         __syncthreads();
-        for (int i = tid; i < 4 * NPIX * 16; i += NT) {
-            const int opx = i >> 4, piece = i & 15;
+        for (int i = tid; i < 4 * NPIX * 12; i += NT) {
+            const int opx = i / 12, piece = i - 12 * opx;
             const int r = opx / (2 * TW), c = opx % (2 * TW);
             const int oy = 2 * y0 + r, ox = 2 * x0 + c;
             if (oy < oh && ox < ow)
-                *reinterpret_cast<u32x4*>(a.y + (((size_t)(n * oh + oy) * ow + ox) * a.cout + cb * WSU_COB) * 4 + piece * 16) =
-                    *reinterpret_cast<const u32x4*>(smem + opx * STRIDE + piece * 16);
+                *reinterpret_cast<u32x4*>(a.y + (((size_t)(n * oh + oy) * ow + ox) * a.cout + cb * WSU_COB) * 3 + piece * 16) =
+                    *reinterpret_cast<const u32x4*>(smem + opx * STRIDE + (piece / 3) * 64 + (piece % 3) * 16);
         }
         return;
     }

@@ -32,7 +32,8 @@ int wsu_check_launch(const char* what);
 //   F32    : 16 channels, granule g = channels 4g..4g+3 (fp32)
 //   BF16   : 32 channels, granule g = channels 8g..8g+7 (bf16)
 //   BF16X3 : 16 channels, granules 0,1 = bf16 hi of channels 0..7 / 8..15, granules 2,3 = bf16 lo
-//   F16F8  : 16 channels, granules 0,1 = f16 of channels 0..7 / 8..15, granule 2 = e4m3 residuals, granule 3 = e4m3 copies (below)
+//   F16F8  : 16 channels, granules 0,1 = f16 of channels 0..7 / 8..15, granule 2 = e4m3 residuals, granule 3 = e4m3 copies (below).
+//            In HBM a chunk is 48 bytes (granules 0-2): granule 3 is derived from granules 0,1 while staging.
 #define WSU_GRAN 4
 #define WSU_COB 64            // output channels per workgroup
 __host__ __device__ inline int wsu_chunk_channels(int mode) { return mode == WSU_MODE_BF16 ? 32 : 16; }
@@ -106,13 +107,26 @@ __device__ __forceinline__ void wsu_split4_f16f8(const f32x4& v, float div_lo, f
     x = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(x, __builtin_amdgcn_fmed3f(v[2], -lim_x, lim_x), __builtin_amdgcn_fmed3f(v[3], -lim_x, lim_x), div_x, true);
     lo = __builtin_bit_cast(uint32_t, l); x8 = __builtin_bit_cast(uint32_t, x);
 }
-// 16 channels of one pixel -> the 4 x 16 B of an F16F8 chunk
+// 16 channels of one pixel -> the 3 x 16 B of a stored F16F8 chunk (the e4m3 copy is derived from the f16 part while staging)
 __device__ __forceinline__ void wsu_split16_f16f8(const f32x4& q0, const f32x4& q1, const f32x4& q2, const f32x4& q3,
-                                                  u32x4& hi0, u32x4& hi1, u32x4& lo8, u32x4& x8) {
+                                                  u32x4& hi0, u32x4& hi1, u32x4& lo8) {
     uint32_t a0, a1, a2, a3, a4, a5, a6, a7, l0, l1, l2, l3, x0, x1, x2, x3;
     wsu_split4_f16f8(q0, WSU_F8_XLO_DIV, WSU_F8_X_DIV, a0, a1, l0, x0); wsu_split4_f16f8(q1, WSU_F8_XLO_DIV, WSU_F8_X_DIV, a2, a3, l1, x1);
     wsu_split4_f16f8(q2, WSU_F8_XLO_DIV, WSU_F8_X_DIV, a4, a5, l2, x2); wsu_split4_f16f8(q3, WSU_F8_XLO_DIV, WSU_F8_X_DIV, a6, a7, l3, x3);
-    hi0 = mk_u4(a0, a1, a2, a3); hi1 = mk_u4(a4, a5, a6, a7); lo8 = mk_u4(l0, l1, l2, l3); x8 = mk_u4(x0, x1, x2, x3);
+    hi0 = mk_u4(a0, a1, a2, a3); hi1 = mk_u4(a4, a5, a6, a7); lo8 = mk_u4(l0, l1, l2, l3);
+}
+// 8 stored f16 values -> their 8 e4m3 copies e4m3(x / 4) (LDS plane 3 of a chunk): clamp to the e4m3 range on the packed f16 pipe
+// (the conversion overflows to NaN), then v_cvt_scalef32_pk_fp8_f16: 3 instructions per pair of values.
+__device__ __forceinline__ u32x2 wsu_f16x8_to_fp8(const u32x4& h) {
+    const _Float16 m = (_Float16)1792.f;
+    const f16x8 lim = {m, m, m, m, m, m, m, m};
+    const f16x8 c = __builtin_elementwise_max(__builtin_elementwise_min(__builtin_bit_cast(f16x8, h), lim), -lim);
+    i16x2 lo = {0, 0}, hi = {0, 0};
+    lo = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(lo, __builtin_shufflevector(c, c, 0, 1), WSU_F8_X_DIV, false);
+    lo = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(lo, __builtin_shufflevector(c, c, 2, 3), WSU_F8_X_DIV, true);
+    hi = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(hi, __builtin_shufflevector(c, c, 4, 5), WSU_F8_X_DIV, false);
+    hi = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(hi, __builtin_shufflevector(c, c, 6, 7), WSU_F8_X_DIV, true);
+    return mk_u2(__builtin_bit_cast(uint32_t, lo), __builtin_bit_cast(uint32_t, hi));
 }
 // hi*hi on the f16 pipe; (a8, b8) = {block 0: e4m3(w) x residual(x), block 1: residual(w) x e4m3(x)} on the block-scaled fp8 pipe.
 // Operand layout of the scaled instruction (tools/mfma_scale_layout_probe.hip): registers 0-3 of every lane are scale block 0, registers

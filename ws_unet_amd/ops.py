@@ -66,9 +66,23 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
 
 
 def act_dtype(mode: int) -> torch.dtype:
-    """dtype of an activation tensor's allocation.  'bf16x3s' / 'f16f8' tensors are float32-shaped (4 bytes per element) but hold the
-    split encodings of include/wsu.h (bf16 hi / lo halves; f16 + two e4m3 bytes): only libwsu kernels read them."""
+    """dtype of an activation tensor's allocation.  'bf16x3s' / 'f16f8' tensors are float32-typed buffers holding the split encodings of
+    include/wsu.h (bf16 hi / lo halves, 4 bytes per element; f16 + one e4m3 residual, 3 bytes per element -> ``store_channels``):
+    only libwsu kernels read them."""
     return torch.bfloat16 if mode == MODE_BF16 else torch.float32
+
+
+def store_channels(c: int, mode: int) -> int:
+    """Last dimension of the float32-shaped allocation holding ``c`` channels: 'f16f8' keeps 3 bytes per element."""
+    return c * 3 // 4 if mode == MODE_F16F8 else c
+
+
+def logical_channels(t: torch.Tensor, mode: int) -> int:
+    return t.shape[3] * 4 // 3 if mode == MODE_F16F8 else t.shape[3]
+
+
+def _esz(mode: int) -> int:
+    return 2 if mode == MODE_BF16 else (3 if mode == MODE_F16F8 else 4)
 
 
 def weight_mode(mode: int) -> int:
@@ -136,19 +150,20 @@ def conv3x3(x1: torch.Tensor, x2: Optional[torch.Tensor], w_packed: torch.Tensor
     """Returns y, or (y, y_pool[, idx]) when ``pool``."""
     lib = _lib.load()
     _dev_check(x1, x2, w_packed, bias)
-    n, h, w, c1 = x1.shape
-    c2 = 0 if x2 is None else x2.shape[3]
+    n, h, w = x1.shape[:3]
+    c1 = logical_channels(x1, mode)
+    c2 = 0 if x2 is None else logical_channels(x2, mode)
     dt = act_dtype(mode)
     assert x1.dtype == dt and (x2 is None or (x2.dtype == dt and x2.shape[:3] == x1.shape[:3]))
-    y = torch.empty((n, h, w, cout), dtype=dt, device=x1.device)
+    y = torch.empty((n, h, w, store_channels(cout, mode)), dtype=dt, device=x1.device)
     yp = idx = None
     if pool:
-        yp = torch.empty((n, h // 2, w // 2, cout), dtype=dt, device=x1.device)
+        yp = torch.empty((n, h // 2, w // 2, store_channels(cout, mode)), dtype=dt, device=x1.device)
         if pool_idx:
             idx = torch.empty((n, h // 2, w // 2, cout), dtype=torch.uint8, device=x1.device)
-    esz = 2 if mode == MODE_BF16 else 4
+    esz = _esz(mode)
     meta = {"flops": 2.0 * 9 * (c1 + c2) * cout * n * h * w,
-            "bytes": float(n * h * w * (c1 + c2 + cout) * esz + (n * h * w // 4 * cout * esz if pool else 0) + 9 * (c1 + c2) * cout * esz)}
+            "bytes": float(n * h * w * (c1 + c2 + cout) * esz + (n * h * w // 4 * cout * esz if pool else 0) + 9 * (c1 + c2) * cout * max(esz, 4 if mode == MODE_F16F8 else 0))}
     check(_launch("conv3x3", meta, lambda: lib.wsu_conv3x3_fwd(
         x1.data_ptr(), _ptr(x2), w_packed.data_ptr(), _ptr(bias), y.data_ptr(), _ptr(yp), _ptr(idx),
         n, h, w, c1, c2, cout, mode, int(relu), int(pad_zero), _stream())), "wsu_conv3x3_fwd")
@@ -164,15 +179,16 @@ def conv3x3_head(x1: torch.Tensor, x2: Optional[torch.Tensor], w_packed: torch.T
     lib = _lib.load()
     hw2 = head_w.detach().reshape(head_w.shape[0], -1)
     _dev_check(x1, x2, w_packed, bias, hw2, head_b)
-    n, h, w, c1 = x1.shape
-    c2 = 0 if x2 is None else x2.shape[3]
+    n, h, w = x1.shape[:3]
+    c1 = logical_channels(x1, mode)
+    c2 = 0 if x2 is None else logical_channels(x2, mode)
     cout, hc = hw2.shape[1], hw2.shape[0]
     out = torch.empty((n, hc, h, w), dtype=torch.float32, device=x1.device)
     logit = torch.empty_like(out) if want_logit else None
-    y = torch.empty((n, h, w, cout), dtype=act_dtype(mode), device=x1.device) if want_y else None
-    esz = 2 if mode == MODE_BF16 else 4
+    y = torch.empty((n, h, w, store_channels(cout, mode)), dtype=act_dtype(mode), device=x1.device) if want_y else None
+    esz = _esz(mode)
     meta = {"flops": 2.0 * 9 * (c1 + c2) * cout * n * h * w,
-            "bytes": float(n * h * w * ((c1 + c2) * esz + hc * 4) + 9 * (c1 + c2) * cout * esz)}
+            "bytes": float(n * h * w * ((c1 + c2) * esz + hc * 4) + 9 * (c1 + c2) * cout * max(esz, 4 if mode == MODE_F16F8 else 0))}
     check(_launch("conv3x3", meta, lambda: lib.wsu_conv3x3_head_fwd(
         x1.data_ptr(), _ptr(x2), w_packed.data_ptr(), _ptr(bias), _ptr(y), hw2.data_ptr(), _ptr(head_b), out.data_ptr(), _ptr(logit),
         n, h, w, c1, c2, cout, hc, mode, _stream())), "wsu_conv3x3_head_fwd")
@@ -192,12 +208,12 @@ def conv3x3_fused_first(x_nchw: torch.Tensor, w1: torch.Tensor, b1: Optional[tor
     _dev_check(x_nchw, w1, b1, w_packed, bias)
     n, cin, h, w = x_nchw.shape
     assert cin == 1 and tuple(w1.shape) == (64, 1, 3, 3) and x_nchw.dtype == torch.float32
-    y = torch.empty((n, h, w, cout), dtype=act_dtype(mode), device=x_nchw.device)
-    yp = torch.empty((n, h // 2, w // 2, cout), dtype=act_dtype(mode), device=x_nchw.device) if pool else None
+    y = torch.empty((n, h, w, store_channels(cout, mode)), dtype=act_dtype(mode), device=x_nchw.device)
+    yp = torch.empty((n, h // 2, w // 2, store_channels(cout, mode)), dtype=act_dtype(mode), device=x_nchw.device) if pool else None
     idx = torch.empty((n, h // 2, w // 2, cout), dtype=torch.uint8, device=x_nchw.device) if (pool and pool_idx) else None
-    esz = 2 if mode == MODE_BF16 else 4
+    esz = _esz(mode)
     meta = {"flops": 2.0 * 9 * 64 * cout * n * h * w,
-            "bytes": float(n * h * w * (4 + cout * esz) + 9 * 64 * cout * esz + (n * (h // 2) * (w // 2) * cout * esz if pool else 0))}
+            "bytes": float(n * h * w * (4 + cout * esz) + 9 * 64 * cout * max(esz, 4 if mode == MODE_F16F8 else 0) + (n * (h // 2) * (w // 2) * cout * esz if pool else 0))}
     check(_launch("conv3x3", meta, lambda: lib.wsu_conv3x3_fused_first_fwd(
         x_nchw.data_ptr(), w1.data_ptr(), _ptr(b1), w_packed.data_ptr(), _ptr(bias), y.data_ptr(), _ptr(yp), _ptr(idx),
         n, h, w, cout, mode, int(relu), _stream())), "wsu_conv3x3_fused_first_fwd")
@@ -279,10 +295,11 @@ def maxpool2x2(x: torch.Tensor, mode: int, want_idx: bool = False):
 def convt2x2(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor], cout: int, mode: int) -> torch.Tensor:
     lib = _lib.load()
     _dev_check(x, w_packed, bias)
-    n, h, w, cin = x.shape
-    y = torch.empty((n, 2 * h, 2 * w, cout), dtype=x.dtype, device=x.device)
-    esz = 2 if mode == MODE_BF16 else 4
-    meta = {"flops": 2.0 * 4 * cin * cout * n * h * w, "bytes": float(n * h * w * (cin + 4 * cout) * esz + 4 * cin * cout * esz)}
+    n, h, w = x.shape[:3]
+    cin = logical_channels(x, mode)
+    y = torch.empty((n, 2 * h, 2 * w, store_channels(cout, mode)), dtype=x.dtype, device=x.device)
+    esz = _esz(mode)
+    meta = {"flops": 2.0 * 4 * cin * cout * n * h * w, "bytes": float(n * h * w * (cin + 4 * cout) * esz + 4 * cin * cout * 4)}
     check(_launch("convt2x2", meta, lambda: lib.wsu_convt2x2_fwd(
         x.data_ptr(), w_packed.data_ptr(), _ptr(bias), y.data_ptr(), n, h, w, cin, cout, mode, _stream())), "wsu_convt2x2_fwd")
     return y
