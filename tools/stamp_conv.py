@@ -9,7 +9,7 @@ import numpy as np, torch
 from ws_unet_amd import ops, _lib
 mode, cin, cout, hw, n = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
 m = ops.mode_id(mode); dt = ops.act_dtype(m)
-x = torch.rand(n, hw, hw, cin, device="cuda").to(dt)
+x = torch.rand(n, hw, hw, ops.store_channels(cin, m), device="cuda").to(dt)
 w = torch.randn(cout, cin, 3, 3, device="cuda") * 0.05
 wp = ops.pack_conv3x3(w, m); b = torch.zeros(cout, device="cuda")
 for _ in range(3):

@@ -318,6 +318,8 @@ __device__ __forceinline__ void store_f16f8(const ConvArgs& a, char* smem, int t
                     *reinterpret_cast<const u32x4*>(smem + pp * STRIDE + (piece / 3) * 64 + (piece % 3) * 16);
         }
     }
+    WSU_STAMP(27);
+    if ((a.ablate & 512) && blockIdx.x < 2048 && threadIdx.x == 0) g_stamps[blockIdx.x * WSU_NSTAMP + 31] = __builtin_amdgcn_s_memrealtime();
 }
 
 // Everything behind the [pixel][channel] LDS tile (TH x 32 pixels, Epi<MODE>::STRIDE bytes per pixel): fused 1x1 head, coalesced
