@@ -205,6 +205,33 @@ def test_batched_iterator_prefetch_runs_one_chunk_ahead(tmp_path):
     assert [e[1][0] for e in log if e[0] == "pre"] == ["0.png", "3.png", "6.png"]
 
 
+def test_batched_iterator_submits_the_next_chunk_before_collecting(tmp_path):
+    """fn.submit / fn.collect (evaluate.py's split predict): chunk k+1 is launched before chunk k's rows are read back, rows stay in order."""
+    (tmp_path / "images").mkdir()
+    names = [f"images/{i}.png" for i in range(7)]
+    (tmp_path / "images" / "files.csv").write_text("name,height,width\n" + "".join(f"{n},8,8\n" for n in names))
+    log = []
+
+    def fn(fnames, kws, prefetched=None):                       # the unsplit form must not be used when the split one exists
+        raise AssertionError("unsplit call")
+
+    def submit(fnames, kws, prefetched=None):
+        log.append(("submit", Path(fnames[0]).name))
+        return (prefetched, kws)
+
+    def collect(handle):
+        log.append(("collect", handle[0]))
+        return [{**kw, "tag": handle[0]} for kw in handle[1]]
+
+    fn.prefetch = lambda fnames, kws: "staged:" + Path(fnames[0]).name
+    fn.submit, fn.collect = submit, collect
+    df = fabrika.precovers(iterator="batched", convert_to="pandas", ignore_missing=False, batch_size=3)(fn)(tmp_path)
+    assert df["name"].tolist() == sorted(names)
+    assert df["tag"].tolist() == ["staged:0.png"] * 3 + ["staged:3.png"] * 3 + ["staged:6.png"]
+    assert log == [("submit", "0.png"), ("submit", "3.png"), ("collect", "staged:0.png"), ("submit", "6.png"),
+                   ("collect", "staged:3.png"), ("collect", "staged:6.png")]
+
+
 def _pair_dataset(root, n=10, size=16):
     from PIL import Image
     from ws_unet_amd import formula

@@ -169,10 +169,15 @@ def load_planes_u8(fnames, imread: typing.Callable = imread4_u8) -> typing.Optio
             if len(_PINNED) > 8:
                 _PINNED.clear()
             pin = torch.cuda.is_available()
-            _PINNED[key] = [[torch.empty(key, dtype=torch.uint8, pin_memory=pin) for _ in range(2)], 0]
+            _PINNED[key] = {"bufs": [torch.empty(key, dtype=torch.uint8, pin_memory=pin) for _ in range(3)], "next": 0,
+                            "uploaded": [None, None, None]}
         slot = _PINNED[key]
-        buf = slot[0][slot[1]]                               # two buffers: chunk k+1 is decoded while chunk k is uploaded / in use
-        slot[1] ^= 1
+        i = slot["next"]                                     # three buffers: chunk k+1 is decoded while chunk k is uploaded and chunk
+        slot["next"] = (i + 1) % 3                           # k-1 may still wait in the stream (submit / collect pipelining)
+        if slot["uploaded"][i] is not None:                  # the upload that last read this buffer (mark_uploaded)
+            slot["uploaded"][i].synchronize()
+            slot["uploaded"][i] = None
+        buf = slot["bufs"][i]
         try:
             read_luma_batch(fnames, out=buf.numpy())
         except ValueError:                                   # ragged shapes
@@ -184,26 +189,86 @@ def load_planes_u8(fnames, imread: typing.Callable = imread4_u8) -> typing.Optio
     return torch.from_numpy(np.stack(imgs))
 
 
+def mark_uploaded(planes: torch.Tensor) -> None:
+    """Record, for a pinned buffer handed out by load_planes_u8, the point in the current stream after which it may be overwritten."""
+    if not planes.is_pinned():
+        return
+    for slot in _PINNED.values():
+        for i, b in enumerate(slot["bufs"]):
+            if b.data_ptr() == planes.data_ptr():
+                ev = torch.cuda.Event()
+                ev.record()
+                slot["uploaded"][i] = ev
+
+
+def submit_unet_batch(fnames, *, model: torch.nn.Module, imread: typing.Callable = imread4_u8, prefetched=None):
+    """First half of predict_unet_batch: upload + launch, nothing waits for the GPU.  Returns a handle for collect_unet_batch
+    (ragged / non-512 chunks go through the per-image path right here and the handle carries their rows)."""
+    planes = prefetched[0] if prefetched is not None else load_planes_u8(fnames, imread)
+    if planes is None or tuple(planes.shape[1:]) != (512, 512):
+        # CenterCrop(512) would change the geometry; only the per-image path defines what happens then
+        res = [predict_unet(f, model, imread=imread4_f32) for f in fnames]
+        return ("host", np.array([[r["beta_hat"], r["l1"]] for r in res], dtype=np.float32))
+    x_u8 = planes.to(_model_device(model), non_blocking=True)
+    mark_uploaded(planes)
+    beta, l1 = predict_u8_batch(x_u8, model)
+    return ("device", torch.stack([beta, l1], dim=1))
+
+
+def collect_unet_batch(handle) -> np.ndarray:
+    """Second half: (N, 2) float32 rows [beta_hat, l1] of a submitted chunk (waits for that chunk only)."""
+    kind, val = handle
+    return val if kind == "host" else val.cpu().numpy()
+
+
 def predict_unet_batch(fnames, kws, *, model: torch.nn.Module, imread: typing.Callable = imread4_u8, device=None,
                        prefetched=None, **_ignored):
     """Batched predict_unet for `fabrika` iterator='batched': one result dict per (fname, kw).  `prefetched`: the planes of
     this chunk if the iterator already decoded them (load_planes_u8 run one chunk ahead)."""
-    planes = prefetched[0] if prefetched is not None else load_planes_u8(fnames, imread)
-    if planes is None or tuple(planes.shape[1:]) != (512, 512):
-        # CenterCrop(512) would change the geometry; only the per-image path defines what happens then
-        return [predict_unet(f, model, imread=imread4_f32, **kw) for f, kw in zip(fnames, kws)]
-    x_u8 = planes.to(_model_device(model), non_blocking=True)
-    beta, l1 = predict_u8_batch(x_u8, model)
-    beta, l1 = beta.cpu().numpy(), l1.cpu().numpy()          # also orders the reuse of the pinned staging buffer
-    return [{**kw, "beta_hat": beta[i], "l1": l1[i]} for i, kw in enumerate(kws)]
+    rows = collect_unet_batch(submit_unet_batch(fnames, model=model, imread=imread, prefetched=prefetched))
+    return [{**kw, "beta_hat": rows[i, 0], "l1": rows[i, 1]} for i, kw in enumerate(kws)]
+
+
+def pipelined_unet_rows(chunks, model: torch.nn.Module, imread: typing.Callable = imread4_u8):
+    """(N_k, 2) rows per chunk of file names, in order, with the three stages of a chunk overlapped across chunks: decode of chunk
+    k+1 on a helper thread, upload + GPU work of chunk k queued without waiting, read-back of chunk k-1."""
+    from concurrent.futures import ThreadPoolExecutor
+    chunks = list(chunks)
+    if not chunks:
+        return
+    with ThreadPoolExecutor(max_workers=1) as ex:
+        fut = ex.submit(load_planes_u8, chunks[0], imread)
+        pending = None
+        for k, chunk in enumerate(chunks):
+            staged = (fut.result(),)
+            fut = ex.submit(load_planes_u8, chunks[k + 1], imread) if k + 1 < len(chunks) else None
+            handle = submit_unet_batch(chunk, model=model, imread=imread, prefetched=staged)
+            if pending is not None:
+                yield collect_unet_batch(pending)
+            pending = handle
+        yield collect_unet_batch(pending)
 
 
 def _drop_model_kw(fn):
+    def _clean(kws):
+        return [{k: v for k, v in kw.items() if k not in ("model", "imread", "device")} for kw in kws]
+
     def wrapped(fnames, kws, prefetched=None):
         model = kws[0]["model"]
         extra = {k: kws[0][k] for k in ("imread",) if k in kws[0]}
-        clean = [{k: v for k, v in kw.items() if k not in ("model", "imread", "device")} for kw in kws]
-        return fn(fnames, clean, model=model, prefetched=prefetched, **extra)
+        return fn(fnames, _clean(kws), model=model, prefetched=prefetched, **extra)
+
+    # split form for the iterator's pipelining: submit(chunk k+1) is called before collect(chunk k)
+    def submit(fnames, kws, prefetched=None):
+        extra = {k: kws[0][k] for k in ("imread",) if k in kws[0]}
+        return submit_unet_batch(fnames, model=kws[0]["model"], prefetched=prefetched, **extra), _clean(kws)
+
+    def collect(handle):
+        rows = collect_unet_batch(handle[0])
+        return [{**kw, "beta_hat": rows[i, 0], "l1": rows[i, 1]} for i, kw in enumerate(handle[1])]
+
+    if fn is predict_unet_batch:
+        wrapped.submit, wrapped.collect = submit, collect
     # decode of the next chunk beside the GPU work of the current one (fabrika iterator='batched'); a 1-tuple so that
     # "ragged chunk" (None) stays distinguishable from "nothing prefetched"
     wrapped.prefetch = lambda fnames, kws: (load_planes_u8(fnames, kws[0].get("imread", imread4_u8)),)
@@ -270,17 +335,12 @@ def predict_unet_sharded(dataset, model: torch.nn.Module, *, stego_method: str =
     df = df.reset_index(drop=True)
     files = df["name"].tolist()                              # iterator=None hands over absolute paths (fabrika.py:104-110)
 
-    def predict_chunk(chunk):
-        planes = load_planes_u8(chunk)
-        if planes is None or tuple(planes.shape[1:]) != (512, 512):
-            res = [predict_unet(f, model, imread=imread4_f32) for f in chunk]
-            return torch.tensor([[r["beta_hat"], r["l1"]] for r in res], dtype=torch.float32)
-        beta, l1 = predict_u8_batch(planes.to(_model_device(model), non_blocking=True), model)
-        out = torch.stack([beta, l1], dim=1)
-        torch.cuda.current_stream().synchronize()            # the pinned staging buffer is reused by the next chunk
-        return out
+    def predict_shard(shard_files):                          # decode / GPU / read-back of consecutive chunks overlapped
+        chunks = [shard_files[i:i + batch_size] for i in range(0, len(shard_files), batch_size)]
+        rows = list(pipelined_unet_rows(chunks, model))
+        return torch.from_numpy(np.concatenate(rows)) if rows else torch.zeros((0, 2), dtype=torch.float32)
 
-    table = parallel.evaluate_sharded(files, predict_chunk, batch_size).cpu().numpy()
+    table = parallel.evaluate_sharded(files, predict_shard, None).cpu().numpy()
     df["name"] = [str(pathlib.Path(f).relative_to(dataset)) for f in files]
     df["beta_hat"], df["l1"] = table[:, 0], table[:, 1]
     if stego_method is not None:

@@ -99,13 +99,18 @@ def gather_rows(local_indices: Sequence[int], local_values: torch.Tensor, total:
 
 def evaluate_sharded(rows: Sequence, predict_batch: Callable[[Sequence], torch.Tensor], batch_size: int = 32) -> torch.Tensor:
     """Batch-sharded evaluate: every rank runs ``predict_batch(rows[i:j]) -> (j-i, k)`` on its shard of ``rows``
-    (kept in the caller's order) and all ranks receive the full (len(rows), k) result table."""
+    (kept in the caller's order) and all ranks receive the full (len(rows), k) result table.  ``batch_size=None`` hands the rank's
+    whole shard to ``predict_batch`` in one call."""
     rank, world = world_info()
     mine = shard_indices(len(rows), rank, world)
     outs = []
-    for i in range(0, len(mine), batch_size):
-        chunk = mine[i:i + batch_size]
-        outs.append(predict_batch([rows[j] for j in chunk]))
+    if batch_size is None:                              # the callable takes the rank's whole shard (it pipelines its own chunks)
+        if len(mine):
+            outs.append(predict_batch([rows[j] for j in mine]))
+    else:
+        for i in range(0, len(mine), batch_size):
+            chunk = mine[i:i + batch_size]
+            outs.append(predict_batch([rows[j] for j in chunk]))
     if outs:
         local = torch.cat([o.reshape(len(o), -1).float() for o in outs])
     else:
