@@ -8,6 +8,7 @@
 // interleaves the 4 sub-position tiles into a [4 x 64 output pixels][64 co] LDS tile so that the NHWC
 // stores are whole 16-byte pieces of contiguous output rows.
 #include "wsu_device.h"
+#include <cstdlib>
 
 namespace {
 
@@ -258,6 +259,173 @@ __global__ __launch_bounds__(NT, 2) void convt2x2_kernel(const CtArgs a) {
     }
 }
 
+// ---- mode F16F8, 4 x 32 input pixels per workgroup ------------------------------------------------------------------------------------
+// The 2 x 32 tile above stages a 16 KB weight slice per 16-channel chunk for 64 input pixels: 2.6 weight bytes through L2 -> LDS per
+// output byte, and two barriers per 8 matrix instructions of a wave (measured 2.6 / 1.8 TB/s of HBM traffic on upconv4 / upconv3).
+// This variant doubles the pixels per workgroup (wave = one sub-position x 64 co x 128 px, 128 accumulator registers) and writes the
+// 8 x 64 output pixels in two passes through the same 69.6 KB epilogue tile.
+namespace f8t {
+constexpr int TH4 = 4, NPIX4 = TW * TH4;                     // 128 input pixels
+constexpr int PLANE4 = NPIX4 * 16 + 32;                       // 2080 B
+constexpr int LDS_IN4 = WSU_GRAN * PLANE4;                    // 8320
+constexpr int LDS_MAIN4 = LDS_IN4 + LDS_W;
+constexpr int STRIDE = WSU_COB * 4 + 16;
+constexpr int EPI4 = 4 * NPIX * STRIDE;                       // one pass = 4 output rows x 64 columns
+}
+
+__global__ __launch_bounds__(NT, 2) void convt2x2_f16f8_kernel(const CtArgs a) {
+    using namespace f8t;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const unsigned lid = wsu_xcd_remap(blockIdx.x, gridDim.x);
+    const int cb = lid % a.ncb;
+    int tile = lid / a.ncb;
+    const int tx = tile % a.tiles_x; tile /= a.tiles_x;
+    const int ty = tile % a.tiles_y;
+    const int n = tile / a.tiles_y;
+    const int y0 = ty * TH4, x0 = tx * TW;
+
+    // staging plan: 384 items (pixel, 16-byte piece of the 48 stored bytes of a chunk), two rounds of 256 threads
+    const char* xsrc[2]; int ldsoff[2]; bool has[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int i = tid + j * NT;
+        const int pix = i / 3, sub = i - 3 * pix;
+        has[j] = i < NPIX4 * 3;
+        const int pr = (pix / TW) % TH4, pc = pix % TW;
+        const int yy = min(y0 + pr, a.h - 1), xx = min(x0 + pc, a.w - 1);        // clamp: out-of-image lanes are never stored
+        xsrc[j] = a.x + ((size_t)(n * a.h + yy) * a.w + xx) * a.cin * 3 + sub * 16;
+        ldsoff[j] = sub * PLANE4 + (pix % NPIX4) * 16;
+    }
+    u32x4 st_in[2], st_w[W_VEC];
+    auto load = [&](int c) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            st_in[j] = mk_u4(0, 0, 0, 0);
+            if (has[j]) st_in[j] = *reinterpret_cast<const u32x4*>(xsrc[j] + (size_t)c * 48);
+        }
+        const u32x4* wsrc = reinterpret_cast<const u32x4*>(a.wp + ((size_t)cb * a.nch + c) * LDS_W);
+        WSU_STATIC_FOR(W_VEC, k, st_w[k] = wsrc[tid + k * NT];);
+    };
+    auto commit = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            if (has[j]) {
+                *reinterpret_cast<u32x4*>(smem + ldsoff[j]) = st_in[j];
+                if (ldsoff[j] < 2 * PLANE4) {                         // an f16 piece: its 8 e4m3 copies fill half of the pixel's slot in plane 3
+                    const int half = ldsoff[j] >= PLANE4 ? 1 : 0;
+                    *reinterpret_cast<u32x2*>(smem + 3 * PLANE4 + (ldsoff[j] - half * PLANE4) + half * 8) = wsu_f16x8_to_fp8(st_in[j]);
+                }
+            }
+        u32x4* wdst = reinterpret_cast<u32x4*>(smem + LDS_IN4);
+        WSU_STATIC_FOR(W_VEC, k, wdst[tid + k * NT] = st_w[k];);
+    };
+
+    const int wv = tid >> 6, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;   // wave = sub-position a*2+b
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][q][r] = 0.f;
+    const char* ldsA = smem + LDS_IN4 + ((wv * WSU_GRAN) * 64 + l31) * 16;      // + (g*64 + m*32)*16
+    const char* ldsB = smem + l31 * 16;                                          // + g*PLANE4 + q*32*16
+    const u32x4 z4 = mk_u4(0, 0, 0, 0);
+    u32x4 f8a0[2] = {z4, z4}, f8a1[2] = {z4, z4}, f8b0[4] = {z4, z4, z4, z4}, f8b1[4] = {z4, z4, z4, z4};
+    const int sc_a = hh ? WSU_F8_SCALE_WLO : WSU_F8_SCALE_W, sc_b = hh ? WSU_F8_SCALE_X : WSU_F8_SCALE_XLO;
+
+    load(0);
+    for (int c = 0; c < a.nch; ++c) {
+        __syncthreads();
+        commit();
+        __syncthreads();
+        if (c + 1 < a.nch) load(c + 1);
+        if ((c & 1) == hh) {                                  // this lane half's chunk of the pair: fetch its fp8 operands (see convt2x2_kernel)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                f8a0[m] = *reinterpret_cast<const u32x4*>(ldsA + (2 * 64 + m * 32) * 16);
+                f8a1[m] = *reinterpret_cast<const u32x4*>(ldsA + (3 * 64 + m * 32) * 16);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f8b0[q] = *reinterpret_cast<const u32x4*>(ldsB + 2 * PLANE4 + q * TW * 16);
+                f8b1[q] = *reinterpret_cast<const u32x4*>(ldsB + 3 * PLANE4 + q * TW * 16);
+            }
+        }
+        u32x4 ah[2], bh[4];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) ah[m] = *reinterpret_cast<const u32x4*>(ldsA + (hh * 64 + m * 32) * 16);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bh[q] = *reinterpret_cast<const u32x4*>(ldsB + hh * PLANE4 + q * TW * 16);
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) wsu_mfma_f16(ah[m], bh[q], acc[m][q]);
+        if (c & 1) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) wsu_mfma_f8x2(f8a0[m], f8a1[m], f8b0[q], f8b1[q], sc_a, sc_b, acc[m][q]);
+        }
+    }
+
+    // ---- epilogue, two passes: input rows (2p, 2p+1) -> 4 output rows x 64 output columns through the [pixel][64 co] fp32 tile ----
+    const int sa = wv >> 1, sb = wv & 1;
+    const int oh = 2 * a.h, ow = 2 * a.w;
+    WSU_STATIC_FOR(2, p, {
+        __syncthreads();
+_Pragma("unroll")
+        for (int m = 0; m < 2; ++m)
+_Pragma("unroll")
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int co = m * 32 + 8 * g4 + 4 * hh;
+                f32x4 b4 = mk_f4(0.f, 0.f, 0.f, 0.f);
+                if (a.bias) b4 = *reinterpret_cast<const f32x4*>(a.bias + cb * WSU_COB + co);
+_Pragma("unroll")
+                for (int q = 0; q < 2; ++q) {
+                    const f32x16& v = acc[m][2 * p + q];
+                    const int opx = (2 * q + sa) * (2 * TW) + 2 * l31 + sb;
+                    *reinterpret_cast<f32x4*>(smem + opx * STRIDE + co * 4) =
+                        mk_f4(v[4 * g4 + 0] + b4.x, v[4 * g4 + 1] + b4.y, v[4 * g4 + 2] + b4.z, v[4 * g4 + 3] + b4.w);
+                }
+            }
+        __syncthreads();
+        for (int i = tid; i < 4 * NPIX * 4; i += NT) {            // encode in place: a 16-channel chunk keeps its 64-byte slot (48 used)
+            u32x4* row = reinterpret_cast<u32x4*>(smem + (i >> 2) * STRIDE + (i & 3) * 64);
+            u32x4 hi0, hi1, lo8;
+            wsu_split16_f16f8(__builtin_bit_cast(f32x4, row[0]), __builtin_bit_cast(f32x4, row[1]), __builtin_bit_cast(f32x4, row[2]),
+                              __builtin_bit_cast(f32x4, row[3]), hi0, hi1, lo8);
+            row[0] = hi0; row[1] = hi1; row[2] = lo8;
+        }
+        __syncthreads();
+        for (int i = tid; i < 4 * NPIX * 12; i += NT) {           // 12 consecutive lanes per output pixel: whole 192-byte rows per store
+            const int opx = i / 12, piece = i - 12 * opx;
+            const int r = opx / (2 * TW), c = opx % (2 * TW);
+            const int oy = 2 * y0 + 4 * p + r, ox = 2 * x0 + c;
+            if (oy < oh && ox < ow)
+                *reinterpret_cast<u32x4*>(a.y + (((size_t)(n * oh + oy) * ow + ox) * a.cout + cb * WSU_COB) * 3 + piece * 16) =
+                    *reinterpret_cast<const u32x4*>(smem + opx * STRIDE + (piece / 3) * 64 + (piece % 3) * 16);
+        }
+    });
+}
+
+int launch_ct_f16f8(const CtArgs& a_in, hipStream_t s) {
+    CtArgs a = a_in;
+    a.tiles_y = (a.h + f8t::TH4 - 1) / f8t::TH4;
+    const int lds = f8t::EPI4 > f8t::LDS_MAIN4 ? f8t::EPI4 : f8t::LDS_MAIN4;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&convt2x2_f16f8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) { wsu_set_error("hipFuncSetAttribute(convt2x2_f16f8): %s", hipGetErrorString(e)); return WSU_ERR_HIP; }
+        attr_done = true;
+    }
+    const long long nblk = (long long)a.n * a.tiles_x * a.tiles_y * a.ncb;
+    if (nblk <= 0 || nblk > 0x7FFFFFFFLL) { wsu_set_error("convt2x2: grid of %lld workgroups out of range", nblk); return WSU_ERR_ARG; }
+    hipLaunchKernelGGL(convt2x2_f16f8_kernel, dim3((unsigned)nblk), dim3(NT), lds, s, a);
+    return wsu_check_launch("convt2x2_f16f8_kernel");
+}
+
 template <int MODE, bool PS = false>
 int launch_ct(const CtArgs& a, hipStream_t s) {
     constexpr int ESZ = (MODE == WSU_MODE_BF16) ? 2 : 4;
@@ -370,7 +538,11 @@ int wsu_convt2x2_fwd(const void* x, const void* w_packed, const float* bias, voi
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (mode == WSU_MODE_F32) return launch_ct<WSU_MODE_F32>(a, s);
     if (presplit) return launch_ct<WSU_MODE_BF16X3, true>(a, s);
-    if (mode == WSU_MODE_F16F8) return launch_ct<WSU_MODE_F16F8, true>(a, s);
+    if (mode == WSU_MODE_F16F8) {
+        static int small = -1;                                    // WSU_CONVT_TILE=2: the 2 x 32 tile of the generic kernel (A/B runs)
+        if (small < 0) { const char* e = getenv("WSU_CONVT_TILE"); small = (e && e[0] == '2') ? 1 : 0; }
+        return small ? launch_ct<WSU_MODE_F16F8, true>(a, s) : launch_ct_f16f8(a, s);
+    }
     if (mode == WSU_MODE_BF16X3) return launch_ct<WSU_MODE_BF16X3>(a, s);
     return launch_ct<WSU_MODE_BF16>(a, s);
 }
