@@ -519,7 +519,7 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 4 : 2) void conv3x3_kernel(const
     int pixidx[IN_VEC];      // linear pixel index (n*H + y)*W + x of the source, -1 = zero, -2 = no item
     int ldsoff[IN_VEC];
     constexpr bool SPLIT_HERE = (MODE == WSU_MODE_BF16X3 || MODE == WSU_MODE_F16F8) && !PS;     // F1 computes its input and always splits here
-    static_assert(MODE != WSU_MODE_F16F8 || ((PS != F1) && (NW == 8 || NW == 4) && !S16), "F16F8: stored-split or self-computed input");
+    static_assert(MODE != WSU_MODE_F16F8 || ((PS != F1) && (NW == 8 || NW == 4 || NW == 16) && !S16), "F16F8: stored-split or self-computed input");
     constexpr bool STORED48 = MODE == WSU_MODE_F16F8 && PS;         // 3 stored pieces of 16 B per pixel and chunk
     constexpr int NITEMS = SPLIT_HERE ? NPIX_IN * 2 : (STORED48 ? NPIX_IN * 3 : NPIX_IN * 4);
     constexpr int NLOOP = SPLIT_HERE ? Shape<NW>::IN_VEC3 : (STORED48 ? Shape<NW>::IN_VEC48 : IN_VEC);
@@ -1428,9 +1428,10 @@ int launch_conv(const ConvArgs& a, hipStream_t s, bool in_split = false) {
     }
     if constexpr (MODE == WSU_MODE_F16F8) {
         if (a.img) return launch_conv_nw<MODE, 8, false, true, false>(a, s);
-        static int nw4 = -1;                                        // WSU_CONV_WAVES=4: 64 co x 64 px per wave (fewer LDS fragment reads per MFMA)
-        if (nw4 < 0) { const char* e = getenv("WSU_CONV_WAVES"); nw4 = (e && atoi(e) == 4) ? 1 : 0; }
-        return nw4 ? launch_conv_nw<MODE, 4, false, false, true>(a, s) : launch_conv_nw<MODE, 8, false, false, true>(a, s);
+        static int nw = -1;                 // WSU_CONV_WAVES=4: 64 co x 64 px per wave (fewer LDS fragment reads per MFMA); 16: 16x32-pixel tile
+        if (nw < 0) { const char* e = getenv("WSU_CONV_WAVES"); nw = e ? atoi(e) : 8; }
+        if (nw == 16) return launch_conv_nw<MODE, 16, false, false, true>(a, s);
+        return nw == 4 ? launch_conv_nw<MODE, 4, false, false, true>(a, s) : launch_conv_nw<MODE, 8, false, false, true>(a, s);
     } else {
     // Default = the per-tile kernel (v1): measured faster (bench conv3x3 15.8 ms vs 17.9 ms per batch-32 forward in bf16x3).
     // WSU_CONV_IMPL=pp selects the ping-pong kernel (kept for the next tuning round; profiles/r01/conv3x3_ablation.md).
