@@ -21,7 +21,7 @@ def ref_model():
     return unet_ref.build_ref(2, formula.formula_state_dict(2, "he"))
 
 
-@pytest.mark.parametrize("mode,tol", [("f32", 3e-3), ("bf16x3", 1e-2)])
+@pytest.mark.parametrize("mode,tol", [("f32", 3e-3), ("bf16x3", 1e-2), ("f16f8", 3e-2)])
 def test_infere_single_and_predict_unet_on_real_cover(ref_model, mode, tol):
     """cover_10.png is one of the reference's own 512x512 covers; tolerances are in 0..255 units
     (tol/255 on the [0,1] output: 1.2e-5 / 4e-5, max over 260k pixels)."""
