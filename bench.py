@@ -174,6 +174,14 @@ def main():
             "note": "algorithmic FLOPs = 2*9*Cin*Cout*N*H*W summed over the 9 conv3x3 launches of a forward "
                     "(the split modes issue extra MFMAs per product -- bf16x3: 3 bf16; f16f8: 1 f16 + one fp8 instruction per tap pair -- they are not counted)",
         }
+        # matrix-pipe occupancy next to the algorithmic fraction: one unit = one 32x32x16 bf16/f16 MFMA (32 cycles, 32 768 FLOP); per
+        # 16-channel chunk and 32x32 output tile a product costs 9 units of work, the modes issue 27 (bf16x3: 3 per tap), 19 (f16f8: 9
+        # f16 + 5 fp8 instructions of 2 units), 9 (bf16) -- the fused first layer and the 16x16x32 shape issue the same unit counts
+        units = {"bf16x3": 27 / 9, "bf16x3s": 27 / 9, "f16f8": 19 / 9, "bf16": 1.0}.get(args.mode)
+        if units is not None:
+            roofline["mfma_issue"] = {"units_per_product": units, "tflops_equivalent": achieved * units / 1e12,
+                                      "frac_of_peak": achieved * units / PEAK[args.mode],
+                                      "note": "matrix-pipe time actually issued (split terms included) against the same dense bf16 peak"}
         roofline.update(pmc_traffic(args, conv["bytes"] / conv["launches"]))
         gpu_ms = {k: round(v["total_ms"] / args.steps, 3) for k, v in ks.items()}
         result = {
