@@ -38,6 +38,9 @@
  *                           the second cross term needs is derived from the f16 part while staging); weights packed by the pack
  *                           entry points with this mode (4 bytes per weight).  Values beyond +-448 lose the residual term (plain f16 accuracy); beyond +-65504 the f16 part overflows
  *                           like any f16 pipeline (use BF16X3S for such networks).
+ *      WSU_MODE_F16F8X = 5  the arithmetic of F16F8 on fp32 tensors (operands encoded while staging, fp32 results): the forward 3x3
+ *                           conv (wsu_conv3x3_fwd, with pool and pool_idx) and wsu_convt2x2_fwd of the training path; weights packed
+ *                           as for F16F8.
  */
 #ifndef WSU_H
 #define WSU_H
@@ -51,7 +54,7 @@ extern "C" {
 
 #define WSU_VERSION 100
 
-enum { WSU_MODE_F32 = 0, WSU_MODE_BF16X3 = 1, WSU_MODE_BF16 = 2, WSU_MODE_BF16X3S = 3, WSU_MODE_F16F8 = 4 };
+enum { WSU_MODE_F32 = 0, WSU_MODE_BF16X3 = 1, WSU_MODE_BF16 = 2, WSU_MODE_BF16X3S = 3, WSU_MODE_F16F8 = 4, WSU_MODE_F16F8X = 5 };
 
 enum {
     WSU_OK = 0,
@@ -63,7 +66,7 @@ enum {
 int wsu_version(void);
 const char* wsu_last_error(void);
 
-/* Bytes per activation element for a mode (4, 4, 2, 4, 3). */
+/* Bytes per activation element for a mode (4, 4, 2, 4, 3, 4). */
 int wsu_act_elem_size(int mode);
 
 /* ---- weight packing (done once per weight update; replaces nothing in the reference:

@@ -154,7 +154,8 @@ def test_unet_gradients_golden(golden, ns, mode):
     loss = losses.L1WSLoss()(out, (covers, alphas), inputs)
     loss.backward()
     assert math.isclose(loss.item(), float(g[f"grad{ns}_loss"][0]), rel_tol=1e-5)
-    np.testing.assert_allclose(out.detach().cpu().numpy(), g[f"grad{ns}_out"], atol=4e-6 if mode == "f32" else 2e-5, rtol=0)
+    # the matrix layers of a 'bf16x3' training forward run the f16f8 arithmetic on fp32 tensors (model.train_fwd_mode = 'f16f8x')
+    np.testing.assert_allclose(out.detach().cpu().numpy(), g[f"grad{ns}_out"], atol=4e-6 if mode == "f32" else 1e-4, rtol=0)
     for k, p in model.named_parameters():
         got = p.grad.detach().cpu().numpy().reshape(-1)
         ref = g[f"grad{ns}_{k}_sub"]

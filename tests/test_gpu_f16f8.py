@@ -108,3 +108,34 @@ def test_large_values_degrade_gracefully():
     got = unsplit_f16f8(res[F8])
     assert torch.isfinite(got).all()
     assert (got - ref).abs().max().item() <= 2.0 ** -9 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 32, 64, 64), (1, 24, 40, 128, 64), (1, 8, 8, 64, 128)])
+def test_f16f8x_on_fp32_tensors(shape):
+    """Mode 'f16f8x' (the training forward): the f16f8 arithmetic on fp32 tensors, with the fused pool and its argmax, against the
+    split-bf16 kernels on the same tensors."""
+    n, h, w, cin, cout = shape
+    FX = ops.mode_id("f16f8x")
+    x = torch.from_numpy(formula.formula_tensor(f"fx/x/{shape}", (n, h, w, cin), 1.0)).abs().to(DEV)
+    wt, b = _w(f"fx/w/{shape}", (cout, cin, 3, 3), 0.05), _w(f"fx/b/{shape}", (cout,), 0.1)
+    y1, p1, i1 = ops.conv3x3(x, None, ops.pack_conv3x3(wt, X3), b, cout, X3, pool=True, pool_idx=True)
+    y2, p2, i2 = ops.conv3x3(x, None, ops.pack_conv3x3(wt, FX), b, cout, FX, pool=True, pool_idx=True)
+    scale = y1.abs().max().item()
+    assert y2.dtype == torch.float32 and y2.shape == y1.shape
+    assert (y1 - y2).abs().max().item() <= 1e-4 * scale and (p1 - p2).abs().max().item() <= 1e-4 * scale
+    # the argmax names an element of the window that carries the pooled value (ties / near-ties may pick another position)
+    win = y2.reshape(n, h // 2, 2, w // 2, 2, cout).permute(0, 1, 3, 5, 2, 4).reshape(n, h // 2, w // 2, cout, 4)
+    assert torch.equal(torch.gather(win, 4, i2.long().unsqueeze(-1)).squeeze(-1), p2)
+    assert (i1 != i2).float().mean().item() <= 0.01
+    # concat input and the transposed conv
+    x2 = torch.from_numpy(formula.formula_tensor(f"fx/x2/{shape}", (n, h, w, 64), 1.0)).to(DEV)
+    wc = _w(f"fx/wc/{shape}", (64, cin + 64, 3, 3), 0.04)
+    c1 = ops.conv3x3(x, x2, ops.pack_conv3x3(wc, X3), None, 64, X3)
+    c2 = ops.conv3x3(x, x2, ops.pack_conv3x3(wc, FX), None, 64, FX)
+    assert (c1 - c2).abs().max().item() <= 1e-4 * c1.abs().max().item()
+    wu, bu = _w(f"fx/wu/{shape}", (cin, 64, 2, 2), 0.09), _w(f"fx/bu/{shape}", (64,), 0.1)
+    u1 = ops.convt2x2(x, ops.pack_convt2x2(wu, X3), bu, 64, X3)
+    u2 = ops.convt2x2(x, ops.pack_convt2x2(wu, FX), bu, 64, FX)
+    assert u2.shape == (n, 2 * h, 2 * w, 64) and (u1 - u2).abs().max().item() <= 1e-4 * u1.abs().max().item()
+    with pytest.raises(ValueError, match="training forward"):
+        gpu_model(2, "he", "f16f8x")

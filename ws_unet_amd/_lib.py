@@ -20,8 +20,8 @@ from pathlib import Path
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "libwsu.so"
 
-MODE_F32, MODE_BF16X3, MODE_BF16, MODE_BF16X3S, MODE_F16F8 = 0, 1, 2, 3, 4
-MODES = {"f32": MODE_F32, "bf16x3": MODE_BF16X3, "bf16": MODE_BF16, "bf16x3s": MODE_BF16X3S, "f16f8": MODE_F16F8}
+MODE_F32, MODE_BF16X3, MODE_BF16, MODE_BF16X3S, MODE_F16F8, MODE_F16F8X = 0, 1, 2, 3, 4, 5
+MODES = {"f32": MODE_F32, "bf16x3": MODE_BF16X3, "bf16": MODE_BF16, "bf16x3s": MODE_BF16X3S, "f16f8": MODE_F16F8, "f16f8x": MODE_F16F8X}
 
 
 class WsuError(RuntimeError):

@@ -94,7 +94,7 @@ __device__ __forceinline__ void stage_load(const ConvArgs& a, int cb, int c, int
     constexpr int NT = Shape<NW>::NT, W_VEC = Shape<NW>::W_VEC;
     constexpr int ESZ = Epi<MODE>::ESZ;
     constexpr int CK = (MODE == WSU_MODE_BF16) ? 32 : 16;
-    constexpr bool SPLIT_HERE = MODE == WSU_MODE_BF16X3 && !PS;     // fp32 in HBM, split while committing (2 items of 32 B per pixel)
+    constexpr bool SPLIT_HERE = (MODE == WSU_MODE_BF16X3 || MODE == WSU_MODE_F16F8) && !PS;     // fp32 in HBM, split while committing (2 items of 32 B per pixel)
     constexpr int NLOOP = SPLIT_HERE ? Shape<NW>::IN_VEC3 : (MODE == WSU_MODE_F16F8 ? Shape<NW>::IN_VEC48 : Shape<NW>::IN_VEC);
     const char* src; int csrc, ch0;
     if (c < a.nch1) { src = a.x1; csrc = a.c1; ch0 = c * CK; }
@@ -226,12 +226,21 @@ __device__ __forceinline__ void stage_commit(char* smem, int tid, const int (&pi
                                              const u32x4 (&st_in)[Shape<NW>::ST_IN], const u32x4 (&st_w)[Shape<NW>::W_VEC]) {
     constexpr int NT = Shape<NW>::NT, W_VEC = Shape<NW>::W_VEC;
     constexpr int PLANE_IN = Shape<NW>::PLANE_IN, LDS_IN = Shape<NW>::LDS_IN;
-    constexpr bool SPLIT_HERE = MODE == WSU_MODE_BF16X3 && !PS;
+    constexpr bool SPLIT_HERE = (MODE == WSU_MODE_BF16X3 || MODE == WSU_MODE_F16F8) && !PS;
     constexpr int NLOOP = SPLIT_HERE ? Shape<NW>::IN_VEC3 : (MODE == WSU_MODE_F16F8 ? Shape<NW>::IN_VEC48 : Shape<NW>::IN_VEC);
 #pragma unroll
     for (int j = 0; j < NLOOP; ++j) {
         if (pixidx[j] != -2) {
-            if constexpr (SPLIT_HERE) {
+            if constexpr (SPLIT_HERE && MODE == WSU_MODE_F16F8) {
+                // fp32 storage (API mode F16F8X): 8 channels of one pixel -> f16 piece, 8 residuals, 8 e4m3 copies (planes half, 2, 3)
+                const int half = ldsoff[j] >= PLANE_IN ? 1 : 0, pixoff = ldsoff[j] - half * PLANE_IN;
+                uint32_t h0, h1, h2, h3, l0, l1, x0, x1;
+                wsu_split4_f16f8(__builtin_bit_cast(f32x4, st_in[2 * j]), WSU_F8_XLO_DIV, WSU_F8_X_DIV, h0, h1, l0, x0);
+                wsu_split4_f16f8(__builtin_bit_cast(f32x4, st_in[2 * j + 1]), WSU_F8_XLO_DIV, WSU_F8_X_DIV, h2, h3, l1, x1);
+                *reinterpret_cast<u32x4*>(smem + ldsoff[j]) = mk_u4(h0, h1, h2, h3);
+                *reinterpret_cast<u32x2*>(smem + 2 * PLANE_IN + pixoff + half * 8) = mk_u2(l0, l1);
+                *reinterpret_cast<u32x2*>(smem + 3 * PLANE_IN + pixoff + half * 8) = mk_u2(x0, x1);
+            } else if constexpr (SPLIT_HERE) {
                 u32x4 hi, lo;
                 wsu_split8(__builtin_bit_cast(f32x4, st_in[2 * j]), __builtin_bit_cast(f32x4, st_in[2 * j + 1]), hi, lo);
                 *reinterpret_cast<u32x4*>(smem + ldsoff[j]) = hi;
@@ -367,7 +376,9 @@ __device__ __forceinline__ void tile_epilogue(const ConvArgs& a, char* smem, int
                 }
         }
     }
-    if constexpr (MODE == WSU_MODE_F16F8) { store_f16f8<NT, TH, STRIDE>(a, smem, tid, n, y0, x0, cglob, ydst, ych, ycoff); return; }
+    if constexpr (MODE == WSU_MODE_F16F8) {
+        if (a.out_split) { store_f16f8<NT, TH, STRIDE>(a, smem, tid, n, y0, x0, cglob, ydst, ych, ycoff); return; }   // else fp32 stores (F16F8X)
+    }
     if constexpr (MODE == WSU_MODE_BF16X3) {
         if (a.out_split) {
             // ---- pre-split stores (mode BF16X3S): per pixel and 16-channel chunk  hi 0-7 | hi 8-15 | lo 0-7 | lo 8-15; one item = 8 channels
@@ -519,7 +530,7 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 4 : 2) void conv3x3_kernel(const
     int pixidx[IN_VEC];      // linear pixel index (n*H + y)*W + x of the source, -1 = zero, -2 = no item
     int ldsoff[IN_VEC];
     constexpr bool SPLIT_HERE = (MODE == WSU_MODE_BF16X3 || MODE == WSU_MODE_F16F8) && !PS;     // F1 computes its input and always splits here
-    static_assert(MODE != WSU_MODE_F16F8 || ((PS != F1) && (NW == 8 || NW == 4 || NW == 16) && !S16), "F16F8: stored-split or self-computed input");
+    static_assert(MODE != WSU_MODE_F16F8 || (!(PS && F1) && (NW == 8 || NW == 4 || NW == 16) && !S16), "F16F8: stored-split, fp32 or self-computed input");
     constexpr bool STORED48 = MODE == WSU_MODE_F16F8 && PS;         // 3 stored pieces of 16 B per pixel and chunk
     constexpr int NITEMS = SPLIT_HERE ? NPIX_IN * 2 : (STORED48 ? NPIX_IN * 3 : NPIX_IN * 4);
     constexpr int NLOOP = SPLIT_HERE ? Shape<NW>::IN_VEC3 : (STORED48 ? Shape<NW>::IN_VEC48 : IN_VEC);
@@ -1428,6 +1439,7 @@ int launch_conv(const ConvArgs& a, hipStream_t s, bool in_split = false) {
     }
     if constexpr (MODE == WSU_MODE_F16F8) {
         if (a.img) return launch_conv_nw<MODE, 8, false, true, false>(a, s);
+        if (!in_split) return launch_conv_nw<MODE, 8, false, false, false>(a, s);      // API mode F16F8X: fp32 storage on both sides
         static int nw = -1;                 // WSU_CONV_WAVES=4: 64 co x 64 px per wave (fewer LDS fragment reads per MFMA); 16: 16x32-pixel tile
         if (nw < 0) { const char* e = getenv("WSU_CONV_WAVES"); nw = e ? atoi(e) : 8; }
         if (nw == 16) return launch_conv_nw<MODE, 16, false, false, true>(a, s);
@@ -1525,6 +1537,7 @@ __global__ void pack_conv3x3_f16f8_kernel(const float* __restrict__ w, char* __r
 }
 
 int pack_impl(const float* w, void* dst, int cin, int cout, int mode, int tf, void* stream) {
+    if (mode == WSU_MODE_F16F8X) mode = WSU_MODE_F16F8;
     const int kin = tf ? cout : cin, mout = tf ? cin : cout;
     WSU_REQUIRE(w && dst, "conv3x3_pack: null pointer");
     WSU_REQUIRE((mode >= 0 && mode <= 2) || (mode == WSU_MODE_F16F8 && !tf), "conv3x3_pack: bad mode %d", mode);
@@ -1550,7 +1563,7 @@ int wsu_debug_read_stamps(unsigned long long* host_dst, int nblocks) {
 }
 
 size_t wsu_conv3x3_packed_bytes(int cin, int cout, int mode) {
-    if (cin <= 0 || cout <= 0 || mode < 0 || (mode > 2 && mode != WSU_MODE_F16F8)) return 0;
+    if (cin <= 0 || cout <= 0 || mode < 0 || (mode > 2 && mode != WSU_MODE_F16F8 && mode != WSU_MODE_F16F8X)) return 0;
     const size_t per_elem = mode == WSU_MODE_BF16 ? 2 : 4;    // BF16X3 stores hi + lo bf16, F16F8 f16 + two e4m3 = 4 bytes
     return (size_t)cin * cout * 9 * per_elem;
 }
@@ -1576,10 +1589,14 @@ static int conv3x3_launch_full(const void* x1, const void* x2, const void* w_pac
                           int n, int h, int w, int c1, int c2, int cout,
                           int mode, int relu, int pad_zero, void* stream,
                           const float* first_img = nullptr, const float* first_w = nullptr, const float* first_b = nullptr) {
-    WSU_REQUIRE(mode >= 0 && mode <= 4, "conv3x3: bad mode %d", mode);
+    WSU_REQUIRE(mode >= 0 && mode <= 5, "conv3x3: bad mode %d", mode);
     const bool presplit = mode == WSU_MODE_BF16X3S;             // split-bf16 arithmetic on activations stored already split
     if (presplit) mode = WSU_MODE_BF16X3;
-    WSU_REQUIRE(!(presplit || mode == WSU_MODE_F16F8) || (!pool_idx && !relu_mask && !relu_mask2 && !y2 && !pad_zero),
+    const bool f16f8x = mode == WSU_MODE_F16F8X;                // F16F8 arithmetic on fp32 storage (training forward: pool_idx allowed)
+    if (f16f8x) mode = WSU_MODE_F16F8;
+    WSU_REQUIRE(!f16f8x || (!first_img && !relu_mask && !relu_mask2 && !y2 && !pad_zero && !head_w),
+                "conv3x3: mode F16F8X is the forward 3x3 conv on fp32 tensors (no fused first layer / head, masks, split outputs or zero padding)");
+    WSU_REQUIRE(!(presplit || (mode == WSU_MODE_F16F8 && !f16f8x)) || (!pool_idx && !relu_mask && !relu_mask2 && !y2 && !pad_zero),
                 "conv3x3: modes BF16X3S / F16F8 are forward inference formats (no pool_idx, ReLU masks, split outputs or zero padding)");
     const int ck = wsu_chunk_channels(mode);
     WSU_REQUIRE((x1 || first_img) && w_packed && (y || head_w), "conv3x3: null pointer");
@@ -1605,14 +1622,14 @@ static int conv3x3_launch_full(const void* x1, const void* x2, const void* w_pac
     a.relu = relu; a.pad_zero = pad_zero;
     a.head_w = head_w; a.head_b = head_b; a.head_out = head_out; a.head_logit = head_logit; a.head_cout = head_cout;
     a.img = first_img; a.w1 = first_w; a.b1 = first_b;
-    a.out_split = presplit;
+    a.out_split = presplit || (mode == WSU_MODE_F16F8 && !f16f8x);
     static int ablate = -1;
     if (ablate < 0) { const char* e = getenv("WSU_CONV_ABLATE"); ablate = e ? atoi(e) : 0; }
     a.ablate = ablate;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (mode == WSU_MODE_F32) return launch_conv<WSU_MODE_F32>(a, s);
     if (mode == WSU_MODE_BF16X3) return launch_conv<WSU_MODE_BF16X3>(a, s, presplit && !first_img);
-    if (mode == WSU_MODE_F16F8) return launch_conv<WSU_MODE_F16F8>(a, s);
+    if (mode == WSU_MODE_F16F8) return launch_conv<WSU_MODE_F16F8>(a, s, !f16f8x);
     return launch_conv<WSU_MODE_BF16>(a, s);
 }
 

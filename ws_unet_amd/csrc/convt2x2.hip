@@ -35,9 +35,9 @@ __device__ __forceinline__ void ct_load(const CtArgs& a, int cb, int c, int tid,
     constexpr int CK = (MODE == WSU_MODE_BF16) ? 32 : 16;
     st_in[0] = mk_u4(0, 0, 0, 0); st_in[1] = st_in[0];
     if (has_item) {
-        const u32x4* g = reinterpret_cast<const u32x4*>(xsrc + (size_t)c * (MODE == WSU_MODE_F16F8 ? 48 : CK * ESZ));
+        const u32x4* g = reinterpret_cast<const u32x4*>(xsrc + (size_t)c * ((MODE == WSU_MODE_F16F8 && PS) ? 48 : CK * ESZ));
         st_in[0] = g[0];
-        if constexpr (MODE == WSU_MODE_BF16X3 && !PS) st_in[1] = g[1];
+        if constexpr ((MODE == WSU_MODE_BF16X3 || MODE == WSU_MODE_F16F8) && !PS) st_in[1] = g[1];
     }
     const u32x4* wsrc = reinterpret_cast<const u32x4*>(a.wp + ((size_t)cb * a.nch + c) * LDS_W);
     WSU_STATIC_FOR(W_VEC, k, st_w[k] = wsrc[tid + k * NT];);
@@ -47,14 +47,22 @@ template <int MODE, bool PS = false>
 __device__ __forceinline__ void ct_commit(char* smem, int tid, bool has_item, int ldsoff,
                                           const u32x4 (&st_in)[2], const u32x4 (&st_w)[W_VEC]) {
     if (has_item) {
-        if constexpr (MODE == WSU_MODE_BF16X3 && !PS) {
+        if constexpr (MODE == WSU_MODE_F16F8 && !PS) {             // fp32 storage (API mode F16F8X): split 8 channels into planes half, 2, 3
+            const int half = ldsoff >= PLANE_IN ? 1 : 0, pixoff = ldsoff - half * PLANE_IN;
+            uint32_t h0, h1, h2, h3, l0, l1, x0, x1;
+            wsu_split4_f16f8(__builtin_bit_cast(f32x4, st_in[0]), WSU_F8_XLO_DIV, WSU_F8_X_DIV, h0, h1, l0, x0);
+            wsu_split4_f16f8(__builtin_bit_cast(f32x4, st_in[1]), WSU_F8_XLO_DIV, WSU_F8_X_DIV, h2, h3, l1, x1);
+            *reinterpret_cast<u32x4*>(smem + ldsoff) = mk_u4(h0, h1, h2, h3);
+            *reinterpret_cast<u32x2*>(smem + 2 * PLANE_IN + pixoff + half * 8) = mk_u2(l0, l1);
+            *reinterpret_cast<u32x2*>(smem + 3 * PLANE_IN + pixoff + half * 8) = mk_u2(x0, x1);
+        } else if constexpr (MODE == WSU_MODE_BF16X3 && !PS) {
             u32x4 hi, lo;
             wsu_split8(__builtin_bit_cast(f32x4, st_in[0]), __builtin_bit_cast(f32x4, st_in[1]), hi, lo);
             *reinterpret_cast<u32x4*>(smem + ldsoff) = hi;
             *reinterpret_cast<u32x4*>(smem + ldsoff + 2 * PLANE_IN) = lo;
         } else {
             *reinterpret_cast<u32x4*>(smem + ldsoff) = st_in[0];
-            if constexpr (MODE == WSU_MODE_F16F8) {               // an f16 piece: its 8 e4m3 copies fill half of the pixel's slot in plane 3
+            if constexpr (MODE == WSU_MODE_F16F8 && PS) {         // an f16 piece: its 8 e4m3 copies fill half of the pixel's slot in plane 3
                 if (ldsoff < 2 * PLANE_IN) {
                     const int half = ldsoff >= PLANE_IN ? 1 : 0;
                     *reinterpret_cast<u32x2*>(smem + 3 * PLANE_IN + (ldsoff - half * PLANE_IN) + half * 8) = wsu_f16x8_to_fp8(st_in[0]);
@@ -83,8 +91,8 @@ __global__ __launch_bounds__(NT, 2) void convt2x2_kernel(const CtArgs a) {
     const int y0 = ty * TH, x0 = tx * TW;
 
     // staging plan: F32/BF16: 256 items (pixel, granule); BF16X3: 128 items (pixel, half) of 32 B
-    constexpr bool SPLIT_HERE = MODE == WSU_MODE_BF16X3 && !PS;       // PS: pre-split input, 4 granule items per pixel like F32 / BF16
-    constexpr bool STORED48 = MODE == WSU_MODE_F16F8;                  // 3 stored pieces of 16 B per pixel and chunk (plane 3 is derived)
+    constexpr bool SPLIT_HERE = (MODE == WSU_MODE_BF16X3 || MODE == WSU_MODE_F16F8) && !PS;   // PS: pre-split input, 4 granule items per pixel like F32 / BF16
+    constexpr bool STORED48 = MODE == WSU_MODE_F16F8 && PS;            // 3 stored pieces of 16 B per pixel and chunk (plane 3 is derived)
     constexpr int NITEMS = SPLIT_HERE ? NPIX * 2 : (STORED48 ? NPIX * 3 : NPIX * 4);
     const int pix = SPLIT_HERE ? (tid >> 1) : (STORED48 ? tid / 3 : (tid >> 2));
     const int sub = SPLIT_HERE ? (tid & 1) : (STORED48 ? tid - 3 * pix : (tid & 3));
@@ -121,7 +129,6 @@ __global__ __launch_bounds__(NT, 2) void convt2x2_kernel(const CtArgs a) {
             // f16(w) * f16(x) per 16-channel chunk; the two cross terms of TWO chunks share one block-scaled fp8 instruction (a scale block
             // is 32 k: lanes 0-31 carry the even chunk's 16 channels, lanes 32-63 the odd chunk's).  Each lane half reads its operands
             // while its chunk is in LDS and holds them in registers; the instruction is issued on odd chunks (cin % 32 == 0, checked).
-            static_assert(PS, "F16F8 activations are stored split");
             if ((c & 1) == hh) {
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
@@ -209,7 +216,7 @@ __global__ __launch_bounds__(NT, 2) void convt2x2_kernel(const CtArgs a) {
     }
     __syncthreads();
     const int oh = 2 * a.h, ow = 2 * a.w;
-    if constexpr (MODE == WSU_MODE_F16F8) {
+    if constexpr (MODE == WSU_MODE_F16F8 && PS) {
         // encode the tile in place (a 16-channel chunk keeps its 64-byte slot, 48 bytes used), then copy out with 12 consecutive lanes per
         // output pixel so that every store instruction writes whole 192-byte pixel rows (see store_f16f8 in conv3x3.hip)
         for (int i = tid; i < 4 * NPIX * 4; i += NT) {
@@ -501,12 +508,13 @@ __global__ void pack_convt_f16f8_kernel(const float* __restrict__ w, char* __res
 extern "C" {
 
 size_t wsu_convt2x2_packed_bytes(int cin, int cout, int mode) {
-    if (cin <= 0 || cout <= 0 || mode < 0 || (mode > 2 && mode != WSU_MODE_F16F8)) return 0;
+    if (cin <= 0 || cout <= 0 || mode < 0 || (mode > 2 && mode != WSU_MODE_F16F8 && mode != WSU_MODE_F16F8X)) return 0;
     return (size_t)cin * cout * 4 * (mode == WSU_MODE_BF16 ? 2 : 4);
 }
 
 int wsu_convt2x2_pack(const float* w_iohw, void* w_packed, int cin, int cout, int mode, void* stream) {
     WSU_REQUIRE(w_iohw && w_packed, "convt2x2_pack: null pointer");
+    if (mode == WSU_MODE_F16F8X) mode = WSU_MODE_F16F8;
     WSU_REQUIRE((mode >= 0 && mode <= 2) || mode == WSU_MODE_F16F8, "convt2x2_pack: bad mode %d", mode);
     WSU_REQUIRE(cin > 0 && cin % wsu_chunk_channels(mode) == 0, "convt2x2_pack: cin=%d not a multiple of %d", cin, wsu_chunk_channels(mode));
     WSU_REQUIRE(cout > 0 && cout % WSU_COB == 0, "convt2x2_pack: cout=%d not a multiple of %d", cout, WSU_COB);
@@ -520,9 +528,11 @@ int wsu_convt2x2_pack(const float* w_iohw, void* w_packed, int cin, int cout, in
 
 int wsu_convt2x2_fwd(const void* x, const void* w_packed, const float* bias, void* y,
                      int n, int h, int w, int cin, int cout, int mode, void* stream) {
-    WSU_REQUIRE(mode >= 0 && mode <= 4, "convt2x2: bad mode %d", mode);
+    WSU_REQUIRE(mode >= 0 && mode <= 5, "convt2x2: bad mode %d", mode);
     const bool presplit = mode == WSU_MODE_BF16X3S;             // input and output stored already split (see wsu.h)
     if (presplit) mode = WSU_MODE_BF16X3;
+    const bool f16f8x = mode == WSU_MODE_F16F8X;                // F16F8 arithmetic on fp32 tensors
+    if (f16f8x) mode = WSU_MODE_F16F8;
     WSU_REQUIRE(x && w_packed && y, "convt2x2: null pointer");
     WSU_REQUIRE(n > 0 && h > 0 && w > 0, "convt2x2: bad shape n=%d h=%d w=%d", n, h, w);
     WSU_REQUIRE(cin > 0 && cin % wsu_chunk_channels(mode) == 0, "convt2x2: cin=%d not a multiple of %d", cin, wsu_chunk_channels(mode));
@@ -538,6 +548,7 @@ int wsu_convt2x2_fwd(const void* x, const void* w_packed, const float* bias, voi
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (mode == WSU_MODE_F32) return launch_ct<WSU_MODE_F32>(a, s);
     if (presplit) return launch_ct<WSU_MODE_BF16X3, true>(a, s);
+    if (f16f8x) return launch_ct<WSU_MODE_F16F8, false>(a, s);
     if (mode == WSU_MODE_F16F8) {
         static int small = -1;                                    // WSU_CONVT_TILE=2: the 2 x 32 tile of the generic kernel (A/B runs)
         if (small < 0) { const char* e = getenv("WSU_CONVT_TILE"); small = (e && e[0] == '2') ? 1 : 0; }

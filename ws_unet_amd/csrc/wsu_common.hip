@@ -26,5 +26,5 @@ int wsu_check_launch(const char* what) {
 extern "C" {
 int wsu_version(void) { return WSU_VERSION; }
 const char* wsu_last_error(void) { return g_err; }
-int wsu_act_elem_size(int mode) { return mode == WSU_MODE_BF16 ? 2 : (mode == WSU_MODE_F16F8 ? 3 : (mode == WSU_MODE_F32 || mode == WSU_MODE_BF16X3 || mode == WSU_MODE_BF16X3S ? 4 : 0)); }
+int wsu_act_elem_size(int mode) { return mode == WSU_MODE_BF16 ? 2 : (mode == WSU_MODE_F16F8 ? 3 : (mode == WSU_MODE_F32 || mode == WSU_MODE_BF16X3 || mode == WSU_MODE_BF16X3S || mode == WSU_MODE_F16F8X ? 4 : 0)); }
 }

@@ -25,11 +25,16 @@ def _param_list(model) -> List[torch.nn.Parameter]:
     return [p for _, p in model.named_parameters()]
 
 
-def _forward_train(model, x: torch.Tensor, m: int) -> Dict[str, torch.Tensor]:
-    """Same dataflow as UNet.forward_features, keeping what backward needs."""
+def _forward_train(model, x: torch.Tensor, m0: int) -> Dict[str, torch.Tensor]:
+    """Same dataflow as UNet.forward_features, keeping what backward needs.  The matrix layers of a split-bf16 training run use the
+    'f16f8x' arithmetic (exact f16 products + fp8 cross terms on fp32 tensors, ~2^-15 relative: 0.7 of bf16x3's matrix cycles);
+    ``model.train_fwd_mode`` / WSU_TRAIN_FWD_MODE='bf16x3' keeps the forward in split-bf16."""
     t: Dict[str, torch.Tensor] = {}
     e11 = model.e11
-    cur = t["xe11"] = ops.conv3x3_first(x, e11.weight.detach(), e11.bias.detach(), m, relu=True)
+    cur = t["xe11"] = ops.conv3x3_first(x, e11.weight.detach(), e11.bias.detach(), m0, relu=True)
+    m = m0
+    if m0 == ops.MODE_BF16X3:
+        m = ops.mode_id(getattr(model, "train_fwd_mode", None) or "f16f8x")
     for lvl in range(model.nsteps + 1):
         a, b = ENC[lvl]
         if lvl >= 1:
@@ -50,7 +55,7 @@ def _forward_train(model, x: torch.Tensor, m: int) -> Dict[str, torch.Tensor]:
         cur = t["x" + c1] = ops.conv3x3(xu, skip, model._packed(c1, m, "conv"), l1.bias.detach(), l1.out_channels, m)
         cur = t["x" + c2] = ops.conv3x3(cur, None, model._packed(c2, m, "conv"), l2.bias.detach(), l2.out_channels, m)
     t["last"] = cur
-    t["out"] = ops.conv1x1_sigmoid(cur, model.outconv.weight.detach(), model.outconv.bias.detach(), m)
+    t["out"] = ops.conv1x1_sigmoid(cur, model.outconv.weight.detach(), model.outconv.bias.detach(), m0)
     return t
 
 

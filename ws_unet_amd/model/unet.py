@@ -87,7 +87,11 @@ class UNet(nn.Module):
         # arithmetic of the autograd path: exact fp32 MFMA for an 'f32' model, split-bf16 (fp32 storage and accumulation,
         # ~2^-16 relative per product -- finer than the TF32 convs PyTorch trains with by default on the reference's GPUs) otherwise
         self.train_mode = os.environ.get("WSU_TRAIN_MODE") or ("f32" if self.mode == "f32" else "bf16x3")
+        # matrix layers of the training FORWARD when train_mode is 'bf16x3': 'f16f8x' (default) or 'bf16x3'
+        self.train_fwd_mode = os.environ.get("WSU_TRAIN_FWD_MODE") or "f16f8x"
         ops.mode_id(self.mode)                                    # validate early
+        if self.mode == "f16f8x":
+            raise ValueError("'f16f8x' is the arithmetic of the training forward (fp32 tensors); the inference mode is 'f16f8'")
         conv_kw = {"kernel_size": 3, "padding": 1, "padding_mode": "reflect"}
         ups_kw = {"kernel_size": 2, "stride": 2}
         if drop_rate is not None:
