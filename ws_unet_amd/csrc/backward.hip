@@ -528,7 +528,7 @@ size_t wsu_conv3x3_bwd_data_workspace_bytes(int n, int h, int w, int cin, int co
 int wsu_conv3x3_bwd_data(const void* g, const void* w_packed_dgrad, const float* w_oihw, void* workspace, size_t workspace_bytes,
                          void* dx1, void* dx2, int csplit, const void* relu_mask1, const void* relu_mask2,
                          int n, int h, int w, int cin, int cout, int mode, void* stream) {
-    WSU_REQUIRE(mode == WSU_MODE_F32 || mode == WSU_MODE_BF16X3, "conv3x3_bwd_data: fp32-storage modes only (got %d)", mode);
+    WSU_REQUIRE(mode == WSU_MODE_F32 || mode == WSU_MODE_BF16X3 || mode == WSU_MODE_F16F8X, "conv3x3_bwd_data: fp32-storage modes only (got %d)", mode);
     WSU_REQUIRE(w_oihw && workspace, "conv3x3_bwd_data: null weight / workspace");
     WSU_REQUIRE(cin % WSU_COB == 0 && csplit % 4 == 0 && cout % 4 == 0, "conv3x3_bwd_data: cin=%d must be a multiple of %d", cin, WSU_COB);
     WSU_REQUIRE(workspace_bytes >= wsu_conv3x3_bwd_data_workspace_bytes(n, h, w, cin, cout, mode), "conv3x3_bwd_data: workspace too small");

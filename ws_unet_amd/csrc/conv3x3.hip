@@ -1513,9 +1513,11 @@ __global__ void pack_conv3x3_kernel(const float* __restrict__ w, char* __restric
 }
 
 // F16F8: one thread per (cob, chunk, tap, co) row of 16 channels -> [f16 0-7][f16 8-15][e4m3(w * 2^6)][e4m3((w - f16 w) * 2^18)]
-__global__ void pack_conv3x3_f16f8_kernel(const float* __restrict__ w, char* __restrict__ dst, int cin, int cout) {
-    const int nch = cin / 16;
-    const long long total = (long long)(cout / WSU_COB) * nch * 9 * WSU_COB;
+// transpose_flip as in pack_conv3x3_kernel (data-gradient weights: the roles of Cin / Cout swap, taps flipped; 2 = tap axes swapped too).
+__global__ void pack_conv3x3_f16f8_kernel(const float* __restrict__ w, char* __restrict__ dst, int cin, int cout, int transpose_flip) {
+    const int kin = transpose_flip ? cout : cin, mout = transpose_flip ? cin : cout;
+    const int nch = kin / 16;
+    const long long total = (long long)(mout / WSU_COB) * nch * 9 * WSU_COB;
     for (long long d = (long long)blockIdx.x * blockDim.x + threadIdx.x; d < total; d += (long long)gridDim.x * blockDim.x) {
         long long t = d;
         const int co = t % WSU_COB; t /= WSU_COB;
@@ -1524,7 +1526,14 @@ __global__ void pack_conv3x3_f16f8_kernel(const float* __restrict__ w, char* __r
         const int cb = (int)t;
         f32x4 q[4];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) q[e >> 2][e & 3] = w[(((size_t)(cb * WSU_COB + co)) * cin + c * 16 + e) * 9 + tap];
+        for (int e = 0; e < 16; ++e) {
+            const int ci = c * 16 + e, m = cb * WSU_COB + co, u = tap / 3, v = tap % 3;
+            float val;
+            if (transpose_flip == 2) val = w[(((size_t)ci * cin + m) * 3 + (2 - v)) * 3 + (2 - u)];
+            else if (transpose_flip) val = w[(((size_t)ci * cin + m) * 3 + (2 - u)) * 3 + (2 - v)];
+            else                     val = w[(((size_t)m * cin + ci) * 3 + u) * 3 + v];
+            q[e >> 2][e & 3] = val;
+        }
         uint32_t h[8], l[4], x[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) wsu_split4_f16f8(q[k], WSU_F8_WLO_DIV, WSU_F8_W_DIV, h[2 * k], h[2 * k + 1], l[k], x[k]);
@@ -1540,12 +1549,12 @@ int pack_impl(const float* w, void* dst, int cin, int cout, int mode, int tf, vo
     if (mode == WSU_MODE_F16F8X) mode = WSU_MODE_F16F8;
     const int kin = tf ? cout : cin, mout = tf ? cin : cout;
     WSU_REQUIRE(w && dst, "conv3x3_pack: null pointer");
-    WSU_REQUIRE((mode >= 0 && mode <= 2) || (mode == WSU_MODE_F16F8 && !tf), "conv3x3_pack: bad mode %d", mode);
+    WSU_REQUIRE((mode >= 0 && mode <= 2) || mode == WSU_MODE_F16F8, "conv3x3_pack: bad mode %d", mode);
     WSU_REQUIRE(kin > 0 && kin % wsu_chunk_channels(mode) == 0, "conv3x3_pack: reduction channels %d not a multiple of %d", kin, wsu_chunk_channels(mode));
     WSU_REQUIRE(mout > 0 && mout % WSU_COB == 0, "conv3x3_pack: output channels %d not a multiple of %d", mout, WSU_COB);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int blocks = 1024;
-    if (mode == WSU_MODE_F16F8) hipLaunchKernelGGL(pack_conv3x3_f16f8_kernel, dim3(blocks), dim3(256), 0, s, w, (char*)dst, cin, cout);
+    if (mode == WSU_MODE_F16F8) hipLaunchKernelGGL(pack_conv3x3_f16f8_kernel, dim3(blocks), dim3(256), 0, s, w, (char*)dst, cin, cout, tf);
     else if (mode == WSU_MODE_F32) hipLaunchKernelGGL(pack_conv3x3_kernel<WSU_MODE_F32>, dim3(blocks), dim3(256), 0, s, w, (char*)dst, cin, cout, tf);
     else if (mode == WSU_MODE_BF16X3) hipLaunchKernelGGL(pack_conv3x3_kernel<WSU_MODE_BF16X3>, dim3(blocks), dim3(256), 0, s, w, (char*)dst, cin, cout, tf);
     else hipLaunchKernelGGL(pack_conv3x3_kernel<WSU_MODE_BF16>, dim3(blocks), dim3(256), 0, s, w, (char*)dst, cin, cout, tf);
@@ -1594,8 +1603,7 @@ static int conv3x3_launch_full(const void* x1, const void* x2, const void* w_pac
     if (presplit) mode = WSU_MODE_BF16X3;
     const bool f16f8x = mode == WSU_MODE_F16F8X;                // F16F8 arithmetic on fp32 storage (training forward: pool_idx allowed)
     if (f16f8x) mode = WSU_MODE_F16F8;
-    WSU_REQUIRE(!f16f8x || (!first_img && !relu_mask && !relu_mask2 && !y2 && !pad_zero && !head_w),
-                "conv3x3: mode F16F8X is the forward 3x3 conv on fp32 tensors (no fused first layer / head, masks, split outputs or zero padding)");
+    WSU_REQUIRE(!f16f8x || (!first_img && !head_w), "conv3x3: mode F16F8X runs on fp32 tensors (no fused first layer / head)");
     WSU_REQUIRE(!(presplit || (mode == WSU_MODE_F16F8 && !f16f8x)) || (!pool_idx && !relu_mask && !relu_mask2 && !y2 && !pad_zero),
                 "conv3x3: modes BF16X3S / F16F8 are forward inference formats (no pool_idx, ReLU masks, split outputs or zero padding)");
     const int ck = wsu_chunk_channels(mode);

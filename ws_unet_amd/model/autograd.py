@@ -4,7 +4,8 @@ The reference has no hand-written backward -- it relies on autograd through
 src/unet/model/unet.py:137-189.  Here the whole network is ONE autograd node: forward saves the NHWC
 activations (and 2-bit pool argmax), backward walks the layers in reverse calling the K7 kernels
 (include/wsu.h).  All activations stay fp32; `model.train_mode` picks the arithmetic of the forward /
-data-gradient / weight-gradient GEMMs ('f32' exact, default, or 'bf16x3' split-bf16); bias gradients are exact fp32 sums.
+data-gradient / weight-gradient GEMMs ('f32' exact, or 'bf16x3': split-bf16 weight gradients, and -- `train_fwd_mode` / `train_bwd_mode`,
+default 'f16f8x' -- the f16f8 arithmetic for the forward and data-gradient 3x3 convs); bias gradients are exact fp32 sums.
 The gradient w.r.t. the network input (saliency, src/saliency.py:159-174) is produced when `x.requires_grad`.
 
 Conventions inside backward: `g` is the PRE-activation gradient of the layer being processed; every kernel
@@ -75,6 +76,15 @@ class _UNetFn(torch.autograd.Function):
         grads: Dict[str, torch.Tensor] = {}
         dx = None
         dout = dout.contiguous().float()
+        # data-gradient 3x3 convs of a split-bf16 run: f16f8 arithmetic on the fp32 gradient tensors (model.train_bwd_mode).  Gradients of
+        # a mean-reduced loss sit far below f16's normal range, so the whole backward chain runs on gradients scaled by a power of two
+        # chosen from |dL/dout| (every kernel on the way is linear in the gradient; ReLU masks and pool routing ignore the scale) and all
+        # parameter / input gradients are scaled back at the end -- exact, and computed on the device (no host synchronisation).
+        mb, scale = m, None
+        if m == ops.MODE_BF16X3 and (getattr(model, "train_bwd_mode", None) or "f16f8x") == "f16f8x":
+            mb = ops.MODE_F16F8X
+            scale = torch.exp2(torch.floor(4.0 - torch.log2(dout.abs().max().clamp_min(1e-30))))     # max |dout| * scale in [16, 32)
+            dout = dout * scale
 
         def conv_bwd(name, g, x1, x2, mask1, mask2, need_dx=True):
             layer = getattr(model, name)
@@ -82,7 +92,7 @@ class _UNetFn(torch.autograd.Function):
             if not need_dx:
                 return None, None
             csplit = x1.shape[3]
-            return ops.conv3x3_bwd_data(g, model._packed(name, m, "dgrad"), layer.weight, csplit, mask1, mask2, m)
+            return ops.conv3x3_bwd_data(g, model._packed(name, mb, "dgrad"), layer.weight, csplit, mask1, mask2, mb)
 
         g, grads["outconv.weight"], grads["outconv.bias"] = ops.conv1x1_sigmoid_bwd(t["last"], model.outconv.weight, t["out"], dout)
         skip_g: Dict[int, torch.Tensor] = {}
@@ -109,6 +119,10 @@ class _UNetFn(torch.autograd.Function):
             else:
                 g, _ = conv_bwd(a, g, t[f"xp{lvl}"], None, None, None)           # pooled tensor: no ReLU of its own
         ctx.t = None
+        if scale is not None:
+            inv = 1.0 / scale
+            grads = {k: v * inv for k, v in grads.items()}
+            dx = dx * inv if dx is not None else None
         out = [None, dx if ctx.needs_input_grad[1] else None]
         for name, p in model.named_parameters():
             out.append(grads[name] if p.requires_grad else None)

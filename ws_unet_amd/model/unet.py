@@ -89,6 +89,7 @@ class UNet(nn.Module):
         self.train_mode = os.environ.get("WSU_TRAIN_MODE") or ("f32" if self.mode == "f32" else "bf16x3")
         # matrix layers of the training FORWARD when train_mode is 'bf16x3': 'f16f8x' (default) or 'bf16x3'
         self.train_fwd_mode = os.environ.get("WSU_TRAIN_FWD_MODE") or "f16f8x"
+        self.train_bwd_mode = os.environ.get("WSU_TRAIN_BWD_MODE") or "f16f8x"     # data-gradient 3x3 convs: 'f16f8x' or 'bf16x3'
         ops.mode_id(self.mode)                                    # validate early
         if self.mode == "f16f8x":
             raise ValueError("'f16f8x' is the arithmetic of the training forward (fp32 tensors); the inference mode is 'f16f8'")
