@@ -139,3 +139,22 @@ def test_f16f8x_on_fp32_tensors(shape):
     assert u2.shape == (n, 2 * h, 2 * w, 64) and (u1 - u2).abs().max().item() <= 1e-4 * u1.abs().max().item()
     with pytest.raises(ValueError, match="training forward"):
         gpu_model(2, "he", "f16f8x")
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 32, 128, 64), (1, 12, 40, 128, 128)])
+def test_f16f8x_data_gradient(shape):
+    """The data gradient of the reflect-padded conv (interior conv with flipped weights, border-ring fold, ReLU masks, concat split) in
+    the f16f8 arithmetic against the split-bf16 one, on gradients brought into f16's range the way the autograd node does."""
+    n, h, w, cin, cout = shape
+    FX = ops.mode_id("f16f8x")
+    g = torch.from_numpy(formula.formula_tensor(f"dg/g/{shape}", (n, h, w, cout), 1.0)).to(DEV) * 3e-7       # a mean-reduced loss's scale
+    wt = _w(f"dg/w/{shape}", (cout, cin, 3, 3), 0.05)
+    mask = torch.from_numpy(formula.formula_tensor(f"dg/m/{shape}", (n, h, w, cin), 1.0)).to(DEV)
+    m1, m2 = mask[..., :cin // 2].contiguous(), mask[..., cin // 2:].contiguous()
+    scale = torch.exp2(torch.floor(2.0 - torch.log2(g.abs().max())))
+    a1, a2 = ops.conv3x3_bwd_data(g, ops.pack_conv3x3(wt, X3, dgrad=True), wt, cin // 2, m1, m2, X3)
+    b1, b2 = ops.conv3x3_bwd_data(g * scale, ops.pack_conv3x3(wt, FX, dgrad=True), wt, cin // 2, m1, m2, FX)
+    for a, b in ((a1, b1), (a2, b2)):
+        b = b / scale
+        assert torch.equal(a == 0, b == 0) or ((a == 0) != (b == 0)).float().mean().item() < 1e-3        # the ReLU masks zero the same places
+        assert (a - b).abs().max().item() <= 1e-4 * a.abs().max().item()
