@@ -38,9 +38,10 @@
  *                           the second cross term needs is derived from the f16 part while staging); weights packed by the pack
  *                           entry points with this mode (4 bytes per weight).  Values beyond +-448 lose the residual term (plain f16 accuracy); beyond +-65504 the f16 part overflows
  *                           like any f16 pipeline (use BF16X3S for such networks).
- *      WSU_MODE_F16F8X = 5  the arithmetic of F16F8 on fp32 tensors (operands encoded while staging, fp32 results): the forward 3x3
- *                           conv (wsu_conv3x3_fwd, with pool and pool_idx) and wsu_convt2x2_fwd of the training path; weights packed
- *                           as for F16F8.
+ *      WSU_MODE_F16F8X = 5  the arithmetic of F16F8 on fp32 tensors (operands encoded while staging, fp32 results): the matrix kernels of
+ *                           the training path -- wsu_conv3x3_fwd (with pool and pool_idx), wsu_convt2x2_fwd, wsu_conv3x3_bwd_data,
+ *                           wsu_conv3x3_bwd_weight, wsu_convt2x2_bwd_weight; weights packed as for F16F8.  Gradient operands must be
+ *                           brought into f16's range by the caller (a power-of-two scale, undone on the results).
  */
 #ifndef WSU_H
 #define WSU_H

@@ -158,3 +158,29 @@ def test_f16f8x_data_gradient(shape):
         b = b / scale
         assert torch.equal(a == 0, b == 0) or ((a == 0) != (b == 0)).float().mean().item() < 1e-3        # the ReLU masks zero the same places
         assert (a - b).abs().max().item() <= 1e-4 * a.abs().max().item()
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 32, 128, 64), (1, 12, 40, 64, 128), (2, 6, 70, 64, 64)])
+def test_f16f8x_weight_gradient(shape):
+    """dW / db of the 3x3 conv (concat input) and of the transposed conv in the f16f8 arithmetic (f16 products per 16 pixels, both cross
+    terms of 32 pixels in one block-scaled fp8 MFMA, transposing 8-bit LDS reads) against the split-bf16 kernels, on a gradient
+    brought into f16's range the way the autograd node does."""
+    n, h, w, cin, cout = shape
+    FX = ops.mode_id("f16f8x")
+    g = torch.from_numpy(formula.formula_tensor(f"wg/g/{shape}", (n, h, w, cout), 1.0)).to(DEV) * 3e-7
+    x1 = torch.from_numpy(formula.formula_tensor(f"wg/x1/{shape}", (n, h, w, cin), 1.0)).abs().to(DEV)
+    x2 = torch.from_numpy(formula.formula_tensor(f"wg/x2/{shape}", (n, h, w, 64), 1.0)).to(DEV)
+    scale = torch.exp2(torch.floor(2.0 - torch.log2(g.abs().max())))
+    dw1, db1 = ops.conv3x3_bwd_weight(g, x1, x2, mode=X3)
+    dw2, db2 = ops.conv3x3_bwd_weight(g * scale, x1, x2, mode=FX)
+    dw2, db2 = dw2 / scale, db2 / scale
+    assert (dw1 - dw2).abs().max().item() <= 2e-4 * dw1.abs().max().item()
+    assert (db1 - db2).abs().max().item() <= 1e-6 * db1.abs().max().item() + 1e-12        # exact fp32 sums on both sides
+    # transposed conv: U = the low-resolution activation, V = the (scaled) gradient at twice the resolution
+    xl = torch.from_numpy(formula.formula_tensor(f"wg/xl/{shape}", (n, h, w, cin), 1.0)).to(DEV)
+    dy = torch.from_numpy(formula.formula_tensor(f"wg/dy/{shape}", (n, 2 * h, 2 * w, cout), 1.0)).to(DEV) * 3e-7
+    s2 = torch.exp2(torch.floor(2.0 - torch.log2(dy.abs().max())))
+    tw1, tb1 = ops.convt2x2_bwd_weight(xl, dy, mode=X3)
+    tw2, tb2 = ops.convt2x2_bwd_weight(xl, dy * s2, mode=FX)
+    assert (tw1 - tw2 / s2).abs().max().item() <= 2e-4 * tw1.abs().max().item()
+    assert (tb1 - tb2 / s2).abs().max().item() <= 1e-5 * tb1.abs().max().item() + 1e-12

@@ -149,12 +149,42 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 constexpr int X3_ROW = 144;                       // bytes per pixel row: 64 bf16 + 16 pad (16-byte aligned rows)
 
+constexpr int F8_ROW = 96;                        // bytes per pixel row of an e4m3 image: 64 + 32 pad (conflict-free transposing reads)
+
 template <int KIND> struct GeoX3 {
     static constexpr int NTAPS = Geo<KIND>::NTAPS, TH = Geo<KIND>::TH, VH = Geo<KIND>::VH, VW = Geo<KIND>::VW;
     static constexpr int U_PIX = TH * TW, V_PIX = VH * VW;
     static constexpr int U_BYTES = U_PIX * X3_ROW, V_BYTES = V_PIX * X3_ROW;      // per hi / lo image
     static constexpr int LDS = 2 * U_BYTES + 2 * V_BYTES;
+    // F8 variant (mode F16F8X): one f16 image + two e4m3 images (copy, residual) per operand
+    static constexpr int U8_BYTES = U_PIX * F8_ROW, V8_BYTES = V_PIX * F8_ROW;
+    static constexpr int LDS_F8 = U_BYTES + 2 * U8_BYTES + V_BYTES + 2 * V8_BYTES;
 };
+
+// F8 variant: 16 k-values (pixels row0.., row step `rstep`) of the byte column `col + lane&15 (+16 for odd groups)` of an e4m3 image:
+// ds_read_b64_tr_b8 hands lane i of a 16-lane group column i of the 8 rows whose addresses the group's lanes supplied (lane 2q+p -> row
+// q, columns 8p..8p+7; tools/probe_tr8.hip); two reads = one 16-byte scale-block half of v_mfma_scale_f32_32x32x64_f8f6f4.
+typedef __attribute__((ext_vector_type(2))) int i32x2_t;
+typedef __attribute__((address_space(3))) i32x2_t lds_i32x2;
+__device__ __forceinline__ u32x4 f8_frag(const char* img, int row0, int rstep, int colbyte) {
+    const int lane = threadIdx.x & 63, li = lane & 15, q = li >> 1, pp = li & 1;
+    const char* a0 = img + (row0 + q * rstep) * F8_ROW + colbyte + pp * 8;
+    const i32x2_t r0 = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds_i32x2*)a0);
+    const i32x2_t r1 = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds_i32x2*)(a0 + 8 * rstep * F8_ROW));
+    return mk_u4((uint32_t)r0[0], (uint32_t)r0[1], (uint32_t)r1[0], (uint32_t)r1[1]);
+}
+// 8 fp32 channels of one pixel -> f16 row piece (16 B) + e4m3 copy and residual row pieces (8 B each).  `grad`: the operand is the
+// (power-of-two scaled, see model/autograd.py) gradient: copy = e4m3(v * 4), residual = e4m3((v - f16 v) * 2^14); else the activation
+// encoding of wsu_device.h (copy = e4m3(v / 4), residual * 2^12).
+__device__ __forceinline__ void f8_stage(char* hi, char* c8, char* l8, int p, int cg, const f32x4& s0, const f32x4& s1, bool grad) {
+    const float dlo = grad ? 0x1p-14f : WSU_F8_XLO_DIV, dx = grad ? 0.25f : WSU_F8_X_DIV;
+    uint32_t h0, h1, h2, h3, l0, l1, x0, x1;
+    wsu_split4_f16f8(s0, dlo, dx, h0, h1, l0, x0);
+    wsu_split4_f16f8(s1, dlo, dx, h2, h3, l1, x1);
+    *reinterpret_cast<u32x4*>(hi + p * X3_ROW + cg * 16) = mk_u4(h0, h1, h2, h3);
+    *reinterpret_cast<u32x2*>(c8 + p * F8_ROW + cg * 8) = mk_u2(x0, x1);
+    *reinterpret_cast<u32x2*>(l8 + p * F8_ROW + cg * 8) = mk_u2(l0, l1);
+}
 
 // 8 k-values (pixels row0.., row step `rstep` pixels) of channel column `col0 + lane&15 (+16 for odd groups)`
 __device__ __forceinline__ u32x4 x3_frag(const char* img, int row0, int rstep, int colbyte) {
@@ -166,15 +196,20 @@ __device__ __forceinline__ u32x4 x3_frag(const char* img, int row0, int rstep, i
     return mk_u4(lo.x, lo.y, hi.x, hi.y);
 }
 
-template <int KIND>
+// F8 = true (mode F16F8X): hi*hi on v_mfma_f32_32x32x16_f16 per 16 pixels, both cross terms of 32 pixels in one block-scaled fp8 MFMA
+// (4 instead of 6 matrix units per 32 pixels and tap); the gradient operand (U for the conv, V for the transposed conv) arrives scaled.
+template <int KIND, bool F8 = false>
 __global__ __launch_bounds__(NT, 2) void wgrad_x3_kernel(const WgArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using G = GeoX3<KIND>;
     constexpr int NTAPS = G::NTAPS, TH = G::TH, VH = G::VH, VW = G::VW;
     char* u_hi = smem;
-    char* u_lo = smem + G::U_BYTES;
-    char* v_hi = smem + 2 * G::U_BYTES;
+    char* u_lo = smem + G::U_BYTES;                        // F8: e4m3 copy image, then (u_l8) the residual image
+    char* u_l8 = u_lo + G::U8_BYTES;
+    char* v_hi = F8 ? smem + G::U_BYTES + 2 * G::U8_BYTES : smem + 2 * G::U_BYTES;
     char* v_lo = v_hi + G::V_BYTES;
+    char* v_l8 = v_lo + G::V8_BYTES;
+    constexpr bool UGRAD = KIND == 0;                      // which operand is the gradient
 
     const int tid = threadIdx.x;
     int b = blockIdx.x;
@@ -246,21 +281,28 @@ __global__ __launch_bounds__(NT, 2) void wgrad_x3_kernel(const WgArgs a) {
                 bool ok;
                 const f32x4* src = u_src(n, y0, x0, i, ok);
                 u32x4 hi = mk_u4(0, 0, 0, 0), lo = hi;
+                f32x4 s0 = mk_f4(0.f, 0.f, 0.f, 0.f), s1 = s0;
                 if (ok) {
-                    const f32x4 s0 = src[0], s1 = src[1];
+                    s0 = src[0]; s1 = src[1];
                     if (bias_on) { bs0 = bs0 + s0; bs1 = bs1 + s1; }
-                    wsu_split8(s0, s1, hi, lo);
+                    if constexpr (!F8) wsu_split8(s0, s1, hi, lo);
                 }
-                *reinterpret_cast<u32x4*>(u_hi + p * X3_ROW + cg * 16) = hi;
-                *reinterpret_cast<u32x4*>(u_lo + p * X3_ROW + cg * 16) = lo;
+                if constexpr (F8) f8_stage(u_hi, u_lo, u_l8, p, cg, s0, s1, UGRAD);
+                else {
+                    *reinterpret_cast<u32x4*>(u_hi + p * X3_ROW + cg * 16) = hi;
+                    *reinterpret_cast<u32x4*>(u_lo + p * X3_ROW + cg * 16) = lo;
+                }
             }
             for (int i = tid; i < G::V_PIX * 8; i += NT) {
                 const int p = i >> 3, cg = i & 7;
                 const f32x4* src = v_src(n, y0, x0, p, cg);
-                u32x4 hi, lo;
-                wsu_split8(src[0], src[1], hi, lo);
-                *reinterpret_cast<u32x4*>(v_hi + p * X3_ROW + cg * 16) = hi;
-                *reinterpret_cast<u32x4*>(v_lo + p * X3_ROW + cg * 16) = lo;
+                if constexpr (F8) f8_stage(v_hi, v_lo, v_l8, p, cg, src[0], src[1], !UGRAD);
+                else {
+                    u32x4 hi, lo;
+                    wsu_split8(src[0], src[1], hi, lo);
+                    *reinterpret_cast<u32x4*>(v_hi + p * X3_ROW + cg * 16) = hi;
+                    *reinterpret_cast<u32x4*>(v_lo + p * X3_ROW + cg * 16) = lo;
+                }
             }
         } else {
             // ---- commit the prefetched registers: the whole U tile and the TH new V rows (window rows VH-TH .. VH-1)
@@ -268,11 +310,14 @@ __global__ __launch_bounds__(NT, 2) void wgrad_x3_kernel(const WgArgs a) {
 #pragma unroll
             for (int k = 0; k < U_IT; ++k) {
                 const int i = tid + k * NT, p = i >> 3, cg = i & 7;
-                u32x4 hi, lo;
                 if (bias_on) { bs0 = bs0 + pu[k][0]; bs1 = bs1 + pu[k][1]; }
-                wsu_split8(pu[k][0], pu[k][1], hi, lo);
-                *reinterpret_cast<u32x4*>(u_hi + p * X3_ROW + cg * 16) = hi;
-                *reinterpret_cast<u32x4*>(u_lo + p * X3_ROW + cg * 16) = lo;
+                if constexpr (F8) f8_stage(u_hi, u_lo, u_l8, p, cg, pu[k][0], pu[k][1], UGRAD);
+                else {
+                    u32x4 hi, lo;
+                    wsu_split8(pu[k][0], pu[k][1], hi, lo);
+                    *reinterpret_cast<u32x4*>(u_hi + p * X3_ROW + cg * 16) = hi;
+                    *reinterpret_cast<u32x4*>(u_lo + p * X3_ROW + cg * 16) = lo;
+                }
             }
 #pragma unroll
             for (int k = 0; k < VN_IT; ++k) {
@@ -280,10 +325,13 @@ __global__ __launch_bounds__(NT, 2) void wgrad_x3_kernel(const WgArgs a) {
                 if (i < VN_PIX * 8) {
                     const int pn = i >> 3, cg = i & 7, rn = pn / VW, c = pn % VW;
                     const int slot = (VN_ROW0 + rn + rot) & (VH - 1);
-                    u32x4 hi, lo;
-                    wsu_split8(pv[k][0], pv[k][1], hi, lo);
-                    *reinterpret_cast<u32x4*>(v_hi + (slot * VW + c) * X3_ROW + cg * 16) = hi;
-                    *reinterpret_cast<u32x4*>(v_lo + (slot * VW + c) * X3_ROW + cg * 16) = lo;
+                    if constexpr (F8) f8_stage(v_hi, v_lo, v_l8, slot * VW + c, cg, pv[k][0], pv[k][1], !UGRAD);
+                    else {
+                        u32x4 hi, lo;
+                        wsu_split8(pv[k][0], pv[k][1], hi, lo);
+                        *reinterpret_cast<u32x4*>(v_hi + (slot * VW + c) * X3_ROW + cg * 16) = hi;
+                        *reinterpret_cast<u32x4*>(v_lo + (slot * VW + c) * X3_ROW + cg * 16) = lo;
+                    }
                 }
             }
         }
@@ -313,6 +361,30 @@ __global__ __launch_bounds__(NT, 2) void wgrad_x3_kernel(const WgArgs a) {
         }
         // ---- MFMA: k-steps of 16 pixels along a tile row (only the tap loop is unrolled: 144 accumulator + 40 prefetch registers
         //      leave no room for the fragment working set of several k-steps at once)
+        if constexpr (F8) {
+            // per tile row: two f16 k-steps of 16 pixels + ONE fp8 step of 32 pixels (scale block 0: e4m3(U) x residual(V), block 1:
+            // residual(U) x e4m3(V); lanes 0-31 carry pixels 0-15 of the row, lanes 32-63 pixels 16-31)
+            const int colA8 = wm * 32 + ((lane >> 4) & 1) * 16, colB8 = wn * 32 + ((lane >> 4) & 1) * 16;
+            constexpr int SU8 = UGRAD ? 125 : WSU_F8_SCALE_X, SUL = UGRAD ? 113 : WSU_F8_SCALE_XLO;     // e4m3(g * 4), (g - f16 g) * 2^14
+            constexpr int SV8 = UGRAD ? WSU_F8_SCALE_X : 125, SVL = UGRAD ? WSU_F8_SCALE_XLO : 113;
+            const int sc_a = hh ? SUL : SU8, sc_b = hh ? SV8 : SVL;
+#pragma unroll 1
+            for (int r = 0; r < TH; ++r) {
+                const u32x4 a8 = f8_frag(u_lo, r * TW + 16 * hh, 1, colA8), al8 = f8_frag(u_l8, r * TW + 16 * hh, 1, colA8);
+                const u32x4 ah0 = x3_frag(u_hi, r * TW + 8 * hh, 1, colA), ah1 = x3_frag(u_hi, r * TW + 16 + 8 * hh, 1, colA);
+#pragma unroll
+                for (int t = 0; t < NTAPS; ++t) {
+                    int vrow, vstep;
+                    if (KIND == 0) { vrow = ((r + t / 3 + rot) & (VH - 1)) * VW + t % 3; vstep = 1; }
+                    else           { vrow = (2 * r + (t >> 1)) * VW + (t & 1); vstep = 2; }
+                    const u32x4 bl8 = f8_frag(v_l8, vrow + vstep * 16 * hh, vstep, colB8), b8 = f8_frag(v_lo, vrow + vstep * 16 * hh, vstep, colB8);
+                    wsu_mfma_f8x2(a8, al8, bl8, b8, sc_a, sc_b, acc[t]);
+                    const u32x4 bh0 = x3_frag(v_hi, vrow + vstep * 8 * hh, vstep, colB), bh1 = x3_frag(v_hi, vrow + vstep * (16 + 8 * hh), vstep, colB);
+                    wsu_mfma_f16(ah0, bh0, acc[t]);
+                    wsu_mfma_f16(ah1, bh1, acc[t]);
+                }
+            }
+        } else
 #pragma unroll 1
         for (int r = 0; r < TH; ++r) {
 #pragma unroll 1
@@ -419,7 +491,7 @@ __global__ void colsum_final_kernel(const float* __restrict__ part, float* __res
 }
 
 template <int KIND>
-int run_wgrad(WgArgs a, float* dw, float* db, float* workspace, size_t workspace_bytes, hipStream_t s, bool x3 = false) {
+int run_wgrad(WgArgs a, float* dw, float* db, float* workspace, size_t workspace_bytes, hipStream_t s, bool x3 = false, bool f8 = false) {
     using G = Geo<KIND>;
     a.tiles_x = (a.wu + TW - 1) / TW; a.tiles_y = (a.hu + G::TH - 1) / G::TH;
     a.ntiles = a.n * a.tiles_x * a.tiles_y;
@@ -445,6 +517,15 @@ int run_wgrad(WgArgs a, float* dw, float* db, float* workspace, size_t workspace
             if (e != hipSuccess) { wsu_set_error("hipFuncSetAttribute(wgrad_x3): %s", hipGetErrorString(e)); return WSU_ERR_HIP; }
             attr_x3 = true;
         }
+        if (f8) {
+            static bool attr_f8 = false;
+            if (!attr_f8) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_x3_kernel<KIND, true>), hipFuncAttributeMaxDynamicSharedMemorySize, GeoX3<KIND>::LDS_F8);
+                if (e != hipSuccess) { wsu_set_error("hipFuncSetAttribute(wgrad_f8): %s", hipGetErrorString(e)); return WSU_ERR_HIP; }
+                attr_f8 = true;
+            }
+            hipLaunchKernelGGL((wgrad_x3_kernel<KIND, true>), dim3(nsplit * a.nmb * a.nnb), dim3(NT), GeoX3<KIND>::LDS_F8, s, a);
+        } else
         hipLaunchKernelGGL(wgrad_x3_kernel<KIND>, dim3(nsplit * a.nmb * a.nnb), dim3(NT), GeoX3<KIND>::LDS, s, a);
         int rc = wsu_check_launch("wgrad_x3_kernel");
         if (rc) return rc;
@@ -492,7 +573,7 @@ static int colsum_channels(const float* x, float* out, float* workspace, size_t 
 int wsu_conv3x3_bwd_weight(const float* g, const float* x1, const float* x2, float* dw, float* db,
                            float* workspace, size_t workspace_bytes,
                            int n, int h, int w, int c1, int c2, int cout, int mode, void* stream) {
-    WSU_REQUIRE(mode == WSU_MODE_F32 || mode == WSU_MODE_BF16X3, "conv3x3_bwd_weight: mode must be f32 or bf16x3");
+    WSU_REQUIRE(mode == WSU_MODE_F32 || mode == WSU_MODE_BF16X3 || mode == WSU_MODE_F16F8X, "conv3x3_bwd_weight: mode must be f32, bf16x3 or f16f8x");
     WSU_REQUIRE(g && x1 && dw && workspace, "conv3x3_bwd_weight: null pointer");
     WSU_REQUIRE(n > 0 && h >= 2 && w >= 2, "conv3x3_bwd_weight: bad shape");
     WSU_REQUIRE(c1 > 0 && c1 % 64 == 0 && c2 >= 0 && c2 % 64 == 0 && (c2 == 0) == (x2 == nullptr), "conv3x3_bwd_weight: c1=%d c2=%d must be multiples of 64", c1, c2);
@@ -501,20 +582,20 @@ int wsu_conv3x3_bwd_weight(const float* g, const float* x1, const float* x2, flo
     a.u = g; a.v1 = x1; a.v2 = x2; a.n = n; a.hu = h; a.wu = w; a.cu = cout; a.cv1 = c1; a.cv2 = c2;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (mode == WSU_MODE_F32) return run_wgrad<0>(a, dw, db, workspace, workspace_bytes, s);
-    return run_wgrad<0>(a, dw, db, workspace, workspace_bytes, s, true);      // exact fp32 bias gradient from the staging loop
+    return run_wgrad<0>(a, dw, db, workspace, workspace_bytes, s, true, mode == WSU_MODE_F16F8X);      // exact fp32 bias gradient from the staging loop
 }
 
 int wsu_convt2x2_bwd_weight(const float* x, const float* dy, float* dw, float* db,
                             float* workspace, size_t workspace_bytes,
                             int n, int h, int w, int cin, int cout, int mode, void* stream) {
-    WSU_REQUIRE(mode == WSU_MODE_F32 || mode == WSU_MODE_BF16X3, "convt2x2_bwd_weight: mode must be f32 or bf16x3");
+    WSU_REQUIRE(mode == WSU_MODE_F32 || mode == WSU_MODE_BF16X3 || mode == WSU_MODE_F16F8X, "convt2x2_bwd_weight: mode must be f32, bf16x3 or f16f8x");
     WSU_REQUIRE(x && dy && dw && workspace, "convt2x2_bwd_weight: null pointer");
     WSU_REQUIRE(n > 0 && h > 0 && w > 0, "convt2x2_bwd_weight: bad shape");
     WSU_REQUIRE(cin > 0 && cin % 64 == 0 && cout > 0 && cout % 64 == 0, "convt2x2_bwd_weight: cin=%d cout=%d must be multiples of 64", cin, cout);
     WgArgs a{};
     a.u = x; a.v1 = dy; a.v2 = nullptr; a.n = n; a.hu = h; a.wu = w; a.cu = cin; a.cv1 = cout; a.cv2 = 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    int rc = run_wgrad<1>(a, dw, nullptr, workspace, workspace_bytes, s, mode == WSU_MODE_BF16X3);
+    int rc = run_wgrad<1>(a, dw, nullptr, workspace, workspace_bytes, s, mode != WSU_MODE_F32, mode == WSU_MODE_F16F8X);
     if (rc || !db) return rc;
     return colsum_channels(dy, db, workspace, workspace_bytes, (long long)n * h * w * 4, cout, s);   // db[co] = sum of dy
 }

@@ -76,7 +76,7 @@ class _UNetFn(torch.autograd.Function):
         grads: Dict[str, torch.Tensor] = {}
         dx = None
         dout = dout.contiguous().float()
-        # data-gradient 3x3 convs of a split-bf16 run: f16f8 arithmetic on the fp32 gradient tensors (model.train_bwd_mode).  Gradients of
+        # data- and weight-gradient GEMMs of a split-bf16 run: f16f8 arithmetic on the fp32 tensors (model.train_bwd_mode).  Gradients of
         # a mean-reduced loss sit far below f16's normal range, so the whole backward chain runs on gradients scaled by a power of two
         # chosen from |dL/dout| (every kernel on the way is linear in the gradient; ReLU masks and pool routing ignore the scale) and all
         # parameter / input gradients are scaled back at the end -- exact, and computed on the device (no host synchronisation).
@@ -90,7 +90,7 @@ class _UNetFn(torch.autograd.Function):
 
         def conv_bwd(name, g, x1, x2, mask1, mask2, need_dx=True):
             layer = getattr(model, name)
-            grads[name + ".weight"], grads[name + ".bias"] = ops.conv3x3_bwd_weight(g, x1, x2, mode=m)
+            grads[name + ".weight"], grads[name + ".bias"] = ops.conv3x3_bwd_weight(g, x1, x2, mode=mb)
             if not need_dx:
                 return None, None
             csplit = x1.shape[3]
@@ -105,7 +105,7 @@ class _UNetFn(torch.autograd.Function):
             dxu, skip_g[depth] = conv_bwd(c1, g, xu, skip, None, skip)           # upconv output has no ReLU; skip is masked
             below = t["x" + (dec_names(depth + 1)[2] if depth < model.nsteps else ENC[model.nsteps][1])]
             lu = getattr(model, up)
-            grads[up + ".weight"], grads[up + ".bias"] = ops.convt2x2_bwd_weight(below, dxu, mode=m)
+            grads[up + ".weight"], grads[up + ".bias"] = ops.convt2x2_bwd_weight(below, dxu, mode=mb)
             g = ops.convt2x2_bwd_data(dxu, model._packed(up, m, "convt_dgrad"), lu.in_channels, below, m)
         for lvl in range(model.nsteps, -1, -1):
             a, b = ENC[lvl]
