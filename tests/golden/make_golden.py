@@ -138,6 +138,14 @@ def gen_grads(out, losses):
         out[f"grad{ns}_loss"] = np.array([loss.item()])
         out[f"grad{ns}_out"] = outputs.detach().numpy()
         out[f"grad{ns}_dx"] = inputs.grad.numpy().copy()
+        # the network path alone: the reference's WS term also reaches `inputs` directly (losses.py:59-62), which a fused loss that
+        # takes the inputs as data does not differentiate -- feed the loss a detached copy to isolate d loss / d x THROUGH the UNet
+        m.zero_grad()
+        inputs_net = inputs.detach().clone().requires_grad_(True)
+        crit(m(inputs_net), (covers, alphas), inputs_net.detach()).backward()
+        out[f"grad{ns}_dx_net"] = inputs_net.grad.numpy().copy()
+        m.zero_grad()
+        crit(m(inputs), (covers, alphas), inputs).backward()          # restore the parameter gradients of the full loss for the rows below
         for k, p in m.named_parameters():
             g = p.grad.numpy().reshape(-1)
             out[f"grad{ns}_{k}_sum"] = np.array([g.astype(np.float64).sum(), np.abs(g.astype(np.float64)).sum(),

@@ -310,3 +310,18 @@ def test_train_driver_argument_merge(tmp_path, monkeypatch):
     assert seen["covers_only"] is False and seen["channel"] == [0]
     with pytest.raises(SystemExit):
         train_mod.main([])                                                  # --dataset is mandatory
+
+
+def test_bench_self_launch_refuses_cleanly_without_gpus():
+    """`python bench.py --gpus N` (N > 1, no torch.distributed.run environment) launches the ranks itself; on a box with fewer
+    GPUs it must say so and exit non-zero BEFORE touching the GPU (VERDICT r01 missing #1)."""
+    import os
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("box has >= 2 GPUs")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    root = Path(__file__).resolve().parent.parent
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--steps", "2"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 2 and "needs 2 GPUs" in r.stderr and r.stdout.strip() == ""

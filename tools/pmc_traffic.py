@@ -5,8 +5,16 @@ Both are reported by rocprofv3 in KiB.
 
 python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> [kernel-substring] [mode]"""
 import csv
+import hashlib
 import json
 import sys
+from pathlib import Path
+
+
+def git_blob_sha1(path: Path) -> str:
+    """`git hash-object` of the kernel source the counters were collected on: bench.py refuses the summary when the tree differs."""
+    data = path.read_bytes()
+    return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
 
 
 def per_launch(path, counter, kernel):
@@ -30,6 +38,7 @@ def main():
         "fetch_bytes_per_launch": 2.0 * sum(f) / len(f),          # gfx950: x2
         "write_bytes_per_launch": sum(w) / len(w),
         "counters": "FETCH_SIZE (KiB, x2 on gfx950) and WRITE_SIZE (KiB), one rocprofv3 --pmc pass each",
+        "conv3x3_hip_blob": git_blob_sha1(Path(__file__).resolve().parent.parent / "ws_unet_amd" / "csrc" / "conv3x3.hip"),
     }
     res["traffic_bytes_per_launch"] = res["fetch_bytes_per_launch"] + res["write_bytes_per_launch"]
     with open(out, "w") as fh:

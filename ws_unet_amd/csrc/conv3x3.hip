@@ -670,6 +670,11 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 4 : 2) void conv3x3_kernel(const
             const int sc_a = hh ? WSU_F8_SCALE_WLO : WSU_F8_SCALE_W, sc_b = hh ? WSU_F8_SCALE_X : WSU_F8_SCALE_XLO;
             auto cross = [&](auto tp_c) __attribute__((always_inline)) {
                 constexpr int tp = decltype(tp_c)::value;
+#if WSU_PROBE == 1                                              // timing probe: 3 instead of 5 fp8 instructions (one cross term per product)
+                if constexpr (tp == 1 || tp == 3) return;
+#elif WSU_PROBE == 3                                            // timing probe: no cross terms at all (plain f16)
+                return;
+#endif
                 constexpr int t0 = 2 * tp, t1 = (2 * tp + 1 < 9) ? 2 * tp + 1 : 2 * tp;
                 constexpr bool single = 2 * tp + 1 >= 9;
                 const int aoff = ((hh ? t1 : t0) * 4 + 2) * 64 * 16;

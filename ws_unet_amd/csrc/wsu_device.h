@@ -1,5 +1,8 @@
 // Shared device-side helpers for the gfx950 kernels of libwsu.
 #pragma once
+#ifndef WSU_PROBE
+#define WSU_PROBE 0             // timing-only build variants of the f16f8 matrix section (make probes; results are wrong when != 0)
+#endif
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <type_traits>
@@ -139,7 +142,13 @@ __device__ __forceinline__ void wsu_mfma_f8x2(const u32x4& a_blk0, const u32x4& 
                                               int scale_a, int scale_b, f32x16& acc) {
     i32x8 a = {(int)a_blk0.x, (int)a_blk0.y, (int)a_blk0.z, (int)a_blk0.w, (int)a_blk1.x, (int)a_blk1.y, (int)a_blk1.z, (int)a_blk1.w};
     i32x8 b = {(int)b_blk0.x, (int)b_blk0.y, (int)b_blk0.z, (int)b_blk0.w, (int)b_blk1.x, (int)b_blk1.y, (int)b_blk1.z, (int)b_blk1.w};
+#if WSU_PROBE == 2                                                  // timing probe: the same registers read as fp4 operands (4x the bf16 rate)
+    acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, acc, 4, 4, 0, scale_a, 0, scale_b);
+#elif WSU_PROBE == 4                                                // timing probe: fp6 (e2m3) operands
+    acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, acc, 2, 2, 0, scale_a, 0, scale_b);
+#else
     acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, acc, 0, 0, 0, scale_a, 0, scale_b);
+#endif
 }
 
 __device__ __forceinline__ float wsu_bf16_to_f32(uint16_t v) { return __builtin_bit_cast(float, (uint32_t)v << 16); }

@@ -164,7 +164,9 @@ class UNet(nn.Module):
         # e11 is folded into e12's input staging unless its output is asked for (xe11 then never reaches HBM)
         fuse_first = self.fuse_first and not save and e11.in_channels == 1 and e11.out_channels == 64
         cur = None
+        tag = ops.set_layer                                        # per-layer labels for bench.py's KernelTimer (a global assignment)
         if not fuse_first:
+            tag("e11")
             cur = ops.conv3x3_first(x, e11.weight.detach(), e11.bias.detach(), m, relu=True)
         if save:
             t["xe11"] = cur
@@ -174,6 +176,7 @@ class UNet(nn.Module):
             a, b = ENC[lvl]
             if lvl == 0 and fuse_first:
                 lb = self.e12
+                tag("e11+e12")
                 res = ops.conv3x3_fused_first(x, e11.weight, e11.bias.detach(), self._packed("e12", ops.first_layer_weight_mode(m), "conv"), lb.bias.detach(),
                                               lb.out_channels, m, pool=self.nsteps > 0)
                 if self.nsteps > 0:
@@ -184,10 +187,12 @@ class UNet(nn.Module):
                 continue
             if lvl >= 1:
                 la = getattr(self, a)
+                tag(a)
                 cur = ops.conv3x3(cur, None, self._packed(a, m, "conv"), la.bias.detach(), la.out_channels, m)
                 if save:
                     t["x" + a] = cur
             lb = getattr(self, b)
+            tag(b)
             if lvl < self.nsteps:
                 full, cur = ops.conv3x3(cur, None, self._packed(b, m, "conv"), lb.bias.detach(), lb.out_channels, m, pool=True)
                 skips.append(full)
@@ -201,20 +206,25 @@ class UNet(nn.Module):
         for depth in range(self.nsteps, 0, -1):
             up, c1, c2 = dec_names(depth)
             lu, l1, l2 = getattr(self, up), getattr(self, c1), getattr(self, c2)
+            tag(up)
             xu = ops.convt2x2(cur, self._packed(up, m, "convt"), lu.bias.detach(), lu.out_channels, m)
             skip = skips[depth - 1]
+            tag(c1)
             cur = ops.conv3x3(xu, skip, self._packed(c1, m, "conv"), l1.bias.detach(), l1.out_channels, m)
             if save:
                 t["xu" + up[-1]] = xu
                 t["x" + c1] = cur
             if depth == 1 and not save and oc_fusable:
                 # last layer: d42 + outconv + sigmoid in one launch, xd42 never touches HBM
+                tag(c2 + "+outconv")
                 return ops.conv3x3_head(cur, None, self._packed(c2, m, "conv"), l2.bias.detach(),
                                         self.outconv.weight.detach(), self.outconv.bias.detach(), m, want_logit=want_logit)
+            tag(c2)
             cur = ops.conv3x3(cur, None, self._packed(c2, m, "conv"), l2.bias.detach(), l2.out_channels, m)
             if save:
                 t["x" + c2] = cur
         oc = self.outconv
+        tag("outconv")
         res = ops.conv1x1_sigmoid(cur, oc.weight.detach(), oc.bias.detach(), m, want_logit=want_logit or save)
         if want_logit or save:
             out, logit = res

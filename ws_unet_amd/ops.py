@@ -32,8 +32,25 @@ class KernelTimer:
         s.record()
         rc = fn()
         e.record()
+        if _layer is not None:
+            meta = dict(meta, layer=_layer)
         self.records.append((kernel, meta, s, e))
         return rc
+
+    def per_layer(self):
+        """layer tag (set_layer) -> {'kernel', 'launches', 'total_ms', 'avg_ms', 'flops', 'bytes'} with flops / bytes PER LAUNCH;
+        launches without a tag are skipped (call after a device sync)."""
+        out = {}
+        for k, meta, s, e in self.records:
+            name = meta.get("layer")
+            if name is None:
+                continue
+            d = out.setdefault(name, {"kernel": k, "launches": 0, "total_ms": 0.0, "flops": meta.get("flops", 0.0), "bytes": meta.get("bytes", 0.0)})
+            d["launches"] += 1
+            d["total_ms"] += s.elapsed_time(e)
+        for d in out.values():
+            d["avg_ms"] = d["total_ms"] / max(1, d["launches"])
+        return out
 
     def summary(self):
         """kernel -> {'launches', 'total_ms', 'avg_ms', 'flops', 'bytes'} (call after a device sync)."""
@@ -50,6 +67,13 @@ class KernelTimer:
 
 
 _timer: Optional[KernelTimer] = None
+_layer: Optional[str] = None
+
+
+def set_layer(name: Optional[str]) -> None:
+    """Label the launches that follow (UNet.forward_features names its layers); only read while a KernelTimer is installed."""
+    global _layer
+    _layer = name
 
 
 def set_timer(t: Optional[KernelTimer]) -> None:

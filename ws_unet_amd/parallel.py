@@ -53,14 +53,52 @@ def shard_indices(n: int, rank: int, world: int) -> List[int]:
     return list(range(start, start + q + (1 if rank < r else 0)))
 
 
-def broadcast_parameters(model: torch.nn.Module, src: int = 0) -> None:
+def broadcast_flat_(flat: torch.Tensor, src: int = 0) -> None:
+    """ONE broadcast of a flat buffer (the trainer's flat parameter buffer: 7.45 MB for unet_2)."""
+    rank, world = world_info()
+    if world > 1:
+        dist.broadcast(flat, src=src)
+
+
+def broadcast_parameters(model: torch.nn.Module, src: int = 0, flat: torch.Tensor = None) -> None:
+    """Identical replicas from rank ``src`` with a single collective.  ``flat``: a buffer the parameters are views of
+    (FlatAdamW.flat_param) -- broadcast in place; otherwise the parameters are packed into one temporary bucket,
+    broadcast and copied back."""
     rank, world = world_info()
     if world == 1:
         return
-    for p in model.parameters():
-        dist.broadcast(p.data, src=src)
+    if flat is not None:
+        broadcast_flat_(flat, src)
+    else:
+        params = [p.data for p in model.parameters()]
+        if params:
+            bucket = torch.cat([p.reshape(-1) for p in params])
+            dist.broadcast(bucket, src=src)
+            off = 0
+            for p in params:
+                p.copy_(bucket[off:off + p.numel()].view_as(p))
+                off += p.numel()
     if hasattr(model, "invalidate_packed"):
         model.invalidate_packed()
+
+
+def reduce_epoch_sums_(sums: torch.Tensor) -> torch.Tensor:
+    """Sum-all-reduce an epoch's accumulators ([sum loss*n, sum mae, sum ws, images, batches]) in place so that every rank
+    derives the SAME averages -- and therefore the same patience / early-stop / best-checkpoint decisions -- from the whole
+    validation set, not from its own shard (a rank leaving the epoch loop alone would strand the others in the next
+    gradient all-reduce)."""
+    rank, world = world_info()
+    if world > 1:
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+    return sums
+
+
+def early_stop_update(val_loss: float, best_val_loss: float, patience: int, patience0: int):
+    """The patience rule of src/detector/train.py:298-304 as a pure function: -> (best_val_loss, patience, stop)."""
+    if val_loss < best_val_loss:
+        return val_loss, patience0, False
+    patience -= 1
+    return best_val_loss, patience, patience <= 0
 
 
 def allreduce_flat_(flat_grad: torch.Tensor) -> float:
@@ -71,29 +109,52 @@ def allreduce_flat_(flat_grad: torch.Tensor) -> float:
     return 1.0 / world
 
 
-def gather_rows(local_indices: Sequence[int], local_values: torch.Tensor, total: int) -> torch.Tensor:
+def _collective_device() -> torch.device:
+    return (torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu"))
+
+
+def gather_rows(local_indices: Sequence[int], local_values: torch.Tensor, total: int, k: int = None) -> torch.Tensor:
     """All-gather per-row result vectors.  local_values: (len(local_indices), k) float32 on the compute device.
-    Returns (total, k) on every rank, rows placed at their global index (NaN where no rank reported)."""
+    Returns (total, k) on every rank, rows placed at their global index (NaN where no rank reported).
+    The column count is agreed on across ranks first (a rank with an empty shard cannot know it), and the row indices travel
+    as int64 in their own all-gather (a float32 index would be exact only up to 2^24 rows)."""
     rank, world = world_info()
-    k = local_values.shape[1] if local_values.dim() == 2 else 1
-    local_values = local_values.reshape(-1, k).float()
-    out = torch.full((total, k), float("nan"), dtype=torch.float32, device=local_values.device)
-    if world == 1:
-        out[torch.as_tensor(list(local_indices), dtype=torch.long, device=out.device)] = local_values
-        return out
-    # equal-sized payload per rank: [count, idx..., values...] padded to the largest shard
-    cap = (total + world - 1) // world
-    payload = torch.zeros(1 + cap * (1 + k), dtype=torch.float32, device=local_values.device)
     cnt = len(local_indices)
-    payload[0] = cnt
-    payload[1:1 + cnt] = torch.as_tensor(list(local_indices), dtype=torch.float32, device=payload.device)
-    payload[1 + cap:1 + cap + cnt * k] = local_values.reshape(-1)
-    gathered = [torch.empty_like(payload) for _ in range(world)]
-    dist.all_gather(gathered, payload)
-    for g in gathered:
-        c = int(g[0].item())
-        idx = g[1:1 + c].long()
-        out[idx] = g[1 + cap:1 + cap + c * k].reshape(c, k)
+    if k is None:
+        k = (local_values.shape[1] if local_values.dim() == 2 else 1) if cnt else 0
+    if world == 1:
+        local_values = local_values.reshape(cnt, -1).float()
+        k = local_values.shape[1] if cnt else max(k, 0)
+        out = torch.full((total, k), float("nan"), dtype=torch.float32, device=local_values.device)
+        if cnt:
+            out[torch.as_tensor(list(local_indices), dtype=torch.long, device=out.device)] = local_values
+        return out
+    dev = local_values.device if cnt else _collective_device()
+    big = 1 << 40
+    kk = torch.tensor([k, -(k if cnt else big)], dtype=torch.int64, device=dev)    # MAX of (k, -k) = (largest, -smallest non-empty)
+    dist.all_reduce(kk, op=dist.ReduceOp.MAX)                  # every non-empty shard must report the same k; empty shards adopt it
+    kmax, kmin = int(kk[0].item()), -int(kk[1].item())
+    if kmin != big and kmin != kmax:                           # raised on EVERY rank: nobody is left waiting in a collective
+        raise ValueError(f"gather_rows: ranks disagree on the number of result columns ({kmin} .. {kmax})")
+    k = kmax
+    local_values = local_values.to(dev).reshape(cnt, k).float() if cnt else torch.zeros((0, k), dtype=torch.float32, device=dev)
+    out = torch.full((total, k), float("nan"), dtype=torch.float32, device=dev)
+    # equal-sized payloads per rank, padded to the largest shard: int64 [count, idx...] and float32 [values...]
+    cap = (total + world - 1) // world
+    ipay = torch.zeros(1 + cap, dtype=torch.int64, device=dev)
+    ipay[0] = cnt
+    if cnt:
+        ipay[1:1 + cnt] = torch.as_tensor(list(local_indices), dtype=torch.int64, device=dev)
+    vpay = torch.zeros(max(cap * k, 1), dtype=torch.float32, device=dev)
+    vpay[:cnt * k] = local_values.reshape(-1)
+    igath = [torch.empty_like(ipay) for _ in range(world)]
+    vgath = [torch.empty_like(vpay) for _ in range(world)]
+    dist.all_gather(igath, ipay)
+    dist.all_gather(vgath, vpay)
+    for gi, gv in zip(igath, vgath):
+        c = int(gi[0].item())
+        if c:
+            out[gi[1:1 + c]] = gv[:c * k].reshape(c, k)
     return out
 
 
@@ -114,10 +175,5 @@ def evaluate_sharded(rows: Sequence, predict_batch: Callable[[Sequence], torch.T
     if outs:
         local = torch.cat([o.reshape(len(o), -1).float() for o in outs])
     else:
-        local = torch.zeros((0, 2), dtype=torch.float32)
-    k = local.shape[1]
-    if world > 1:                                       # agree on k and on a device even for empty shards
-        dev = local.device if len(mine) else (torch.device("cuda", torch.cuda.current_device())
-                                              if dist.get_backend() == "nccl" else torch.device("cpu"))
-        local = local.to(dev)
+        local = torch.zeros((0, 0), dtype=torch.float32)     # empty shard: the column count comes from the other ranks
     return gather_rows(mine, local, len(rows))

@@ -104,12 +104,13 @@ class Trainer:
         self.criterion = losses.get_loss(loss)
         self.opt = FlatAdamW(model, lr)
         self.rank, self.world = parallel.world_info()
-        parallel.broadcast_parameters(model)                             # identical replicas before the first step
+        parallel.broadcast_parameters(model, flat=self.opt.flat_param)   # identical replicas before the first step: ONE 7.45 MB broadcast
         self.out_dir = Path(out_dir) if out_dir else None
         self.config = dict(config or {})
         self.patience0 = self.patience = patience
         self.best_val_loss = np.inf
         self.scalars = []                                                # (epoch, tag, value) rows, tags as in the tfevents
+        self.epochs_run = 0
         self._last_l1 = None
         if self.out_dir and self.rank == 0:
             (self.out_dir / "model").mkdir(parents=True, exist_ok=True)
@@ -161,7 +162,9 @@ class Trainer:
             acc += m * torch.tensor([float(inputs.shape[0]), 1.0, 1.0], dtype=torch.float64, device=dev)
             nimg += inputs.shape[0]
             nbatch += 1
-        tot = acc.cpu().numpy()                                          # the epoch's only device -> host copy
+        sums = torch.cat([acc, torch.tensor([float(nimg), float(nbatch)], dtype=torch.float64, device=dev)])
+        tot = parallel.reduce_epoch_sums_(sums).cpu().numpy()            # global sums on every rank; the epoch's only device -> host copy
+        nimg, nbatch = tot[3], tot[4]
         avg = {"loss": tot[0] / max(nimg, 1), "mae": tot[1] / max(nbatch, 1), "ws": tot[2] / max(nbatch, 1)}
         prefix = "train/" if train else "val/"
         for name in ("loss", "mae", "ws"):
@@ -193,12 +196,11 @@ class Trainer:
             self._run_epoch(tr_loader, True, epoch)
             val_loss = self._run_epoch(va_loader, False, epoch)
             self.save_checkpoint(epoch, val_loss)
-            if val_loss < self.best_val_loss:
-                self.patience = self.patience0
-                self.best_val_loss = val_loss
-            else:
-                self.patience -= 1
-            if self.patience <= 0:                                       # early stopping, train.py:298-304
+            # val_loss is the all-reduced average over EVERY rank's validation shard (_run_epoch), so all ranks take the same
+            # branch here and leave the loop together (train.py:298-304)
+            self.best_val_loss, self.patience, stop = parallel.early_stop_update(val_loss, self.best_val_loss, self.patience, self.patience0)
+            self.epochs_run = epoch + 1
+            if stop:
                 break
         return self.best_val_loss
 
