@@ -118,6 +118,17 @@ int wsu_conv3x3_wino_fwd(const void* x1, const void* x2, const void* w_packed, c
                          const float* head_w, const float* head_b, float* head_out, float* head_logit, int head_cout,
                          int n, int h, int w, int c1, int c2, int cout, int relu, void* stream);
 
+/* ---- K1p: the same forward conv in the f16f8 arithmetic on PLANAR activations ("F16F8P" storage, forward inference only): a tensor of C
+ *      channels is [n][C/16 chunks][4 planes][H][W][16 B] with, per pixel and 16-channel chunk, plane 0 = f16 ch 0-7, plane 1 = f16 ch
+ *      8-15, plane 2 = e4m3((x - f16 x) * 2^12) ch 0-15, plane 3 = e4m3(x / 4) ch 0-15 (4 bytes per element).  The planes are the LDS
+ *      image of the matrix kernel, so staging is a pure LDS-DMA (global_load_lds) and a persistent workgroup per CU pipelines it across
+ *      chunks and tiles (csrc/conv3x3_pl.hip).  Weights from wsu_conv3x3_pack(mode F16F8).  Outputs, each optional: y (planar),
+ *      y_pool (2x2 max-pooled, planar), head (1x1 conv + sigmoid on cout == 64 channels; out / logit NCHW fp32).  Replaces the same
+ *      reference lines as wsu_conv3x3_fwd / wsu_conv3x3_head_fwd (unet.py:141-189). */
+int wsu_conv3x3_pl_fwd(const void* x1, const void* x2, const void* w_packed, const float* bias, void* y, void* y_pool,
+                       const float* head_w, const float* head_b, float* head_out, float* head_logit, int head_cout,
+                       int n, int h, int w, int c1, int c2, int cout, int relu, void* stream);
+
 /* ---- first layer: conv3x3 reflect on a few input planes given as NCHW fp32 (the model input).
  *      Replaces e11 (unet.py:82,141).  cin <= 8, cout multiple of 8.  w is plain OIHW fp32. */
 int wsu_conv3x3_first_fwd(const float* x_nchw, const float* w_oihw, const float* bias, void* y,

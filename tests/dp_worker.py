@@ -41,6 +41,7 @@ def main():
     sl = slice(rank * per, (rank + 1) * per)
     loss, _ = tr.train_step(inputs[sl].to(DEV), covers[sl].to(DEV), alphas[sl].to(DEV))
     res["loss"] = np.array([loss.item()])
+    res["grad"] = (tr.opt.flat_grad * (1.0 / world)).cpu().numpy()       # the all-reduced bucket with the 1/world the optimiser folds in
     for k, p in model.named_parameters():
         res["p_" + k] = p.detach().cpu().numpy()
 

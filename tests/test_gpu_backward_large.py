@@ -18,7 +18,8 @@ from oracle import unet_ref, losses_ref
 pytestmark = pytest.mark.gpu
 
 # relative L2 per tensor against the fp32 CPU oracle
-REL_L2 = {"f32": 5e-6, "bf16x3": 3e-5, "f16f8x": 6e-5}
+REL_L2 = {"f32": 5e-6, "bf16x3": 1.5e-5, "f16f8x": 3e-5}        # measured on MI355X (r02): 0.5-1.4e-6 / 3.7-4.2e-6 / 8.5-9.5e-6
+DB_TOL = 2e-5      # bias gradients: fp32 sums of 1e5..5e5 random-sign values, the summation order alone moves them by ~2-6e-6
 MODES = ["f32", "bf16x3", "f16f8x"]
 
 
@@ -74,7 +75,7 @@ def test_conv3x3_gradients_production_size(shape):
         tol = REL_L2[mode]
         dw, db = ops.conv3x3_bwd_weight(gd, x1d, x2d, mode=m)
         check(dw, o["dw"], tol, f"{mode} dW", log)
-        check(db, o["db"], 5e-6, f"{mode} db", log)                       # exact fp32 sums in every mode
+        check(db, o["db"], DB_TOL, f"{mode} db", log)                     # exact fp32 sums in every mode
         dx1, dx2 = ops.conv3x3_bwd_data(gd, ops.pack_conv3x3(wd, m, dgrad=True), wd, c1, x1d, None, m)
         check(from_nhwc(dx1), o["dx1"] * (o["x1"] > 0), tol, f"{mode} dx1 (ReLU-masked)", log)
         if c2:
@@ -103,7 +104,7 @@ def test_convt2x2_gradients_production_size(shape):
         m = ops.mode_id(mode)
         dw, db = ops.convt2x2_bwd_weight(xd, dyd, mode=m)
         check(dw, wt.grad, REL_L2[mode], f"{mode} convT dW", log)
-        check(db, b.grad, 5e-6, f"{mode} convT db", log)
+        check(db, b.grad, DB_TOL, f"{mode} convT db", log)
         md = ops.mode_id("bf16x3") if mode == "f16f8x" else m                   # the autograd node runs this kernel in 'bf16x3' (autograd.py)
         dx = ops.convt2x2_bwd_data(dyd, ops.pack_convt2x2_dgrad(wt.detach().to(DEV), md), cin, xd, md)
         check(from_nhwc(dx), x.grad * (x.detach() > 0), REL_L2["bf16x3" if mode == "f16f8x" else mode], f"{mode} convT dx", log)
@@ -119,30 +120,37 @@ def _pairs(n, size, seed):
     return covers, inputs, alphas
 
 
-def _oracle_step(size, n, seed):
+def _oracle_step(size, n, seed, loss_name):
     covers, inputs, alphas = _pairs(n, size, seed)
     ref = unet_ref.build_ref(2, formula.formula_state_dict(2, "he"))
     x = inputs.clone().requires_grad_(True)
     out = ref(x)
-    loss = losses_ref.l1ws_loss(out, (covers, alphas), x.detach())
+    loss = losses_ref.LOSSES[loss_name](out, (covers, alphas), x.detach())
     loss.backward()
     return covers, inputs, alphas, out.detach(), loss.item(), {k: p.grad.clone() for k, p in ref.named_parameters()}, x.grad.clone()
 
 
+# per-tensor relative L2 bands: (f32 model, default split-bf16 model with the f16f8x arithmetic)
+#   'l2'   smooth loss: only ReLU-mask flips separate two implementations -> tight band (measured r02: see gpurun_out/r2_pytest_*.log)
+#   'l1ws' sign(cover - out) flips wherever |cover - out| is below the forward's rounding noise (2.5e-6 in fp32): k flipped pixels of
+#          N*H*W move dL/dout by sqrt(4k / NHW) relative L2 -- 3.5e-3 for k = 3 at 1024^2 -- for ANY two fp32 implementations
+GRAD_TOL = {"l2": (3e-4, 1e-3), "l1ws": (8e-3, 1.2e-2)}
+
+
+@pytest.mark.parametrize("loss_name", ["l2", "l1ws"])
 @pytest.mark.parametrize("size,n", [(1024, 1), (512, 2)])
-def test_unet2_forward_backward_large_vs_oracle(size, n):
-    """BASELINE.json configs[4] runs 1024x1024 pairs: one whole unet_2 forward + L1WS + backward at that size (and a batch of two at
+def test_unet2_forward_backward_large_vs_oracle(size, n, loss_name):
+    """BASELINE.json configs[4] runs 1024x1024 pairs: one whole unet_2 forward + loss + backward at that size (and a batch of two at
     512^2) against the CPU oracle's autograd, in exact fp32 and in the default training arithmetic (split-bf16 model: f16f8x forward,
-    data and weight gradients).  L1's sign(cover - out) and the ReLU masks flip on rounding noise, which bounds the agreement of ANY two
-    fp32 implementations of this loss at ~1e-4..1e-3 relative L2 (profiles/r01/grad_error_vs_fp64_unet2_64x64.txt); the per-tensor band
-    is 2e-3 (f32) / 4e-3 (default arithmetic), against 1.5e-2 x max in the small-size golden test."""
-    covers, inputs, alphas, out_ref, loss_ref, grads_ref, dx_ref = _oracle_step(size, n, seed=300 + size)
+    data and weight gradients), by relative L2 per tensor (the small-size golden test allows 1.5e-2 x max)."""
+    covers, inputs, alphas, out_ref, loss_ref, grads_ref, dx_ref = _oracle_step(size, n, 300 + size, loss_name)
     log = []
-    for mode, tol_out, tol_g in (("f32", 4e-6, 2e-3), ("bf16x3", 1e-4, 4e-3)):
+    crit = {"l2": losses.L2Loss, "l1ws": losses.L1WSLoss}[loss_name]
+    for (mode, tol_out), tol_g in zip((("f32", 4e-6), ("bf16x3", 1e-4)), GRAD_TOL[loss_name]):
         model = gpu_model(2, "he", mode)
         x = inputs.to(DEV).requires_grad_(True)
         out = model(x)
-        loss = losses.L1WSLoss()(out, (covers.to(DEV), alphas.to(DEV)), x)
+        loss = crit()(out, (covers.to(DEV), alphas.to(DEV)), x)
         loss.backward()
         assert math.isclose(loss.item(), loss_ref, rel_tol=2e-5 if mode == "f32" else 2e-4), (mode, loss.item(), loss_ref)
         err = (out.detach().cpu() - out_ref).abs()

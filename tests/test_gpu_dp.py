@@ -43,11 +43,20 @@ def test_two_rank_step_equals_single_rank_step(tmp_path):
     tr = Trainer(model, loss="l1ws", lr=1e-3)
     loss, _ = tr.train_step(inputs.to(DEV), covers.to(DEV), alphas.to(DEV))
     assert abs(0.5 * (r0["loss"][0] + r1["loss"][0]) - loss.item()) <= 1e-6 * abs(loss.item()) + 1e-9
+    # the mean of the two shards' gradients is the whole-batch gradient up to fp32 summation order
+    g1 = tr.opt.flat_grad.cpu().numpy()
+    np.testing.assert_array_equal(r0["grad"], r1["grad"])
+    assert np.abs(r0["grad"] - g1).max() <= 2e-6 * np.abs(g1).max(), np.abs(r0["grad"] - g1).max() / np.abs(g1).max()
+    nbad = ntot = 0
     for k, p in model.named_parameters():
         ref = p.detach().cpu().numpy()
         np.testing.assert_array_equal(r0["p_" + k], r1["p_" + k], err_msg=f"replicas diverged: {k}")     # bitwise identical replicas
-        # one AdamW step moves every weight by ~lr; the sharded gradient differs from the whole-batch one by fp32 summation order only
-        np.testing.assert_allclose(r0["p_" + k], ref, rtol=0, atol=2e-6, err_msg=k)
+        # the first AdamW step moves every weight by lr * g / (|g| + eps): where |g| is near eps = 1e-8 the summation-order noise of the
+        # gradient changes the step, so a handful of weights may differ by a fraction of lr; everything else agrees to fp32 rounding
+        d = np.abs(r0["p_" + k] - ref)
+        assert d.max() <= 2.1e-3, k
+        nbad += int((d > 2e-6).sum()); ntot += d.size
+    assert nbad <= 1e-4 * ntot, (nbad, ntot)
     # both ranks stop after the same number of epochs, on the GLOBAL validation average (1.0, then 1.1 -> patience 1 exhausted)
     np.testing.assert_array_equal(r0["fit"], r1["fit"])
     assert r0["fit"][0] == 2 and abs(r0["fit"][1] - 1.0) < 1e-12

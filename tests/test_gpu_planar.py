@@ -1,0 +1,81 @@
+"""GPU parity of the planar-format (F16F8P) inference kernels against the CPU oracle: the DMA-fed, persistent 3x3 conv
+(csrc/conv3x3_pl.hip) with its fused concat / pool / head, ragged and tiny shapes, and the storage encodings it writes."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from gpu_util import DEV, rand_act, planar_encode, planar_decode, planar_x8
+from ws_unet_amd import formula, ops
+from oracle import unet_ref
+
+pytestmark = pytest.mark.gpu
+M = ops.mode_id("f16f8")
+
+
+def _w(key, shape, bound):
+    return torch.from_numpy(formula.formula_tensor(key, shape, bound))
+
+
+@pytest.mark.parametrize("shape", [
+    (2, 16, 32, 64, 0, 64),        # exactly one tile per image
+    (1, 40, 72, 64, 0, 128),       # ragged in both directions, two output-channel blocks, more tiles than ... one image
+    (1, 2, 2, 16, 0, 64),          # smallest legal image: every tap reflects
+    (1, 6, 34, 32, 32, 64),        # fused concat, one column past a tile edge
+    (3, 48, 64, 128, 128, 128),    # several chunks per source, several tiles per workgroup
+])
+def test_conv3x3_pl_matches_oracle(shape):
+    n, h, w, c1, c2, cout = shape
+    x1 = rand_act((n, c1, h, w), f"pl/x1/{shape}")
+    x2 = rand_act((n, c2, h, w), f"pl/x2/{shape}") if c2 else None
+    wt = _w(f"pl/w/{shape}", (cout, c1 + c2, 3, 3), (6.0 / (9 * (c1 + c2))) ** 0.5)
+    b = _w(f"pl/b/{shape}", (cout,), 0.1)
+    ref = F.relu(unet_ref.conv3x3_reflect(x1 if x2 is None else torch.cat([x1, x2], 1), wt, b))
+    wp = ops.pack_conv3x3(wt.to(DEV), M)
+    even = h % 2 == 0 and w % 2 == 0
+    res = ops.conv3x3_pl(planar_encode(x1), None if x2 is None else planar_encode(x2), wp, b.to(DEV), cout, pool=even)
+    y, yp = res if even else (res, None)
+    torch.cuda.synchronize()
+    scale = ref.abs().max().item()
+    got = planar_decode(y)
+    assert (got - ref).abs().max().item() <= 1e-4 * scale, (got - ref).abs().max().item() / scale
+    # the e4m3 copy plane carries e4m3(y / 4): 3 mantissa bits -> within 2^-4 relative (or the e4m3 subnormal step) of the value
+    x8 = planar_x8(y)
+    assert ((x8 - ref).abs() <= ref.abs() / 16 + 4 * 2.0 ** -9 + 1e-4 * scale).all()
+    if even:
+        refp = F.max_pool2d(ref, 2, 2)
+        gotp = planar_decode(yp)
+        assert (gotp - refp).abs().max().item() <= 1e-4 * scale
+        # pooled values are the maxima of the stored full-resolution values up to the encoding's own rounding
+        assert (gotp - F.max_pool2d(got, 2, 2)).abs().max().item() <= 2e-7 * scale + 1e-30
+
+
+def test_conv3x3_pl_fused_head_and_no_relu():
+    n, h, w = 2, 24, 40
+    x = rand_act((n, 64, h, w), "plh/x")
+    wt, b = _w("plh/w", (64, 64, 3, 3), (6.0 / 576) ** 0.5), _w("plh/b", (64,), 0.1)
+    hw_, hb = _w("plh/hw", (1, 64, 1, 1), 0.3), _w("plh/hb", (1,), 0.1)
+    mid = F.relu(unet_ref.conv3x3_reflect(x, wt, b))
+    logit_ref = F.conv2d(mid, hw_, hb)
+    wp = ops.pack_conv3x3(wt.to(DEV), M)
+    out, logit, y = ops.conv3x3_pl(planar_encode(x), None, wp, b.to(DEV), 64, head_w=hw_.to(DEV), head_b=hb.to(DEV), want_logit=True, want_y=True)
+    assert (logit.cpu() - logit_ref).abs().max().item() <= 1e-4 * logit_ref.abs().max().item()
+    assert (out.cpu() - torch.sigmoid(logit_ref)).abs().max().item() <= 2e-5
+    assert (planar_decode(y) - mid).abs().max().item() <= 1e-4 * mid.abs().max().item()
+    out2 = ops.conv3x3_pl(planar_encode(x), None, wp, b.to(DEV), 64, head_w=hw_.to(DEV), head_b=hb.to(DEV), want_y=False)
+    assert torch.equal(out2, out)                                          # the head alone (y never stored) gives the same bits
+    # relu = False keeps negative values (signed f16 / e4m3 encodings)
+    y2 = ops.conv3x3_pl(planar_encode(x), None, wp, b.to(DEV), 64, relu=False)
+    pre = unet_ref.conv3x3_reflect(x, wt, b)
+    assert (planar_decode(y2) - pre).abs().max().item() <= 1e-4 * pre.abs().max().item() and pre.min().item() < 0
+
+
+def test_conv3x3_pl_is_deterministic_and_batch_position_invariant():
+    x = rand_act((4, 64, 32, 64), "pld/x")
+    x[2] = x[0]
+    wt, b = _w("pld/w", (128, 64, 3, 3), (6.0 / 576) ** 0.5), _w("pld/b", (128,), 0.1)
+    wp = ops.pack_conv3x3(wt.to(DEV), M)
+    xe = planar_encode(x)
+    y1 = ops.conv3x3_pl(xe, None, wp, b.to(DEV), 128)
+    y2 = ops.conv3x3_pl(xe, None, wp, b.to(DEV), 128)
+    assert torch.equal(y1, y2) and torch.equal(y1[0], y1[2])

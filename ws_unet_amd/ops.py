@@ -247,6 +247,44 @@ def conv3x3_fused_first(x_nchw: torch.Tensor, w1: torch.Tensor, b1: Optional[tor
     return y
 
 
+def planar_shape(n: int, c: int, h: int, w: int):
+    """Allocation shape (float32-typed) of a planar 'F16F8P' activation tensor: [n][C/16][4 planes][H][W][16 B] (include/wsu.h)."""
+    return (n, c // 16, 4, h, w, 4)
+
+
+def conv3x3_pl(x1: torch.Tensor, x2: Optional[torch.Tensor], w_packed: torch.Tensor, bias: Optional[torch.Tensor], cout: int,
+               relu: bool = True, pool: bool = False, want_y: bool = True,
+               head_w: Optional[torch.Tensor] = None, head_b: Optional[torch.Tensor] = None, want_logit: bool = False):
+    """3x3 reflect conv (+ReLU, +2x2 max-pool, +1x1 head and sigmoid) on planar F16F8P activations (wsu_conv3x3_pl_fwd).
+    x1 / x2: planar tensors (N, C/16, 4, H, W, 4); w_packed from pack_conv3x3(mode f16f8).  Returns y [, y_pool] or, with head_w,
+    out [, logit][, y]."""
+    lib = _lib.load()
+    hw2 = None if head_w is None else head_w.detach().reshape(head_w.shape[0], -1).contiguous()
+    _dev_check(x1, x2, w_packed, bias, hw2, head_b)
+    assert x1.dtype == torch.float32 and x1.dim() == 6 and x1.shape[2] == 4 and x1.shape[5] == 4 and x1.is_contiguous()
+    n, nch1, _, h, w, _ = x1.shape
+    c1 = nch1 * 16
+    c2 = 0
+    if x2 is not None:
+        assert x2.dtype == torch.float32 and x2.dim() == 6 and x2.shape[0] == n and x2.shape[3:5] == x1.shape[3:5] and x2.is_contiguous()
+        c2 = x2.shape[1] * 16
+    y = torch.empty(planar_shape(n, cout, h, w), dtype=torch.float32, device=x1.device) if want_y else None
+    yp = torch.empty(planar_shape(n, cout, h // 2, w // 2), dtype=torch.float32, device=x1.device) if pool else None
+    hc = 0 if hw2 is None else hw2.shape[0]
+    out = torch.empty((n, hc, h, w), dtype=torch.float32, device=x1.device) if hc else None
+    logit = torch.empty_like(out) if (hc and want_logit) else None
+    meta = {"flops": 2.0 * 9 * (c1 + c2) * cout * n * h * w,
+            "bytes": float(n * h * w * ((c1 + c2) * 4 + (cout * 4 if want_y else 0) + hc * 4) + (n * (h // 2) * (w // 2) * cout * 4 if pool else 0)
+                           + 9 * (c1 + c2) * cout * 4)}
+    check(_launch("conv3x3_pl", meta, lambda: lib.wsu_conv3x3_pl_fwd(
+        x1.data_ptr(), _ptr(x2), w_packed.data_ptr(), _ptr(bias), _ptr(y), _ptr(yp), _ptr(hw2), _ptr(head_b), _ptr(out), _ptr(logit), hc,
+        n, h, w, c1, c2, cout, int(relu), _stream())), "wsu_conv3x3_pl_fwd")
+    if hc:
+        res = [out] + ([logit] if want_logit else []) + ([y] if want_y else [])
+        return res[0] if len(res) == 1 else tuple(res)
+    return (y, yp) if pool else y
+
+
 def pack_conv3x3_wino(w: torch.Tensor) -> torch.Tensor:
     """OIHW fp32 -> Winograd F(2,3) packed weights of wsu_conv3x3_wino_fwd (mode bf16x3)."""
     lib = _lib.load()
