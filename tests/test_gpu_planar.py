@@ -79,3 +79,29 @@ def test_conv3x3_pl_is_deterministic_and_batch_position_invariant():
     y1 = ops.conv3x3_pl(xe, None, wp, b.to(DEV), 128)
     y2 = ops.conv3x3_pl(xe, None, wp, b.to(DEV), 128)
     assert torch.equal(y1, y2) and torch.equal(y1[0], y1[2])
+
+
+def test_conv3x3_pl_race_screen():
+    """Many launches of the pipelined kernel (DMA stages, loader / matrix waves, register epilogue with the fused head): every result
+    bitwise equal to the first (a hand-off placed one barrier too early shows up as rare wrong tiles, not as a consistent error)."""
+    x = rand_act((16, 64, 48, 80), "plr/x")
+    wt, b = _w("plr/w", (64, 64, 3, 3), (6.0 / 576) ** 0.5), _w("plr/b", (64,), 0.1)
+    hw_, hb = _w("plr/hw", (1, 64, 1, 1), 0.3), _w("plr/hb", (1,), 0.1)
+    wp = ops.pack_conv3x3(wt.to(DEV), M)
+    xe = planar_encode(x)
+    args = dict(head_w=hw_.to(DEV), head_b=hb.to(DEV), want_logit=True, want_y=True)
+    ref = [t.clone() for t in ops.conv3x3_pl(xe, None, wp, b.to(DEV), 64, **args)]
+    for it in range(150):
+        out = ops.conv3x3_pl(xe, None, wp, b.to(DEV), 64, **args)
+        if it % 4 == 0:
+            torch.randn(1 << 18, device=DEV).sum()                      # vary the timing of the next launch
+        for a_, b_ in zip(out, ref):
+            assert torch.equal(a_, b_), f"launch {it} differs"
+    # several tiles per workgroup (the next tile's DMA runs under the epilogue)
+    x2 = rand_act((24, 64, 128, 128), "plr/x2")
+    xe2 = planar_encode(x2)
+    ref2 = [t.clone() for t in ops.conv3x3_pl(xe2, None, wp, b.to(DEV), 64, pool=True)]
+    for it in range(40):
+        out = ops.conv3x3_pl(xe2, None, wp, b.to(DEV), 64, pool=True)
+        for a_, b_ in zip(out, ref2):
+            assert torch.equal(a_, b_), f"launch {it} differs"

@@ -1,0 +1,41 @@
+"""Phase stamps of conv3x3_pl (WSU_PL_STAMP=1): shader cycles per chunk step spent waiting for the DMA, in the barrier, issuing the
+next DMA, in the matrix section, and per tile in the epilogue; in-kernel clock = s_memtime / s_memrealtime x 100 MHz.
+    WSU_PL_STAMP=1 python tools/stamp_pl.py cin cout hw [c2]"""
+import ctypes, os, sys
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import numpy as np, torch
+from ws_unet_amd import _lib
+_lib.LIB_PATH = Path(_lib.LIB_PATH).parent / "libwsu_plstamp.so"          # `make -C ws_unet_amd/csrc probes`
+from ws_unet_amd import ops
+sys.path.insert(0, str(Path(__file__).resolve().parent))
+from time_pl import enc_planar          # noqa: E402  (runs nothing: time_pl guards its main)
+cin, cout, hw = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+c2 = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+n = 32
+M = ops.mode_id("f16f8")
+g = torch.Generator(device="cuda").manual_seed(1)
+def act(c):
+    base = [enc_planar(torch.randn(1, hw, hw, c, device="cuda", generator=g).clamp_min(0)) for _ in range(4)]
+    return torch.cat(base * (n // 4))
+p1 = act(cin - c2); p2 = act(c2) if c2 else None
+w = torch.randn(cout, cin, 3, 3, device="cuda", generator=g) * (2.0 / (9 * cin)) ** 0.5
+wp = ops.pack_conv3x3(w, M); b = torch.zeros(cout, device="cuda")
+for _ in range(20):
+    ops.conv3x3_pl(p1, p2, wp, b, cout)
+torch.cuda.synchronize()
+lib = _lib.load()
+buf = (ctypes.c_ulonglong * (256 * 8))()
+lib.wsu_debug_read_pl_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
+assert lib.wsu_debug_read_pl_stamps(buf, 256) == 0
+allrows = np.array(buf[:], dtype=np.float64).reshape(128, 2, 8)
+ld = allrows[:, 1][allrows[:, 1, 7] > 0]
+s = allrows[:, 0][allrows[:, 0, 7] > 0]
+J = s[:, 7]
+print(f"cin={cin} cout={cout} hw={hw} c2={c2}: workgroups {len(s)}, steps/WG {np.median(J):.0f}")
+print(f"  loader wave: wait vmcnt {np.median(ld[:, 2] / ld[:, 7]):.0f}  barrier {np.median(ld[:, 3] / ld[:, 7]):.0f}  DMA issue {np.median(ld[:, 4] / ld[:, 7]):.0f} cycles/step")
+print(f"  in-kernel clock {np.median(s[:, 0] / s[:, 1]) * 0.1:.3f} GHz; kernel {np.median(s[:, 1]) / 100:.0f} us; cycles/step {np.median(s[:, 0] / J):.0f}")
+for k, name in ((2, "wait vmcnt"), (3, "barrier"), (4, "DMA issue (+tile plan)"), (5, "matrix section")):
+    print(f"  {name:24s} {np.median(s[:, k] / J):8.0f} cycles/step  ({100 * np.median(s[:, k] / s[:, 0]):.1f} %)")
+ntile = J / ((cin) // 16)
+print(f"  {'epilogue':24s} {np.median(s[:, 6] / ntile):8.0f} cycles/tile  ({100 * np.median(s[:, 6] / s[:, 0]):.1f} %)")

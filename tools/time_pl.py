@@ -67,7 +67,8 @@ def run(cin, cout, hw, n=32, c2=0, rounds=2, pool=False, head=False):
           f"planar {min(tn):.0f} us ({fl / min(tn) / 1e6:.0f} TF/s)  speed-up {min(to) / min(tn):.2f}x", flush=True)
 
 
-rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 2
-run(64, 64, 512, rounds=rounds); run(64, 128, 256, rounds=rounds); run(128, 128, 256, rounds=rounds, pool=True)
-run(256, 256, 128, rounds=rounds); run(256, 128, 256, c2=128, rounds=rounds); run(128, 64, 512, c2=64, rounds=rounds)
-run(64, 64, 512, rounds=rounds, head=True); run(64, 64, 512, rounds=rounds, pool=True)
+if __name__ == "__main__":
+    rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+    run(64, 64, 512, rounds=rounds); run(64, 128, 256, rounds=rounds); run(128, 128, 256, rounds=rounds, pool=True)
+    run(256, 256, 128, rounds=rounds); run(256, 128, 256, c2=128, rounds=rounds); run(128, 64, 512, c2=64, rounds=rounds)
+    run(64, 64, 512, rounds=rounds, head=True); run(64, 64, 512, rounds=rounds, pool=True)

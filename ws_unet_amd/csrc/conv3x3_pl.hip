@@ -18,6 +18,7 @@
 // Replaces nn.Conv2d(k=3, reflect) + F.relu (+ torch.cat, nn.MaxPool2d, outconv + sigmoid) of src/unet/model/unet.py:141-189 like
 // conv3x3.hip; same packed weights (wsu_conv3x3_pack, mode F16F8).
 #include "wsu_device.h"
+#include <cstdlib>
 
 namespace {
 
@@ -29,13 +30,18 @@ constexpr int LDS_W = 9 * WSU_GRAN * WSU_COB * 16;        // 36864
 constexpr int STAGE = LDS_IN + LDS_W;                     // 76032
 constexpr int LDS_EXTRA = 2 * STAGE;                      // bias [1024] | head_w [4][64] | head_b [4]
 constexpr int LDS_TOTAL = LDS_EXTRA + 1024 * 4 + 4 * 64 * 4 + 16;
-constexpr int NT = 512, NWAVE = 8;
+constexpr int NWAVE = 8, NLOAD = 4, NT = (NWAVE + NLOAD) * 64;      // 8 matrix waves + 4 loader waves (one per SIMD)
 constexpr int IN_SEG = (NPIX + 63) / 64;                  // 10 wave-instructions per plane (the last one 36 lanes wide)
 constexpr int IN_SLOTS = WSU_GRAN * IN_SEG;               // 40
-constexpr int IN_PER_WAVE = IN_SLOTS / NWAVE;             // 5
+// The DMA of a step is issued by two dedicated LOADER waves (waves 8, 9: 38 pieces each), the matrix waves never touch the vector-memory
+// pipe inside the loop.  Measured on the way (profiles/r02/conv3x3_pl_stamps.md): a piece costs its issuing wave ~150 cycles in the
+// queue, so (v1) all eight waves issuing their pieces after the barrier idled the matrix pipe for 2-3 k cycles per step, (v2/v4)
+// threading the pieces through the matrix section stalled the in-order waves just as long, (v3) giving them to one wave per SIMD let its
+// partner run alone (68 % pipe time).  A wave that only loads costs 168 instead of 256 registers per matrix wave -- nothing else.
+constexpr int IN_PER_WAVE = IN_SLOTS / NLOAD;             // 20
 constexpr int W_SLOTS = LDS_W / 1024;                     // 36
-constexpr int W_PER_WAVE = (W_SLOTS + NWAVE - 1) / NWAVE; // 5 (waves 4..7: 4)
-static_assert(IN_SLOTS % NWAVE == 0, "input DMA slots divide over the waves");
+constexpr int W_PER_WAVE = W_SLOTS / NLOAD;               // 18
+static_assert(IN_SLOTS % NLOAD == 0 && W_SLOTS % NLOAD == 0, "DMA slots divide over the loader waves");
 
 struct PlArgs {
     const char* x1; const char* x2; const char* wp; const float* bias;
@@ -45,9 +51,14 @@ struct PlArgs {
     int tiles_x, tiles_y, ncb, nch1, nch;
     int relu;
     int ntiles;                                           // n * tiles_y * tiles_x * ncb
+    int stamp;                                            // WSU_PL_STAMP=1: diagnostic phase stamps (tools/stamp_pl.py)
 };
 
 struct Tile { int n, y0, x0, cb; };
+
+// Diagnostic stamps (never in production: args.stamp = 0): per workgroup the accumulated shader cycles of each phase of the chunk loop and
+// the s_memrealtime span, read back with wsu_debug_read_pl_stamps().  Values go to a buffer nothing else reads.
+__device__ unsigned long long g_pl_stamps[256 * 8];
 
 __device__ __forceinline__ Tile tile_of(const PlArgs& a, int t) {
     Tile r;
@@ -62,11 +73,11 @@ typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void glb_void;
 
 // source offsets (in 16-byte units, inside one chunk's 4 planes of one image) of this lane's 5 input DMA slots; -1 = lane idle
-__device__ __forceinline__ void plan_tile(const PlArgs& a, const Tile& t, int wv, int lane, int (&goff)[IN_PER_WAVE]) {
+__device__ __forceinline__ void plan_tile(const PlArgs& a, const Tile& t, int lw8, int lane, int (&goff)[IN_PER_WAVE]) {
     const int hw = a.h * a.w;
 #pragma unroll
     for (int k = 0; k < IN_PER_WAVE; ++k) {
-        const int slot = wv + NWAVE * k;
+        const int slot = lw8 + NLOAD * k;
         const int plane = slot / IN_SEG, seg = slot - plane * IN_SEG;
         const int idx = seg * 64 + lane;
         const int r = idx / IW, c = idx - r * IW;
@@ -75,25 +86,41 @@ __device__ __forceinline__ void plan_tile(const PlArgs& a, const Tile& t, int wv
     }
 }
 
-// LDS-DMA of chunk c of tile t into stage `st`: 40 input pieces + 36 weight pieces of 1 KiB, 9-10 per wave, nothing waits here
-__device__ __forceinline__ void issue_dma(const PlArgs& a, int tn, int tcb, int c, char* st, int wv, int lane, const int (&goff)[IN_PER_WAVE]) {
+// LDS-DMA of one chunk into a stage = 40 input pieces + 36 weight pieces of 1 KiB: slots 0..4 of a wave are its input pieces (plane and
+// segment follow from wave + 8 k), slots 5..9 its weight pieces.  The slots are issued ONE AT A TIME between the tap groups of the
+// matrix section (stamps of the first version, profiles/r02/conv3x3_pl_stamps.md: issuing all of a wave's pieces back to back right
+// after the barrier took 2-3 k cycles per step during which BOTH waves of every SIMD were in their issue phase and the matrix pipe idle).
+struct DmaPlan { const char* in_src; const char* w_src; char* st; };
+
+__device__ __forceinline__ DmaPlan dma_plan(const PlArgs& a, int tn, int tcb, int c, char* st, int lane) {
     const size_t plane4 = (size_t)a.h * a.w * 64;                       // bytes of one chunk of one image (4 planes)
-    const char* src = c < a.nch1 ? a.x1 + ((size_t)tn * a.nch1 + c) * plane4
-                                 : a.x2 + ((size_t)tn * (a.nch - a.nch1) + (c - a.nch1)) * plane4;
-#pragma unroll
-    for (int k = 0; k < IN_PER_WAVE; ++k) {
-        const int slot = wv + NWAVE * k;
+    DmaPlan p;
+    p.in_src = c < a.nch1 ? a.x1 + ((size_t)tn * a.nch1 + c) * plane4
+                          : a.x2 + ((size_t)tn * (a.nch - a.nch1) + (c - a.nch1)) * plane4;
+    p.w_src = a.wp + ((size_t)tcb * a.nch + c) * LDS_W + lane * 16;
+    p.st = st;
+    return p;
+}
+
+template <int K>
+__device__ __forceinline__ void dma_slot(const DmaPlan& p, int lw8, const int (&goff)[IN_PER_WAVE]) {
+    if constexpr (K < IN_PER_WAVE) {
+        const int slot = lw8 + NLOAD * K;
         const int plane = slot / IN_SEG, seg = slot - plane * IN_SEG;
-        if (goff[k] >= 0)
-            __builtin_amdgcn_global_load_lds((glb_void*)(src + (size_t)goff[k] * 16), (lds_void*)(st + plane * PLANE + seg * 1024), 16, 0, 0);
-    }
-    const char* wsrc = a.wp + ((size_t)tcb * a.nch + c) * LDS_W + lane * 16;
-#pragma unroll
-    for (int k = 0; k < W_PER_WAVE; ++k) {
-        const int slot = wv + NWAVE * k;
+        if (goff[K] >= 0)
+            __builtin_amdgcn_global_load_lds((glb_void*)(p.in_src + (size_t)goff[K] * 16), (lds_void*)(p.st + plane * PLANE + seg * 1024), 16, 0, 0);
+    } else {
+        const int slot = lw8 + NLOAD * (K - IN_PER_WAVE);
         if (slot < W_SLOTS)
-            __builtin_amdgcn_global_load_lds((glb_void*)(wsrc + slot * 1024), (lds_void*)(st + LDS_IN + slot * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void*)(p.w_src + slot * 1024), (lds_void*)(p.st + LDS_IN + slot * 1024), 16, 0, 0);
     }
+}
+
+__device__ __forceinline__ void issue_dma(const PlArgs& a, int tn, int tcb, int c, char* st, int lw8, int lane, const int (&goff)[IN_PER_WAVE]) {
+    const DmaPlan p = dma_plan(a, tn, tcb, c, st, lane);
+    // weight and input pieces alternate, so that the first pieces of both operands land early
+    WSU_STATIC_FOR(W_PER_WAVE, k, { dma_slot<k>(p, lw8, goff); dma_slot<IN_PER_WAVE + k>(p, lw8, goff); });
+    WSU_STATIC_FOR(IN_PER_WAVE - W_PER_WAVE, k, { dma_slot<W_PER_WAVE + k>(p, lw8, goff); });
 }
 
 __device__ __forceinline__ void swap32(uint32_t& upper_of, uint32_t& lower_of) {
@@ -102,7 +129,14 @@ __device__ __forceinline__ void swap32(uint32_t& upper_of, uint32_t& lower_of) {
     upper_of = r[0]; lower_of = r[1];
 }
 
-__global__ __launch_bounds__(NT, 2) void conv3x3_pl_kernel(const PlArgs a) {
+// Stamps are compiled in only with -DWSU_PL_STAMPS (make probes -> libwsu_plstamp.so): in the product build STAMP() is empty.
+#ifdef WSU_PL_STAMPS
+#define STAMP(var) var = __builtin_amdgcn_s_memtime()
+#else
+#define STAMP(var) do {} while (0)
+#endif
+
+__global__ __launch_bounds__(NT) void conv3x3_pl_kernel(const PlArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
@@ -119,33 +153,67 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_pl_kernel(const PlArgs a) {
         for (int i = tid; i < a.head_cout * 64; i += NT) s_hw[i] = a.head_w[i];
         if (tid < 4) s_hb[tid] = (a.head_b && tid < a.head_cout) ? a.head_b[tid] : 0.f;
     }
-    // the plain loads above must have retired before the first counted / zero vmcnt wait below means anything: they have, the values
-    // were consumed by the LDS stores; the barrier of step 0 publishes them
+    // (these plain loads have retired -- their values went into the LDS stores -- before the first vmcnt wait below; the barrier of
+    // step 0 publishes them)
+    unsigned long long t_wait = 0, t_bar = 0, t_dma = 0, t_mma = 0, t_epi = 0, t0 = 0, rt0 = 0;
+    unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0;
+    STAMP(t0);
+#ifdef WSU_PL_STAMPS
+    rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
 
-    int goff[IN_PER_WAVE];
-    Tile cur = tile_of(a, lw), nxt = cur;
-    if (J > 0) {
-        plan_tile(a, cur, wv, lane, goff);
-        issue_dma(a, cur.n, cur.cb, 0, smem, wv, lane, goff);
+    if (wv >= NWAVE) {
+        // ================= loader waves: the whole DMA of step j+1 right after the barrier that opens step j ========================
+        const int lw8 = wv - NWAVE;
+        int goff[IN_PER_WAVE];
+        Tile t = tile_of(a, lw);
+        if (J > 0) {
+            plan_tile(a, t, lw8, lane, goff);
+            issue_dma(a, t.n, t.cb, 0, smem, lw8, lane, goff);
+        }
+        int c = 0, kt = 0;
+        for (int j = 0; j < J; ++j) {
+            STAMP(s0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // this wave's pieces of step j have landed
+            STAMP(s1);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            STAMP(s2);
+            if (j + 1 < J) {
+                if (++c == a.nch) {
+                    c = 0; ++kt;
+                    t = tile_of(a, lw + kt * G);
+                    plan_tile(a, t, lw8, lane, goff);
+                }
+                issue_dma(a, t.n, t.cb, c, smem + ((j + 1) & 1) * STAGE, lw8, lane, goff);
+            }
+            STAMP(s3);
+            t_wait += s1 - s0; t_bar += s2 - s1; t_dma += s3 - s2;
+        }
+#ifdef WSU_PL_STAMPS
+        if (lane == 0 && wv == NWAVE && blockIdx.x < 128) {
+            unsigned long long* d = g_pl_stamps + (blockIdx.x * 2 + 1) * 8;
+            d[0] = __builtin_amdgcn_s_memtime() - t0; d[1] = __builtin_amdgcn_s_memrealtime() - rt0;
+            d[2] = t_wait; d[3] = t_bar; d[4] = t_dma; d[5] = 0; d[6] = 0; d[7] = (unsigned long long)J;
+        }
+#endif
+        return;
     }
 
+    // ================= matrix waves ===================================================================================================
+    Tile cur = tile_of(a, lw);
     f32x16 acc[2][2];
     const int sc_a = hh ? WSU_F8_SCALE_WLO : WSU_F8_SCALE_W, sc_b = hh ? WSU_F8_SCALE_X : WSU_F8_SCALE_XLO;
     int c = 0, kt = 0;                                                        // chunk inside the tile, tile counter
     for (int j = 0; j < J; ++j) {
-        // ---- step j: its DMA (issued one step ago) has had a whole matrix section to land -------------------------------------
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                                         // everyone's pieces landed; everyone left the other stage
+        // ---- step j: its DMA (issued by the loaders one step ago) has had a whole matrix section to land -----------------------
+        STAMP(s0);
+        STAMP(s1);
+        __builtin_amdgcn_s_barrier();                                         // the loaders' pieces landed; everyone left the other stage
         asm volatile("" ::: "memory");
+        STAMP(s2);
         char* st = smem + (j & 1) * STAGE;
-        if (j + 1 < J) {
-            const int cn = c + 1 == a.nch ? 0 : c + 1;
-            if (cn == 0) {
-                nxt = tile_of(a, lw + (kt + 1) * G);
-                plan_tile(a, nxt, wv, lane, goff);
-            }
-            issue_dma(a, cn == 0 ? nxt.n : cur.n, cn == 0 ? nxt.cb : cur.cb, cn, smem + ((j + 1) & 1) * STAGE, wv, lane, goff);
-        }
+        STAMP(s3);
         if (c == 0) {
 #pragma unroll
             for (int m = 0; m < 2; ++m)
@@ -203,6 +271,8 @@ _Pragma("unroll")
             if constexpr (2 * tp + 1 < 9) main_term(std::integral_constant<int, 2 * tp + 1>{});
         });
 
+        STAMP(s4);
+        t_wait += s1 - s0; t_bar += s2 - s1; t_dma += s3 - s2; t_mma += s4 - s3;
         // ---- epilogue of the tile: accumulators -> planar global memory ---------------------------------------------------------
         if (c + 1 == a.nch) {
             const int col = cur.x0 + l31;
@@ -290,7 +360,9 @@ _Pragma("unroll")
 #pragma unroll
                     for (int o = 0; o < 4; ++o)
                         if (o < a.head_cout) {
-                            const float z = hz[q][o] + __shfl_xor(hz[q][o], 32, 64) + s_hb[o];
+                            uint32_t mine = __builtin_bit_cast(uint32_t, hz[q][o]), other = mine;
+                            swap32(mine, other);                            // lanes 0-31: other = partner's sum; lanes 32-63: mine = partner's
+                            const float z = __builtin_bit_cast(float, mine) + __builtin_bit_cast(float, other) + s_hb[o];
                             if (!hh && row < a.h && col < a.w) {
                                 const size_t off = ((size_t)cur.n * a.head_cout + o) * hw + (size_t)row * a.w + col;
                                 if (a.head_logit) a.head_logit[off] = z;
@@ -299,18 +371,34 @@ _Pragma("unroll")
                         }
                 }
             }
-            cur = nxt;
             ++kt;
             c = 0;
+            if (j + 1 < J) cur = tile_of(a, lw + kt * G);
+#ifdef WSU_PL_STAMPS
+            t_epi += __builtin_amdgcn_s_memtime() - s4;
+#endif
         } else {
             ++c;
         }
     }
+#ifdef WSU_PL_STAMPS
+    if (tid == 64 && blockIdx.x < 128) {                                       // matrix wave 1's view
+        unsigned long long* d = g_pl_stamps + (blockIdx.x * 2) * 8;
+        d[0] = __builtin_amdgcn_s_memtime() - t0; d[1] = __builtin_amdgcn_s_memrealtime() - rt0;
+        d[2] = t_wait; d[3] = t_bar; d[4] = t_dma; d[5] = t_mma; d[6] = t_epi; d[7] = (unsigned long long)J;
+    }
+#endif
 }
 
 }  // namespace
 
 extern "C" {
+
+// diagnostic only (rows alternate: matrix wave 1, loader wave 8 of workgroups 0..127) (not part of include/wsu.h): phase stamps of the last conv3x3_pl launch with WSU_PL_STAMP=1
+int wsu_debug_read_pl_stamps(unsigned long long* host_dst, int nblocks) {
+    if (nblocks > 256) nblocks = 256;
+    return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_pl_stamps), (size_t)nblocks * 8 * sizeof(unsigned long long)) == hipSuccess ? 0 : -2;
+}
 
 // Forward 3x3 reflect conv + bias + ReLU on planar F16F8P activations (layout: wsu.h).  x1 (c1 channels) and optional x2 (c2, fused
 // concat), packed weights of wsu_conv3x3_pack(mode F16F8); outputs, each optional: y (cout channels, planar), y_pool (2x2 max-pooled,
@@ -336,6 +424,7 @@ int wsu_conv3x3_pl_fwd(const void* x1, const void* x2, const void* w_packed, con
     const long long nt = (long long)n * a.tiles_x * a.tiles_y * a.ncb;
     WSU_REQUIRE(nt > 0 && nt < 0x3FFFFFFFLL, "conv3x3_pl: %lld tiles out of range", nt);
     a.ntiles = (int)nt;
+    a.stamp = 0;
     static int ncu = 0;
     if (ncu == 0) {
         int dev = 0; hipDeviceProp_t prop;
