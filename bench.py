@@ -13,9 +13,10 @@ Workload (`config.workload`): BASELINE.json configs[1] -- `unet_2` forward-only 
 One step = one forward pass over one batch.  Multi-GPU = batch sharding: each rank predicts its own 32 images (weak
 scaling), no data-path collective; a barrier brackets the timed region and the slowest rank's time is used.
 
-Precision: default mode 'f16f8' (exact f16 products on the f16 matrix pipe + the two residual cross terms on the
-block-scaled fp8 pipe, fp32 accumulate) -- the fastest mode that meets the 1e-4 MAE gate against the fp32 CPU oracle;
-the other modes ('bf16', 'f32', 'bf16x3', 'bf16x3s') are measured in the same run with fewer steps (`other_modes`).
+Precision: default mode 'f16f8p' (exact f16 products on the f16 matrix pipe + the two residual cross terms on the
+block-scaled fp8 pipe, fp32 accumulate; planar activation storage fed by LDS-DMA) -- the fastest mode that meets the
+1e-4 MAE gate against the fp32 CPU oracle; the other modes ('f16f8' = the same arithmetic on NHWC storage, 'bf16', 'f32',
+'bf16x3', 'bf16x3s') are measured in the same run with fewer steps (`other_modes`).
 
 Extra JSON objects on the one line rank 0 prints:
   roofline      dominant kernel = conv3x3 implicit GEMM: algorithmic FLOPs / HIP-event launch time vs the dense f16/bf16 MFMA
@@ -38,7 +39,7 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
-PEAK = {"bf16x3": 2.5e15, "bf16x3s": 2.5e15, "f16f8": 2.5e15, "bf16": 2.5e15, "f32": 157.3e12}     # dense MFMA peaks, MI355X_MICROARCH.md
+PEAK = {"bf16x3": 2.5e15, "bf16x3s": 2.5e15, "f16f8": 2.5e15, "f16f8p": 2.5e15, "bf16": 2.5e15, "f32": 157.3e12}     # dense MFMA peaks, MI355X_MICROARCH.md
 HBM_PEAK = 8.0e12
 TRAIN_FLOP_PER_IMAGE_512 = 606.0e9        # 3 x forward minus the e11 data gradient
 
@@ -48,7 +49,7 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--mode", default=os.environ.get("WSU_BENCH_MODE", "f16f8"), choices=["bf16x3", "bf16x3s", "f16f8", "bf16", "f32"])
+    ap.add_argument("--mode", default=os.environ.get("WSU_BENCH_MODE", "f16f8p"), choices=["bf16x3", "bf16x3s", "f16f8", "f16f8p", "bf16", "f32"])
     ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -324,10 +325,10 @@ def main():
     result = None
     if rank == 0:
         ks = timer.summary()
-        conv = ks["conv3x3"]
+        conv = ks["conv3x3_pl"] if "conv3x3_pl" in ks else ks["conv3x3"]
         achieved = conv["flops"] / (conv["total_ms"] * 1e-3)
         roofline = {
-            "bound": "mfma", "kernel": "conv3x3_kernel", "achieved": achieved / 1e12, "peak": PEAK[args.mode] / 1e12,
+            "bound": "mfma", "kernel": "conv3x3_pl_kernel" if "conv3x3_pl" in ks else "conv3x3_kernel", "achieved": achieved / 1e12, "peak": PEAK[args.mode] / 1e12,
             "unit": "TFLOP/s", "frac": achieved / PEAK[args.mode], "traffic": None,
             "avg_launch_ms": conv["avg_ms"], "launches": conv["launches"],
             "algorithmic_gflop_per_launch": conv["flops"] / conv["launches"] / 1e9,
@@ -338,15 +339,16 @@ def main():
         # matrix-pipe occupancy next to the algorithmic fraction: one unit = one 32x32x16 bf16/f16 MFMA (32 cycles, 32 768 FLOP); per
         # 16-channel chunk and 32x32 output tile a product costs 9 units of work, the modes issue 27 (bf16x3: 3 per tap), 19 (f16f8: 9
         # f16 + 5 fp8 instructions of 2 units), 9 (bf16) -- the fused first layer and the 16x16x32 shape issue the same unit counts
-        units = {"bf16x3": 27 / 9, "bf16x3s": 27 / 9, "f16f8": 19 / 9, "bf16": 1.0}.get(args.mode)
+        units = {"bf16x3": 27 / 9, "bf16x3s": 27 / 9, "f16f8": 19 / 9, "f16f8p": 19 / 9, "bf16": 1.0}.get(args.mode)
         if units is not None:
             roofline["mfma_issue"] = {"units_per_product": units, "tflops_equivalent": achieved * units / 1e12,
                                       "frac_of_peak": achieved * units / PEAK[args.mode],
                                       "note": "matrix-pipe time actually issued (split terms included) against the same dense bf16 peak"}
         roofline.update(pmc_traffic(args, conv["bytes"] / conv["launches"]))
         roofline["per_layer"] = per_layer_roofline(timer, args.mode)
-        if "convt2x2" in ks:
-            ct = ks["convt2x2"]
+        ctk = "convt2x2_pl" if "convt2x2_pl" in ks else "convt2x2"
+        if ctk in ks:
+            ct = ks[ctk]
             bw = ct["bytes"] / (ct["total_ms"] * 1e-3)
             roofline["convt2x2"] = {"bound": "hbm", "achieved": bw / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": bw / HBM_PEAK,
                                     "avg_launch_ms": ct["avg_ms"], "launches": ct["launches"],
@@ -359,6 +361,7 @@ def main():
             "dtype": {"bf16x3": "bf16x3 (bf16 MFMA on split fp32 operands, fp32 accumulate)",
                       "bf16x3s": "bf16x3 (bf16 MFMA on split fp32 operands, fp32 accumulate; activations stored as their hi/lo halves)",
                       "f16f8": "f16f8 (f16 MFMA on the f16 halves + block-scaled fp8 MFMA on the residual cross terms, fp32 accumulate)",
+                      "f16f8p": "f16f8 (f16 MFMA on the f16 halves + block-scaled fp8 MFMA on the residual cross terms, fp32 accumulate; planar storage, LDS-DMA pipeline)",
                       "bf16": "bf16", "f32": "f32"}[args.mode],
             "data": "synthetic",
             "config": {"workload": f"unet_2 forward-only predict, batch={args.batch}/GPU synthetic {args.size}x{args.size}x1 "
@@ -372,7 +375,7 @@ def main():
     # other precision modes, same run, fewer steps (rank 0 only, N = 1 only)
     if rank == 0 and world == 1 and not args.no_other_modes:
         other = {}
-        for md in [m for m in ("bf16", "f32", "bf16x3", "bf16x3s", "f16f8") if m != args.mode]:
+        for md in [m for m in ("bf16", "f32", "bf16x3", "bf16x3s", "f16f8", "f16f8p") if m != args.mode]:
             mm = build_model(md, dev)
             st = max(2, args.steps // 3)
             d2, y2 = timed_steps(mm, x, st, 1, False)

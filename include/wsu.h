@@ -129,6 +129,14 @@ int wsu_conv3x3_pl_fwd(const void* x1, const void* x2, const void* w_packed, con
                        const float* head_w, const float* head_b, float* head_out, float* head_logit, int head_cout,
                        int n, int h, int w, int c1, int c2, int cout, int relu, void* stream);
 
+/* ---- K3p / K0p: the other two kernels of the planar (F16F8P) inference path (csrc/planar.hip).
+ *      wsu_convt2x2_pl_fwd: nn.ConvTranspose2d(k2, s2) + bias (unet.py:125,130,177,183), x: cin channels at (h, w) planar -> y: cout channels at
+ *      (2h, 2w) planar; weights from wsu_convt2x2_pack(mode F16F8); cin a multiple of 32, cout of 64.
+ *      wsu_conv3x3_first_pl_fwd: the first layer e11 (unet.py:82,141), x_nchw (N, cin <= 8, H, W) fp32 -> y: cout (multiple of 16) channels planar. */
+int wsu_convt2x2_pl_fwd(const void* x, const void* w_packed, const float* bias, void* y, int n, int h, int w, int cin, int cout, void* stream);
+int wsu_conv3x3_first_pl_fwd(const float* x_nchw, const float* w_oihw, const float* bias, void* y, int n, int h, int w, int cin, int cout,
+                             int relu, void* stream);
+
 /* ---- first layer: conv3x3 reflect on a few input planes given as NCHW fp32 (the model input).
  *      Replaces e11 (unet.py:82,141).  cin <= 8, cout multiple of 8.  w is plain OIHW fp32. */
 int wsu_conv3x3_first_fwd(const float* x_nchw, const float* w_oihw, const float* bias, void* y,

@@ -105,3 +105,40 @@ def test_conv3x3_pl_race_screen():
         out = ops.conv3x3_pl(xe2, None, wp, b.to(DEV), 64, pool=True)
         for a_, b_ in zip(out, ref2):
             assert torch.equal(a_, b_), f"launch {it} differs"
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 32, 128, 64), (1, 5, 37, 256, 128), (1, 1, 1, 32, 64), (3, 16, 64, 64, 64)])
+def test_convt2x2_pl_matches_oracle(shape):
+    n, h, w, cin, cout = shape
+    x = rand_act((n, cin, h, w), f"plt/x/{shape}")
+    wt = _w(f"plt/w/{shape}", (cin, cout, 2, 2), (6.0 / cin) ** 0.5)
+    b = _w(f"plt/b/{shape}", (cout,), 0.1)
+    ref = F.conv_transpose2d(x, wt, b, stride=2)
+    y = ops.convt2x2_pl(planar_encode(x), ops.pack_convt2x2(wt.to(DEV), M), b.to(DEV), cout)
+    got = planar_decode(y)
+    assert got.shape == ref.shape
+    assert (got - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
+    y2 = ops.convt2x2_pl(planar_encode(x), ops.pack_convt2x2(wt.to(DEV), M), b.to(DEV), cout)
+    assert torch.equal(y, y2)
+
+
+@pytest.mark.parametrize("cin,cout,h,w", [(1, 64, 20, 36), (3, 32, 7, 9), (1, 64, 2, 2)])
+def test_first_layer_pl_matches_oracle(cin, cout, h, w):
+    x = rand_act((2, cin, h, w), f"plf/x/{cin}/{h}", relu=False)
+    wt, b = _w(f"plf/w/{cin}", (cout, cin, 3, 3), 0.5), _w(f"plf/b/{cin}", (cout,), 0.1)
+    ref = F.relu(unet_ref.conv3x3_reflect(x, wt, b))
+    y = ops.conv3x3_first_pl(x.to(DEV), wt.to(DEV), b.to(DEV))
+    got = planar_decode(y)
+    assert (got - ref).abs().max().item() <= 2e-5 * max(ref.abs().max().item(), 1e-6)          # fp32 FMAs + the encoding's 2^-15
+
+
+def test_unet_planar_mode_equals_nhwc_mode_closely():
+    """The planar path runs the arithmetic of 'f16f8' (same packed weights, same per-chunk accumulation order), so the two modes agree far
+    inside their common tolerance against the oracle; whole-network goldens for 'f16f8p' are in test_gpu_forward.py (NET_MODES)."""
+    from gpu_util import gpu_model, images01
+    _, x = images01(3, 64, 96, seed=5)
+    with torch.no_grad():
+        ya = gpu_model(2, "he", "f16f8")(x.to(DEV))
+        yb = gpu_model(2, "he", "f16f8p")(x.to(DEV))
+    d = (ya - yb).abs()
+    assert d.max().item() <= 1e-4 and d.mean().item() <= 1e-5, (d.max().item(), d.mean().item())

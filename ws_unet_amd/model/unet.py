@@ -14,6 +14,9 @@ Precision modes (``mode=`` or env ``WSU_MODE``):
   'bf16'    bf16 storage + MFMA                 -- fastest; MAE ~1e-3 on full-range weights
   'bf16x3s' bf16x3 with producer-side split     -- bitwise the results of 'bf16x3', activations stored as hi/lo halves
                                                    between the fused first layer and the fused head (keep= / autograd use 'bf16x3')
+  'f16f8p'  the 'f16f8' arithmetic on PLANAR storage -- [n][C/16][4 planes][H][W][16 B], the LDS image of the matrix kernels: staging is a
+                                                   pure LDS-DMA and one persistent workgroup per CU pipelines it across chunks and tiles
+                                                   (csrc/conv3x3_pl.hip, planar.hip); same values as 'f16f8' up to the accumulation order
   'f16f8'   f16 products + fp8 cross terms      -- default: f16(w)*f16(x) exactly, the two residual cross terms on the block-scaled fp8
                                                    matrix pipe (0.70 of bf16x3's matrix cycles, ~2^-15 relative error per product, MAE
                                                    4e-6 on the full-range test weights); same storage discipline as 'bf16x3s'.
@@ -81,7 +84,7 @@ class UNet(nn.Module):
         if nsteps > 4:
             raise NotImplementedError("the reference defines at most 4 pooling steps (unet.py:85-132)")
         self.nsteps = nsteps
-        self.mode = mode or os.environ.get("WSU_MODE", "f16f8")
+        self.mode = mode or os.environ.get("WSU_MODE", "f16f8p")
         self.fuse_head = os.environ.get("WSU_FUSE_HEAD", "1") != "0"  # fold outconv + sigmoid into the last 3x3 conv
         self.fuse_first = os.environ.get("WSU_FUSE_FIRST", "1") != "0"  # fold e11 into e12's input staging
         # arithmetic of the autograd path: exact fp32 MFMA for an 'f32' model, split-bf16 (fp32 storage and accumulation,
@@ -158,6 +161,11 @@ class UNet(nn.Module):
         t = keep if keep is not None else {}
         save = keep is not None
         e11 = self.e11
+        if m == ops.MODE_F16F8P:
+            if save or not self._planar_ok():
+                m = ops.MODE_BF16X3             # intermediates are only kept in fp32 NHWC; odd channel counts take the general path
+            else:
+                return self._forward_planar(x, want_logit)
         if m in (ops.MODE_BF16X3S, ops.MODE_F16F8) and (save or self.nsteps < 1 or not (self.fuse_first and self.fuse_head)
                                      or e11.in_channels != 1 or e11.out_channels != 64 or self.outconv.out_channels > 4):
             m = ops.MODE_BF16X3             # the split formats live only between the fused first layer and the fused head
@@ -232,6 +240,52 @@ class UNet(nn.Module):
                 t["logit"] = logit
             return (out, logit) if want_logit else out
         return res
+
+    def _planar_ok(self) -> bool:
+        """The planar path needs <= 8 input planes, at most 4 head planes and the reference's channel ladder (multiples of 64)."""
+        return self.e11.in_channels <= 8 and self.outconv.out_channels <= 4 and self.outconv.in_channels == 64 and self.e11.out_channels % 16 == 0
+
+    def _forward_planar(self, x: torch.Tensor, want_logit: bool = False):
+        """unet.py:137-189 on planar F16F8P activations: e11 (VALU) -> 3x3 convs with fused pool / concat / head and transposed convs, all
+        persistent LDS-DMA kernels; no intermediate leaves the format."""
+        W = ops.MODE_F16F8                                           # weights are packed as for 'f16f8'
+        tag = ops.set_layer
+        e11 = self.e11
+        tag("e11")
+        cur = ops.conv3x3_first_pl(x, e11.weight, e11.bias.detach())
+        skips: List[torch.Tensor] = []
+        for lvl in range(self.nsteps + 1):
+            a, b = ENC[lvl]
+            if lvl >= 1:
+                la = getattr(self, a)
+                tag(a)
+                cur = ops.conv3x3_pl(cur, None, self._packed(a, W, "conv"), la.bias.detach(), la.out_channels)
+            lb = getattr(self, b)
+            tag(b)
+            last = lvl == self.nsteps
+            if last and self.nsteps == 0:
+                tag(b + "+outconv")
+                return ops.conv3x3_pl(cur, None, self._packed(b, W, "conv"), lb.bias.detach(), lb.out_channels, want_y=False,
+                                      head_w=self.outconv.weight.detach(), head_b=self.outconv.bias.detach(), want_logit=want_logit)
+            if not last:
+                full, cur = ops.conv3x3_pl(cur, None, self._packed(b, W, "conv"), lb.bias.detach(), lb.out_channels, pool=True)
+                skips.append(full)
+            else:
+                cur = ops.conv3x3_pl(cur, None, self._packed(b, W, "conv"), lb.bias.detach(), lb.out_channels)
+        for depth in range(self.nsteps, 0, -1):
+            up, c1, c2 = dec_names(depth)
+            lu, l1, l2 = getattr(self, up), getattr(self, c1), getattr(self, c2)
+            tag(up)
+            xu = ops.convt2x2_pl(cur, self._packed(up, W, "convt"), lu.bias.detach(), lu.out_channels)
+            tag(c1)
+            cur = ops.conv3x3_pl(xu, skips[depth - 1], self._packed(c1, W, "conv"), l1.bias.detach(), l1.out_channels)
+            if depth == 1:
+                tag(c2 + "+outconv")
+                return ops.conv3x3_pl(cur, None, self._packed(c2, W, "conv"), l2.bias.detach(), l2.out_channels, want_y=False,
+                                      head_w=self.outconv.weight.detach(), head_b=self.outconv.bias.detach(), want_logit=want_logit)
+            tag(c2)
+            cur = ops.conv3x3_pl(cur, None, self._packed(c2, W, "conv"), l2.bias.detach(), l2.out_channels)
+        raise AssertionError("unreachable")
 
     def forward(self, x_in: torch.Tensor) -> torch.Tensor:
         x_in = self._check_input(x_in)

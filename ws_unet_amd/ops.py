@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import MODES, MODE_BF16, MODE_BF16X3, MODE_BF16X3S, MODE_F16F8, MODE_F16F8X, check
+from ._lib import MODES, MODE_BF16, MODE_BF16X3, MODE_BF16X3S, MODE_F16F8, MODE_F16F8X, MODE_F16F8P, check
 
 
 def _stream() -> int:
@@ -112,7 +112,7 @@ def _esz(mode: int) -> int:
 def weight_mode(mode: int) -> int:
     """The packed weights of 'bf16x3s' are the 'bf16x3' ones; 'f16f8' has its own packing, shared by 'f16f8x' (the same arithmetic on
     fp32 tensors: the training forward)."""
-    return MODE_BF16X3 if mode == MODE_BF16X3S else (MODE_F16F8 if mode == MODE_F16F8X else mode)
+    return MODE_BF16X3 if mode == MODE_BF16X3S else (MODE_F16F8 if mode in (MODE_F16F8X, MODE_F16F8P) else mode)
 
 
 def first_layer_weight_mode(mode: int) -> int:
@@ -283,6 +283,35 @@ def conv3x3_pl(x1: torch.Tensor, x2: Optional[torch.Tensor], w_packed: torch.Ten
         res = [out] + ([logit] if want_logit else []) + ([y] if want_y else [])
         return res[0] if len(res) == 1 else tuple(res)
     return (y, yp) if pool else y
+
+
+def convt2x2_pl(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor], cout: int) -> torch.Tensor:
+    """nn.ConvTranspose2d(k=2, s=2) + bias on planar F16F8P activations (wsu_convt2x2_pl_fwd); w_packed from pack_convt2x2(mode f16f8)."""
+    lib = _lib.load()
+    _dev_check(x, w_packed, bias)
+    assert x.dtype == torch.float32 and x.dim() == 6 and x.shape[2] == 4 and x.shape[5] == 4 and x.is_contiguous()
+    n, nch, _, h, w, _ = x.shape
+    cin = nch * 16
+    y = torch.empty(planar_shape(n, cout, 2 * h, 2 * w), dtype=torch.float32, device=x.device)
+    meta = {"flops": 2.0 * 4 * cin * cout * n * h * w, "bytes": float(n * h * w * (cin + 4 * cout) * 4 + 4 * cin * cout * 4)}
+    check(_launch("convt2x2_pl", meta, lambda: lib.wsu_convt2x2_pl_fwd(
+        x.data_ptr(), w_packed.data_ptr(), _ptr(bias), y.data_ptr(), n, h, w, cin, cout, _stream())), "wsu_convt2x2_pl_fwd")
+    return y
+
+
+def conv3x3_first_pl(x_nchw: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], relu: bool = True) -> torch.Tensor:
+    """First layer (N, cin <= 8, H, W) fp32 -> planar F16F8P tensor with w.shape[0] channels (wsu_conv3x3_first_pl_fwd)."""
+    lib = _lib.load()
+    w = w.detach().contiguous()
+    _dev_check(x_nchw, w, bias)
+    n, cin, h, wd = x_nchw.shape
+    cout = w.shape[0]
+    assert x_nchw.dtype == torch.float32 and x_nchw.is_contiguous() and w.shape[1] == cin
+    y = torch.empty(planar_shape(n, cout, h, wd), dtype=torch.float32, device=x_nchw.device)
+    meta = {"flops": 2.0 * 9 * cin * cout * n * h * wd, "bytes": float(n * h * wd * (cin * 4 + cout * 4))}
+    check(_launch("conv3x3_first_pl", meta, lambda: lib.wsu_conv3x3_first_pl_fwd(
+        x_nchw.data_ptr(), w.data_ptr(), _ptr(bias), y.data_ptr(), n, h, wd, cin, cout, int(relu), _stream())), "wsu_conv3x3_first_pl_fwd")
+    return y
 
 
 def pack_conv3x3_wino(w: torch.Tensor) -> torch.Tensor:
