@@ -5,6 +5,9 @@ import sys
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 import torch
+from ws_unet_amd import _lib
+if __name__ == "__main__" and len(sys.argv) > 2:   # A/B build variants: python tools/time_pl.py 2 libwsu_prio5.so
+    _lib.LIB_PATH = Path(_lib.LIB_PATH).parent / sys.argv[2]
 from ws_unet_amd import ops
 
 M = ops.mode_id("f16f8")
@@ -63,7 +66,7 @@ def run(cin, cout, hw, n=32, c2=0, rounds=2, pool=False, head=False):
     for _ in range(rounds):
         to.append(bench(old)); tn.append(bench(new))
     fl = 2 * 9 * cin * cout * n * hw * hw
-    print(f"cin={cin} cout={cout} hw={hw} concat={c2} pool={int(pool)} head={int(head)}: old {min(to):.0f} us ({fl / min(to) / 1e6:.0f} TF/s)  "
+    print(f"{Path(_lib.LIB_PATH).name}: cin={cin} cout={cout} hw={hw} concat={c2} pool={int(pool)} head={int(head)}: old {min(to):.0f} us ({fl / min(to) / 1e6:.0f} TF/s)  "
           f"planar {min(tn):.0f} us ({fl / min(tn) / 1e6:.0f} TF/s)  speed-up {min(to) / min(tn):.2f}x", flush=True)
 
 

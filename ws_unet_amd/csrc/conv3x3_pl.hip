@@ -51,12 +51,12 @@ struct PlArgs {
     int tiles_x, tiles_y, ncb, nch1, nch;
     int relu;
     int ntiles;                                           // n * tiles_y * tiles_x * ncb
-    int stamp;                                            // WSU_PL_STAMP=1: diagnostic phase stamps (tools/stamp_pl.py)
+    int ablate;                                           // timing-only experiments (WSU_PL_ABLATE; results wrong when != 0): 1 = no DMA after step 0
 };
 
 struct Tile { int n, y0, x0, cb; };
 
-// Diagnostic stamps (never in production: args.stamp = 0): per workgroup the accumulated shader cycles of each phase of the chunk loop and
+// Diagnostic stamps (only in the -DWSU_PL_STAMPS build): per workgroup the accumulated shader cycles of each phase of the chunk loop and
 // the s_memrealtime span, read back with wsu_debug_read_pl_stamps().  Values go to a buffer nothing else reads.
 __device__ unsigned long long g_pl_stamps[256 * 8];
 
@@ -123,6 +123,11 @@ __device__ __forceinline__ void issue_dma(const PlArgs& a, int tn, int tcb, int 
     WSU_STATIC_FOR(IN_PER_WAVE - W_PER_WAVE, k, { dma_slot<W_PER_WAVE + k>(p, lw8, goff); });
 }
 
+// value of lane ^ 1 by a DPP quad permutation (a VALU modifier: no LDS crossbar round trip like ds_bpermute)
+__device__ __forceinline__ float dpp_xor1(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true));
+}
+
 __device__ __forceinline__ void swap32(uint32_t& upper_of, uint32_t& lower_of) {
     // lanes 32-63 of `upper_of` <-> lanes 0-31 of `lower_of`
     const auto r = __builtin_amdgcn_permlane32_swap(upper_of, lower_of, false, false);
@@ -179,7 +184,7 @@ __global__ __launch_bounds__(NT) void conv3x3_pl_kernel(const PlArgs a) {
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             STAMP(s2);
-            if (j + 1 < J) {
+            if (j + 1 < J && !(a.ablate & 1)) {
                 if (++c == a.nch) {
                     c = 0; ++kt;
                     t = tile_of(a, lw + kt * G);
@@ -265,6 +270,9 @@ _Pragma("unroll")
 _Pragma("unroll")
                 for (int q = 0; q < 2; ++q) wsu_mfma_f16(ah[m], bh[q], acc[m][q]);
         };
+        // Measured neutral on this section (gpurun_out/ab_prio.log, time_pl*.log): raising the priority of waves 4-7 for its second half so
+        // that SIMD partners reach the barrier together; fetching fragments one unit ahead of their matrix instructions behind scheduling
+        // fences (two ahead needs 190 registers).
         WSU_STATIC_FOR(5, tp, {
             cross(std::integral_constant<int, tp>{});
             main_term(std::integral_constant<int, 2 * tp>{});
@@ -334,8 +342,8 @@ _Pragma("unroll")
                         f32x4 px, py;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {                           // window order (0,0) (0,1) (1,0) (1,1); max is order-free, NaN propagates
-                            const float x1 = __shfl_xor(vx[0][e], 1, 64), x3 = __shfl_xor(vx[1][e], 1, 64);
-                            const float y1 = __shfl_xor(vy[0][e], 1, 64), y3 = __shfl_xor(vy[1][e], 1, 64);
+                            const float x1 = dpp_xor1(vx[0][e]), x3 = dpp_xor1(vx[1][e]);      // the neighbouring column (lane ^ 1)
+                            const float y1 = dpp_xor1(vy[0][e]), y3 = dpp_xor1(vy[1][e]);
                             float bxv = vx[0][e], byv = vy[0][e];
                             if (x1 > bxv || x1 != x1) bxv = x1;
                             if (vx[1][e] > bxv || vx[1][e] != vx[1][e]) bxv = vx[1][e];
@@ -424,7 +432,9 @@ int wsu_conv3x3_pl_fwd(const void* x1, const void* x2, const void* w_packed, con
     const long long nt = (long long)n * a.tiles_x * a.tiles_y * a.ncb;
     WSU_REQUIRE(nt > 0 && nt < 0x3FFFFFFFLL, "conv3x3_pl: %lld tiles out of range", nt);
     a.ntiles = (int)nt;
-    a.stamp = 0;
+    static int ablate = -1;
+    if (ablate < 0) { const char* e = getenv("WSU_PL_ABLATE"); ablate = e ? atoi(e) : 0; }
+    a.ablate = ablate;
     static int ncu = 0;
     if (ncu == 0) {
         int dev = 0; hipDeviceProp_t prop;
