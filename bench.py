@@ -206,14 +206,14 @@ def pmc_traffic(args, algorithmic_bytes_per_launch):
         return out
     with open(cands[-1]) as f:
         pmc = json.load(f)
-    src = ROOT / "ws_unet_amd" / "csrc" / "conv3x3.hip"
+    src = ROOT / "ws_unet_amd" / "csrc" / pmc.get("kernel_source", "conv3x3.hip")
     here = git_blob_sha1(src) if src.exists() else None
     out["traffic_source"] = str(cands[-1].relative_to(ROOT))
     if pmc.get("mode", "bf16x3") != args.mode:
         out["traffic_note"] = f"summary is for mode {pmc.get('mode')}"
         return out
-    if pmc.get("conv3x3_hip_blob") != here:
-        out["traffic_note"] = (f"stale: counters were collected on conv3x3.hip blob {pmc.get('conv3x3_hip_blob')}, "
+    if pmc.get("kernel_source_blob") != here:
+        out["traffic_note"] = (f"stale: counters were collected on {src.name} blob {pmc.get('kernel_source_blob')}, "
                                f"this tree has {here} (re-run tools/profile_round.sh)")
         return out
     out["traffic"] = pmc["traffic_bytes_per_launch"]

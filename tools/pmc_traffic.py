@@ -28,8 +28,9 @@ def per_launch(path, counter, kernel):
 
 def main():
     fetch_csv, write_csv, out = sys.argv[1:4]
-    kernel = sys.argv[4] if len(sys.argv) > 4 else "conv3x3_kernel"
-    mode = sys.argv[5] if len(sys.argv) > 5 else "bf16x3s"
+    kernel = sys.argv[4] if len(sys.argv) > 4 else "conv3x3_pl_kernel"
+    mode = sys.argv[5] if len(sys.argv) > 5 else "f16f8p"
+    source = "conv3x3_pl.hip" if "conv3x3_pl" in kernel else "conv3x3.hip"
     f = per_launch(fetch_csv, "FETCH_SIZE", kernel)
     w = per_launch(write_csv, "WRITE_SIZE", kernel)
     assert f and w and len(f) == len(w), (len(f), len(w))
@@ -38,7 +39,8 @@ def main():
         "fetch_bytes_per_launch": 2.0 * sum(f) / len(f),          # gfx950: x2
         "write_bytes_per_launch": sum(w) / len(w),
         "counters": "FETCH_SIZE (KiB, x2 on gfx950) and WRITE_SIZE (KiB), one rocprofv3 --pmc pass each",
-        "conv3x3_hip_blob": git_blob_sha1(Path(__file__).resolve().parent.parent / "ws_unet_amd" / "csrc" / "conv3x3.hip"),
+        "kernel_source": source,
+        "kernel_source_blob": git_blob_sha1(Path(__file__).resolve().parent.parent / "ws_unet_amd" / "csrc" / source),
     }
     res["traffic_bytes_per_launch"] = res["fetch_bytes_per_launch"] + res["write_bytes_per_launch"]
     with open(out, "w") as fh:
