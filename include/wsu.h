@@ -123,19 +123,22 @@ int wsu_conv3x3_wino_fwd(const void* x1, const void* x2, const void* w_packed, c
  *      8-15, plane 2 = e4m3((x - f16 x) * 2^12) ch 0-15, plane 3 = e4m3(x / 4) ch 0-15 (4 bytes per element).  The planes are the LDS
  *      image of the matrix kernel, so staging is a pure LDS-DMA (global_load_lds) and a persistent workgroup per CU pipelines it across
  *      chunks and tiles (csrc/conv3x3_pl.hip).  Weights from wsu_conv3x3_pack(mode F16F8).  Outputs, each optional: y (planar),
- *      y_pool (2x2 max-pooled, planar), head (1x1 conv + sigmoid on cout == 64 channels; out / logit NCHW fp32).  Replaces the same
+ *      y_pool (2x2 max-pooled, planar), head (1x1 conv + sigmoid on cout == 64 channels; out / logit NCHW fp32).  range_flag (optional
+ *      device word, all three planar entry points): bit 0 is OR-ed in when a stored activation exceeds +-448, where the e4m3 residual
+ *      saturates and that value keeps only f16 accuracy (NaN / Inf set it too) -- the caller's signal to switch to BF16X3S.  Replaces the same
  *      reference lines as wsu_conv3x3_fwd / wsu_conv3x3_head_fwd (unet.py:141-189). */
 int wsu_conv3x3_pl_fwd(const void* x1, const void* x2, const void* w_packed, const float* bias, void* y, void* y_pool,
                        const float* head_w, const float* head_b, float* head_out, float* head_logit, int head_cout,
-                       int n, int h, int w, int c1, int c2, int cout, int relu, void* stream);
+                       int n, int h, int w, int c1, int c2, int cout, int relu, unsigned* range_flag, void* stream);
 
 /* ---- K3p / K0p: the other two kernels of the planar (F16F8P) inference path (csrc/planar.hip).
  *      wsu_convt2x2_pl_fwd: nn.ConvTranspose2d(k2, s2) + bias (unet.py:125,130,177,183), x: cin channels at (h, w) planar -> y: cout channels at
  *      (2h, 2w) planar; weights from wsu_convt2x2_pack(mode F16F8); cin a multiple of 32, cout of 64.
  *      wsu_conv3x3_first_pl_fwd: the first layer e11 (unet.py:82,141), x_nchw (N, cin <= 8, H, W) fp32 -> y: cout (multiple of 16) channels planar. */
-int wsu_convt2x2_pl_fwd(const void* x, const void* w_packed, const float* bias, void* y, int n, int h, int w, int cin, int cout, void* stream);
+int wsu_convt2x2_pl_fwd(const void* x, const void* w_packed, const float* bias, void* y, int n, int h, int w, int cin, int cout,
+                        unsigned* range_flag, void* stream);
 int wsu_conv3x3_first_pl_fwd(const float* x_nchw, const float* w_oihw, const float* bias, void* y, int n, int h, int w, int cin, int cout,
-                             int relu, void* stream);
+                             int relu, unsigned* range_flag, void* stream);
 
 /* ---- first layer: conv3x3 reflect on a few input planes given as NCHW fp32 (the model input).
  *      Replaces e11 (unet.py:82,141).  cin <= 8, cout multiple of 8.  w is plain OIHW fp32. */

@@ -142,3 +142,36 @@ def test_unet_planar_mode_equals_nhwc_mode_closely():
         yb = gpu_model(2, "he", "f16f8p")(x.to(DEV))
     d = (ya - yb).abs()
     assert d.max().item() <= 1e-4 and d.mean().item() <= 1e-5, (d.max().item(), d.mean().item())
+
+
+def test_range_flag_and_loud_fallback(caplog):
+    """activations beyond +-448 lose the e4m3 residual (plain f16 accuracy) -- the kernels raise a device-side flag and the
+    model falls back to 'bf16x3s' on its first forward instead of degrading silently."""
+    import logging
+    from gpu_util import gpu_model, images01, oracle_forward
+    _, x = images01(2, 32, 32, seed=9)
+    m = gpu_model(1, "he", "f16f8p")
+    with torch.no_grad():
+        y = m(x.to(DEV))
+    assert m.mode == "f16f8p" and not m.range_exceeded()
+    # kernel level: one value of 500 in the conv output trips the flag, 400 does not
+    flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+    xin = torch.zeros(1, 16, 16, 32); xin[0, 0, 4, 4] = 1.0
+    wt = torch.zeros(64, 16, 3, 3); b = torch.zeros(64)
+    wt[5, 0, 1, 1] = 400.0
+    ops.conv3x3_pl(planar_encode(xin), None, ops.pack_conv3x3(wt.to(DEV), M), b.to(DEV), 64, range_flag=flag)
+    assert flag.item() == 0
+    wt[5, 0, 1, 1] = 500.0
+    ops.conv3x3_pl(planar_encode(xin), None, ops.pack_conv3x3(wt.to(DEV), M), b.to(DEV), 64, range_flag=flag)
+    assert flag.item() == 1
+    # model level: a checkpoint with huge first-layer weights -> warning + mode switch + still-correct output
+    big = gpu_model(1, "he", "f16f8p")
+    with torch.no_grad():
+        big.e11.weight.mul_(3000.0); big.e11.bias.mul_(3000.0); big.e12.weight.div_(3000.0)
+    big.invalidate_packed()
+    with caplog.at_level(logging.WARNING), torch.no_grad():
+        yb = big(x.to(DEV))
+    assert big.mode == "bf16x3s" and any("beyond" in r.message for r in caplog.records)
+    sd = {k: v.detach().cpu() for k, v in big.state_dict().items()}
+    ref = unet_ref.unet_forward(x.clone(), sd, 1)
+    assert (yb.cpu() - ref).abs().max().item() <= 1e-4

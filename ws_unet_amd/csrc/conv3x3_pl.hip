@@ -51,6 +51,7 @@ struct PlArgs {
     int tiles_x, tiles_y, ncb, nch1, nch;
     int relu;
     int ntiles;                                           // n * tiles_y * tiles_x * ncb
+    unsigned* range_flag;                                 // optional: bit 0 is set when a stored activation exceeds the encodable range (|x| > 448)
     int ablate;                                           // timing-only experiments (WSU_PL_ABLATE; results wrong when != 0): 1 = no DMA after step 0
 };
 
@@ -141,6 +142,9 @@ __device__ __forceinline__ void swap32(uint32_t& upper_of, uint32_t& lower_of) {
 #define STAMP(var) do {} while (0)
 #endif
 
+// HEAD / POOL are compile-time: the kernel sits at the 168-register step (three waves per SIMD), and the head's partial sums or the pool's
+// exchange registers would otherwise be carried -- and spilled -- by the variants that do not use them.
+template <int HC, bool POOL>            // HC = head planes compiled in: 0 (no head), 1 (the reference's single output plane) or 4 (1..4)
 __global__ __launch_bounds__(NT) void conv3x3_pl_kernel(const PlArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -154,7 +158,8 @@ __global__ __launch_bounds__(NT) void conv3x3_pl_kernel(const PlArgs a) {
     float* s_hw = s_bias + 1024;
     float* s_hb = s_hw + 4 * 64;
     for (int i = tid; i < a.cout; i += NT) s_bias[i] = a.bias ? a.bias[i] : 0.f;
-    if (a.head_w) {
+    constexpr bool HEAD = HC > 0;
+    if constexpr (HEAD) {
         for (int i = tid; i < a.head_cout * 64; i += NT) s_hw[i] = a.head_w[i];
         if (tid < 4) s_hb[tid] = (a.head_b && tid < a.head_cout) ? a.head_b[tid] : 0.f;
     }
@@ -286,11 +291,12 @@ _Pragma("unroll")
             const int col = cur.x0 + l31;
             const size_t hw = (size_t)a.h * a.w;
             const int nco = a.cout >> 4;                                       // output chunks
-            float hz[2][4];
+            float hz[2][HC > 0 ? HC : 1];
+            float vmax = 0.f;                                                  // largest stored activation of this lane (range flag)
 #pragma unroll
             for (int q = 0; q < 2; ++q)
 #pragma unroll
-                for (int o = 0; o < 4; ++o) hz[q][o] = 0.f;
+                for (int o = 0; o < (HC > 0 ? HC : 1); ++o) hz[q][o] = 0.f;
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
 #pragma unroll
@@ -306,12 +312,13 @@ _Pragma("unroll")
                             float x = acc[m][q][8 * cp + e] + bx[e], y = acc[m][q][8 * cp + 4 + e] + by[e];
                             if (a.relu) { x = fmaxf(x, 0.f); y = fmaxf(y, 0.f); }
                             vx[q][e] = x; vy[q][e] = y;
+                            vmax = fmaxf(vmax, fmaxf(fabsf(x), fabsf(y)));
                         }
                     }
-                    if (a.head_w) {
+                    if constexpr (HEAD) {
                         const int lc = (m * 2 + cp) * 16 + 4 * hh;             // channel inside the 64-wide block
 #pragma unroll
-                        for (int o = 0; o < 4; ++o)
+                        for (int o = 0; o < HC; ++o)
                             if (o < a.head_cout)
 #pragma unroll
                                 for (int q = 0; q < 2; ++q)
@@ -319,26 +326,29 @@ _Pragma("unroll")
                                     for (int e = 0; e < 4; ++e)
                                         hz[q][o] = fmaf(vx[q][e], s_hw[o * 64 + lc + e], fmaf(vy[q][e], s_hw[o * 64 + lc + 8 + e], hz[q][o]));
                     }
-                    auto store_px = [&](const f32x4& X, const f32x4& Y, char* dst, size_t plane_bytes, bool ok) __attribute__((always_inline)) {
+                    // addresses = wave-uniform 64-bit base (image, output chunk) + 32-bit lane offset (pixel, plane): the stores take the
+                    // SGPR-base form and the epilogue carries no 64-bit address registers (it sits at the 168-register step)
+                    auto store_px = [&](const f32x4& X, const f32x4& Y, char* base, uint32_t off, uint32_t plane_bytes, bool ok) __attribute__((always_inline)) {
                         uint32_t xh0, xh1, xlo, xx8, yh0, yh1, ylo, yx8;
                         wsu_split4_f16f8(X, WSU_F8_XLO_DIV, WSU_F8_X_DIV, xh0, xh1, xlo, xx8);
                         wsu_split4_f16f8(Y, WSU_F8_XLO_DIV, WSU_F8_X_DIV, yh0, yh1, ylo, yx8);
                         swap32(xh0, yh0); swap32(xh1, yh1);                     // lanes 0-31: f16 ch 0-7, lanes 32-63: f16 ch 8-15
                         swap32(xlo, xx8); swap32(ylo, yx8);                     // lanes 0-31: residuals ch 0-15, lanes 32-63: e4m3 copies
                         if (ok) {
-                            *reinterpret_cast<u32x4*>(dst + hh * plane_bytes) = mk_u4(xh0, xh1, yh0, yh1);
-                            *reinterpret_cast<u32x4*>(dst + (2 + hh) * plane_bytes) = mk_u4(xlo, xx8, ylo, yx8);
+                            const uint32_t o1 = off + hh * plane_bytes;
+                            *reinterpret_cast<u32x4*>(base + o1) = mk_u4(xh0, xh1, yh0, yh1);
+                            *reinterpret_cast<u32x4*>(base + o1 + 2 * plane_bytes) = mk_u4(xlo, xx8, ylo, yx8);
                         }
                     };
                     if (a.y) {
 #pragma unroll
                         for (int q = 0; q < 2; ++q) {
                             const int row = cur.y0 + 2 * wv + q;
-                            char* dst = a.y + ((((size_t)cur.n * nco + oc) * 4) * hw + (size_t)row * a.w + col) * 16;
-                            store_px(vx[q], vy[q], dst, hw * 16, row < a.h && col < a.w);
+                            char* base = a.y + (((size_t)cur.n * nco + oc) * 4) * hw * 16;
+                            store_px(vx[q], vy[q], base, (uint32_t)(row * a.w + col) * 16u, (uint32_t)hw * 16u, row < a.h && col < a.w);
                         }
                     }
-                    if (a.ypool) {                                             // wave-uniform: every lane takes part in the exchanges
+                    if constexpr (POOL) {                                      // every lane takes part in the exchanges
                         f32x4 px, py;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {                           // window order (0,0) (0,1) (1,0) (1,1); max is order-free, NaN propagates
@@ -355,30 +365,34 @@ _Pragma("unroll")
                         }
                         const int hp = a.h >> 1, wp2 = a.w >> 1;
                         const int gy = (cur.y0 >> 1) + wv, gx = (cur.x0 >> 1) + (l31 >> 1);
-                        char* dst = a.ypool + ((((size_t)cur.n * nco + oc) * 4) * hp * wp2 + (size_t)gy * wp2 + gx) * 16;
-                        store_px(px, py, dst, (size_t)hp * wp2 * 16, !(l31 & 1) && gy < hp && gx < wp2);
+                        char* base = a.ypool + (((size_t)cur.n * nco + oc) * 4) * hp * wp2 * 16;
+                        store_px(px, py, base, (uint32_t)(gy * wp2 + gx) * 16u, (uint32_t)(hp * wp2) * 16u, !(l31 & 1) && gy < hp && gx < wp2);
                     }
                 }
             }
-            if (a.head_w) {
+            if constexpr (HEAD) {
                 // the other 32 channels of this pixel sit in the partner lane (lane ^ 32)
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                     const int row = cur.y0 + 2 * wv + q;
 #pragma unroll
-                    for (int o = 0; o < 4; ++o)
+                    for (int o = 0; o < HC; ++o)
                         if (o < a.head_cout) {
                             uint32_t mine = __builtin_bit_cast(uint32_t, hz[q][o]), other = mine;
                             swap32(mine, other);                            // lanes 0-31: other = partner's sum; lanes 32-63: mine = partner's
                             const float z = __builtin_bit_cast(float, mine) + __builtin_bit_cast(float, other) + s_hb[o];
                             if (!hh && row < a.h && col < a.w) {
-                                const size_t off = ((size_t)cur.n * a.head_cout + o) * hw + (size_t)row * a.w + col;
-                                if (a.head_logit) a.head_logit[off] = z;
-                                a.head_out[off] = 1.f / (1.f + expf(-z));
+                                const size_t plane = ((size_t)cur.n * a.head_cout + o) * hw;      // wave-uniform
+                                const uint32_t off = (uint32_t)(row * a.w + col);
+                                if (a.head_logit) (a.head_logit + plane)[off] = z;
+                                (a.head_out + plane)[off] = 1.f / (1.f + expf(-z));
                             }
                         }
                 }
             }
+            // beyond +-448 the e4m3 residual saturates (plain f16 accuracy), beyond +-65504 the f16 part overflows: tell the caller once
+            if (a.range_flag && (a.y || POOL) && __builtin_amdgcn_ballot_w64(!(vmax <= WSU_F8_RANGE)) != 0 && lane == 0)
+                atomicOr(a.range_flag, 1u);
             ++kt;
             c = 0;
             if (j + 1 < J) cur = tile_of(a, lw + kt * G);
@@ -409,23 +423,26 @@ int wsu_debug_read_pl_stamps(unsigned long long* host_dst, int nblocks) {
 }
 
 // Forward 3x3 reflect conv + bias + ReLU on planar F16F8P activations (layout: wsu.h).  x1 (c1 channels) and optional x2 (c2, fused
-// concat), packed weights of wsu_conv3x3_pack(mode F16F8); outputs, each optional: y (cout channels, planar), y_pool (2x2 max-pooled,
+// concat), packed weights of wsu_conv3x3_pack(mode F16F8); range_flag (optional device word): bit 0 is OR-ed in when a stored value leaves
+// the format's full-accuracy range; outputs, each optional: y (cout channels, planar), y_pool (2x2 max-pooled,
 // planar), head (1x1 conv + sigmoid on the 64 output channels: out / logit NCHW fp32; needs cout == 64).  c1, c2 multiples of 16,
 // cout of 64.  Asynchronous on `stream`; allocates nothing.
 int wsu_conv3x3_pl_fwd(const void* x1, const void* x2, const void* w_packed, const float* bias, void* y, void* y_pool,
                        const float* head_w, const float* head_b, float* head_out, float* head_logit, int head_cout,
-                       int n, int h, int w, int c1, int c2, int cout, int relu, void* stream) {
+                       int n, int h, int w, int c1, int c2, int cout, int relu, unsigned* range_flag, void* stream) {
     WSU_REQUIRE(x1 && w_packed && (y || y_pool || head_w), "conv3x3_pl: null pointer");
     WSU_REQUIRE(n > 0 && h >= 2 && w >= 2, "conv3x3_pl: bad shape n=%d h=%d w=%d (reflect pad 1 needs h,w >= 2)", n, h, w);
     WSU_REQUIRE(c1 > 0 && c1 % 16 == 0 && c2 >= 0 && c2 % 16 == 0 && (c2 == 0) == (x2 == nullptr), "conv3x3_pl: c1=%d c2=%d must be multiples of 16", c1, c2);
     WSU_REQUIRE(cout > 0 && cout % WSU_COB == 0 && cout <= 1024, "conv3x3_pl: cout=%d must be a multiple of %d (<= 1024)", cout, WSU_COB);
     WSU_REQUIRE(!head_w || (head_out && cout == WSU_COB && head_cout >= 1 && head_cout <= 4), "conv3x3_pl: fused head needs cout == %d and 1..4 head planes", WSU_COB);
     WSU_REQUIRE(!y_pool || (h % 2 == 0 && w % 2 == 0), "conv3x3_pl: fused pool needs even h, w");
+    WSU_REQUIRE(!(y_pool && head_w), "conv3x3_pl: the fused pool and the fused head exclude each other");
     WSU_REQUIRE((long long)h * w * 4 < 0x7FFFFFFFLL, "conv3x3_pl: h*w too large");
     PlArgs a;
     a.x1 = (const char*)x1; a.x2 = (const char*)x2; a.wp = (const char*)w_packed; a.bias = bias;
     a.y = (char*)y; a.ypool = (char*)y_pool;
     a.head_w = head_w; a.head_b = head_b; a.head_out = head_out; a.head_logit = head_logit; a.head_cout = head_cout;
+    a.range_flag = range_flag;
     a.n = n; a.h = h; a.w = w; a.c1 = c1; a.c2 = c2; a.cout = cout;
     a.tiles_x = (w + TW - 1) / TW; a.tiles_y = (h + TH - 1) / TH; a.ncb = cout / WSU_COB;
     a.nch1 = c1 / 16; a.nch = (c1 + c2) / 16; a.relu = relu;
@@ -441,12 +458,20 @@ int wsu_conv3x3_pl_fwd(const void* x1, const void* x2, const void* w_packed, con
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
             wsu_set_error("conv3x3_pl: cannot query the device"); return WSU_ERR_HIP;
         }
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_pl_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
-        if (e != hipSuccess) { wsu_set_error("hipFuncSetAttribute(conv3x3_pl): %s", hipGetErrorString(e)); return WSU_ERR_HIP; }
+        const void* fns[4] = {reinterpret_cast<const void*>(&conv3x3_pl_kernel<0, false>), reinterpret_cast<const void*>(&conv3x3_pl_kernel<0, true>),
+                              reinterpret_cast<const void*>(&conv3x3_pl_kernel<1, false>), reinterpret_cast<const void*>(&conv3x3_pl_kernel<4, false>)};
+        for (const void* fn : fns) {
+            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
+            if (e != hipSuccess) { wsu_set_error("hipFuncSetAttribute(conv3x3_pl): %s", hipGetErrorString(e)); return WSU_ERR_HIP; }
+        }
         ncu = prop.multiProcessorCount;
     }
     const int grid = (int)(nt < ncu ? nt : ncu);
-    hipLaunchKernelGGL(conv3x3_pl_kernel, dim3(grid), dim3(NT), LDS_TOTAL, static_cast<hipStream_t>(stream), a);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (head_w && head_cout == 1) hipLaunchKernelGGL((conv3x3_pl_kernel<1, false>), dim3(grid), dim3(NT), LDS_TOTAL, s, a);
+    else if (head_w) hipLaunchKernelGGL((conv3x3_pl_kernel<4, false>), dim3(grid), dim3(NT), LDS_TOTAL, s, a);
+    else if (y_pool) hipLaunchKernelGGL((conv3x3_pl_kernel<0, true>), dim3(grid), dim3(NT), LDS_TOTAL, s, a);
+    else hipLaunchKernelGGL((conv3x3_pl_kernel<0, false>), dim3(grid), dim3(NT), LDS_TOTAL, s, a);
     return wsu_check_launch("conv3x3_pl_kernel");
 }
 

@@ -54,7 +54,7 @@ constexpr int IN_PER = IN_SLOTS / NLOAD, W_PER = W_SLOTS / NLOAD;   // 4, 8
 }
 
 struct CtpArgs {
-    const char* x; const char* wp; const float* bias; char* y;
+    const char* x; const char* wp; const float* bias; char* y; unsigned* range_flag;
     int n, h, w, cin, cout;
     int tiles_x, tiles_y, ncb, nst;                       // nst = steps per tile = cin / 32
     int ntiles;
@@ -178,6 +178,7 @@ __global__ __launch_bounds__(ct::NT) void convt2x2_pl_kernel(const CtpArgs a) {
             const size_t ohw = (size_t)oh * ow;
             const int nco = a.cout >> 4;
             const int icol = cur.x0 + l31;
+            float vmax = 0.f;
 #pragma unroll
             for (int cp = 0; cp < 2; ++cp) {
                 const int oc = cur.cb * 4 + mh * 2 + cp;
@@ -192,11 +193,15 @@ __global__ __launch_bounds__(ct::NT) void convt2x2_pl_kernel(const CtpArgs a) {
                     for (int b = 0; b < 2; ++b) {
                         f32x4 X, Y;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { X[e] = acc[b][q][8 * cp + e] + bx[e]; Y[e] = acc[b][q][8 * cp + 4 + e] + by[e]; }
+                        for (int e = 0; e < 4; ++e) {
+                            X[e] = acc[b][q][8 * cp + e] + bx[e]; Y[e] = acc[b][q][8 * cp + 4 + e] + by[e];
+                            vmax = fmaxf(vmax, fmaxf(fabsf(X[e]), fabsf(Y[e])));
+                        }
                         store_chunk_px(X, Y, dst + b * 16, ohw * 16, hh, ok);
                     }
                 }
             }
+            if (a.range_flag && __builtin_amdgcn_ballot_w64(!(vmax <= WSU_F8_RANGE)) != 0 && lane == 0) atomicOr(a.range_flag, 1u);
             ++kt; c = 0;
             if (j + 1 < J) cur = ct_tile_of(a, lw + kt * G);
         } else {
@@ -211,7 +216,7 @@ __global__ __launch_bounds__(ct::NT) void convt2x2_pl_kernel(const CtpArgs a) {
 // time from tap-major weights in LDS; fp32 FMAs in the tap order of conv3x3_first_kernel (pointwise.hip), so the values before encoding are
 // bitwise those of the NHWC first-layer kernel.  HBM-write bound: 4 bytes per output element.
 // =====================================================================================================================================
-struct FirstPlArgs { const float* x; const float* w; const float* b; char* y; int n, h, w_, cin, cout, relu; };
+struct FirstPlArgs { const float* x; const float* w; const float* b; char* y; unsigned* range_flag; int n, h, w_, cin, cout, relu; };
 
 __global__ __launch_bounds__(256) void first_pl_kernel(const FirstPlArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -226,6 +231,7 @@ __global__ __launch_bounds__(256) void first_pl_kernel(const FirstPlArgs a) {
     const size_t hw = (size_t)a.h * a.w_;
     const long long total = (long long)a.n * hw;
     const int nco = a.cout >> 4;
+    float vmax = 0.f;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int x = (int)(i % a.w_); long long t = i / a.w_;
         const int y = (int)(t % a.h); const int img = (int)(t / a.h);
@@ -262,6 +268,8 @@ __global__ __launch_bounds__(256) void first_pl_kernel(const FirstPlArgs a) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[g][e] = fmaxf(v[g][e], 0.f);
                 }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) vmax = fmaxf(vmax, fabsf(v[g][e]));
                 wsu_split4_f16f8(v[g], WSU_F8_XLO_DIV, WSU_F8_X_DIV, h[2 * g], h[2 * g + 1], lo[g], x8[g]);
             }
             char* dst = a.y + ((((size_t)img * nco + oc) * 4) * hw + (size_t)y * a.w_ + x) * 16;
@@ -271,6 +279,7 @@ __global__ __launch_bounds__(256) void first_pl_kernel(const FirstPlArgs a) {
             *reinterpret_cast<u32x4*>(dst + 3 * hw * 16) = mk_u4(x8[0], x8[1], x8[2], x8[3]);
         }
     }
+    if (a.range_flag && !(vmax <= WSU_F8_RANGE)) atomicOr(a.range_flag, 1u);      // rare: at most one atomic per lane
 }
 
 }  // namespace
@@ -279,14 +288,15 @@ extern "C" {
 
 // K3p: transposed 2x2 stride-2 conv + bias on planar F16F8P activations.  x: cin channels at (h, w); y: cout channels at (2h, 2w); weights from
 // wsu_convt2x2_pack(mode F16F8).  cin a multiple of 32, cout of 64.
-int wsu_convt2x2_pl_fwd(const void* x, const void* w_packed, const float* bias, void* y, int n, int h, int w, int cin, int cout, void* stream) {
+int wsu_convt2x2_pl_fwd(const void* x, const void* w_packed, const float* bias, void* y, int n, int h, int w, int cin, int cout,
+                        unsigned* range_flag, void* stream) {
     WSU_REQUIRE(x && w_packed && y, "convt2x2_pl: null pointer");
     WSU_REQUIRE(n > 0 && h > 0 && w > 0, "convt2x2_pl: bad shape n=%d h=%d w=%d", n, h, w);
     WSU_REQUIRE(cin > 0 && cin % 32 == 0, "convt2x2_pl: cin=%d must be a multiple of 32", cin);
     WSU_REQUIRE(cout > 0 && cout % WSU_COB == 0 && cout <= 1024, "convt2x2_pl: cout=%d must be a multiple of %d (<= 1024)", cout, WSU_COB);
     WSU_REQUIRE((long long)h * w * 16 < 0x7FFFFFFFLL, "convt2x2_pl: h*w too large");
     CtpArgs a;
-    a.x = (const char*)x; a.wp = (const char*)w_packed; a.bias = bias; a.y = (char*)y;
+    a.x = (const char*)x; a.wp = (const char*)w_packed; a.bias = bias; a.y = (char*)y; a.range_flag = range_flag;
     a.n = n; a.h = h; a.w = w; a.cin = cin; a.cout = cout;
     a.tiles_x = (w + ct::TW - 1) / ct::TW; a.tiles_y = (h + ct::TH - 1) / ct::TH; a.ncb = cout / WSU_COB; a.nst = cin / 32;
     const long long nt = (long long)n * a.tiles_x * a.tiles_y * a.ncb;
@@ -309,10 +319,10 @@ int wsu_convt2x2_pl_fwd(const void* x, const void* w_packed, const float* bias, 
 
 // K0p: first layer into planar storage.  x_nchw: (N, cin, H, W) fp32, cin 1..8; w_oihw: (cout, cin, 3, 3); cout a multiple of 16 (<= 128).
 int wsu_conv3x3_first_pl_fwd(const float* x_nchw, const float* w_oihw, const float* bias, void* y, int n, int h, int w, int cin, int cout,
-                             int relu, void* stream) {
+                             int relu, unsigned* range_flag, void* stream) {
     WSU_REQUIRE(x_nchw && w_oihw && y, "conv3x3_first_pl: null pointer");
     WSU_REQUIRE(n > 0 && h >= 2 && w >= 2 && cin >= 1 && cin <= 8 && cout > 0 && cout % 16 == 0 && cout <= 128, "conv3x3_first_pl: bad shape");
-    FirstPlArgs a{x_nchw, w_oihw, bias, (char*)y, n, h, w, cin, cout, relu};
+    FirstPlArgs a{x_nchw, w_oihw, bias, (char*)y, range_flag, n, h, w, cin, cout, relu};
     const long long total = (long long)n * h * w;
     const unsigned nblk = (unsigned)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
     const size_t lds = ((size_t)cin * 9 * cout + cout) * sizeof(float);

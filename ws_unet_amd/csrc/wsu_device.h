@@ -90,6 +90,7 @@ typedef __attribute__((ext_vector_type(8))) int i32x8;
 #define WSU_F8_SCALE_X 129
 #define WSU_F8_SCALE_W 121
 #define WSU_F8_SCALE_WLO 109
+#define WSU_F8_RANGE 448.f             // |x| beyond this: the e4m3 residual (x - f16 x) * 2^12 saturates -> plain f16 accuracy for that value
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 typedef __attribute__((ext_vector_type(2))) short i16x2;

@@ -165,7 +165,18 @@ class UNet(nn.Module):
             if save or not self._planar_ok():
                 m = ops.MODE_BF16X3             # intermediates are only kept in fp32 NHWC; odd channel counts take the general path
             else:
-                return self._forward_planar(x, want_logit)
+                res = self._forward_planar(x, want_logit)
+                if not getattr(self, "_range_checked", False):
+                    # first planar forward of this model: one synchronising look at the range flag.  Weights whose activations leave
+                    # the format's full-accuracy range (nobody knows that of a foreign checkpoint) fall back LOUDLY to fp32-range storage.
+                    self._range_checked = True
+                    if self.range_exceeded():
+                        import logging
+                        logging.warning("ws_unet_amd.UNet: activations beyond +-448 in mode 'f16f8p' (the e4m3 residual saturates there); "
+                                        "switching this model to mode 'bf16x3s'")
+                        self.mode = "bf16x3s"
+                        return self.forward_features(x, keep, want_logit)
+                return res
         if m in (ops.MODE_BF16X3S, ops.MODE_F16F8) and (save or self.nsteps < 1 or not (self.fuse_first and self.fuse_head)
                                      or e11.in_channels != 1 or e11.out_channels != 64 or self.outconv.out_channels > 4):
             m = ops.MODE_BF16X3             # the split formats live only between the fused first layer and the fused head
@@ -241,6 +252,24 @@ class UNet(nn.Module):
             return (out, logit) if want_logit else out
         return res
 
+    def _range_flag_tensor(self, device) -> torch.Tensor:
+        rf = getattr(self, "_range_flag", None)
+        if rf is None or rf.device != device:
+            rf = self._range_flag = torch.zeros(1, dtype=torch.int32, device=device)
+        return rf
+
+    def range_exceeded(self, clear: bool = True) -> bool:
+        """True if, since the last call, a planar ('f16f8p') forward stored an activation beyond +-448 -- where the format's e4m3 residual
+        saturates and that value keeps only f16 accuracy (NaN / Inf count too).  One device word OR-ed by the kernels' epilogues; reading
+        it synchronises.  A network that trips it should run in mode 'bf16x3s' (fp32-range storage)."""
+        rf = getattr(self, "_range_flag", None)
+        if rf is None:
+            return False
+        hit = bool(rf.item())
+        if clear and hit:
+            rf.zero_()
+        return hit
+
     def _planar_ok(self) -> bool:
         """The planar path needs <= 8 input planes, at most 4 head planes and the reference's channel ladder (multiples of 64)."""
         return self.e11.in_channels <= 8 and self.outconv.out_channels <= 4 and self.outconv.in_channels == 64 and self.e11.out_channels % 16 == 0
@@ -251,15 +280,16 @@ class UNet(nn.Module):
         W = ops.MODE_F16F8                                           # weights are packed as for 'f16f8'
         tag = ops.set_layer
         e11 = self.e11
+        rf = self._range_flag_tensor(x.device)
         tag("e11")
-        cur = ops.conv3x3_first_pl(x, e11.weight, e11.bias.detach())
+        cur = ops.conv3x3_first_pl(x, e11.weight, e11.bias.detach(), range_flag=rf)
         skips: List[torch.Tensor] = []
         for lvl in range(self.nsteps + 1):
             a, b = ENC[lvl]
             if lvl >= 1:
                 la = getattr(self, a)
                 tag(a)
-                cur = ops.conv3x3_pl(cur, None, self._packed(a, W, "conv"), la.bias.detach(), la.out_channels)
+                cur = ops.conv3x3_pl(cur, None, self._packed(a, W, "conv"), la.bias.detach(), la.out_channels, range_flag=rf)
             lb = getattr(self, b)
             tag(b)
             last = lvl == self.nsteps
@@ -268,23 +298,23 @@ class UNet(nn.Module):
                 return ops.conv3x3_pl(cur, None, self._packed(b, W, "conv"), lb.bias.detach(), lb.out_channels, want_y=False,
                                       head_w=self.outconv.weight.detach(), head_b=self.outconv.bias.detach(), want_logit=want_logit)
             if not last:
-                full, cur = ops.conv3x3_pl(cur, None, self._packed(b, W, "conv"), lb.bias.detach(), lb.out_channels, pool=True)
+                full, cur = ops.conv3x3_pl(cur, None, self._packed(b, W, "conv"), lb.bias.detach(), lb.out_channels, pool=True, range_flag=rf)
                 skips.append(full)
             else:
-                cur = ops.conv3x3_pl(cur, None, self._packed(b, W, "conv"), lb.bias.detach(), lb.out_channels)
+                cur = ops.conv3x3_pl(cur, None, self._packed(b, W, "conv"), lb.bias.detach(), lb.out_channels, range_flag=rf)
         for depth in range(self.nsteps, 0, -1):
             up, c1, c2 = dec_names(depth)
             lu, l1, l2 = getattr(self, up), getattr(self, c1), getattr(self, c2)
             tag(up)
-            xu = ops.convt2x2_pl(cur, self._packed(up, W, "convt"), lu.bias.detach(), lu.out_channels)
+            xu = ops.convt2x2_pl(cur, self._packed(up, W, "convt"), lu.bias.detach(), lu.out_channels, range_flag=rf)
             tag(c1)
-            cur = ops.conv3x3_pl(xu, skips[depth - 1], self._packed(c1, W, "conv"), l1.bias.detach(), l1.out_channels)
+            cur = ops.conv3x3_pl(xu, skips[depth - 1], self._packed(c1, W, "conv"), l1.bias.detach(), l1.out_channels, range_flag=rf)
             if depth == 1:
                 tag(c2 + "+outconv")
                 return ops.conv3x3_pl(cur, None, self._packed(c2, W, "conv"), l2.bias.detach(), l2.out_channels, want_y=False,
                                       head_w=self.outconv.weight.detach(), head_b=self.outconv.bias.detach(), want_logit=want_logit)
             tag(c2)
-            cur = ops.conv3x3_pl(cur, None, self._packed(c2, W, "conv"), l2.bias.detach(), l2.out_channels)
+            cur = ops.conv3x3_pl(cur, None, self._packed(c2, W, "conv"), l2.bias.detach(), l2.out_channels, range_flag=rf)
         raise AssertionError("unreachable")
 
     def forward(self, x_in: torch.Tensor) -> torch.Tensor:

@@ -254,7 +254,8 @@ def planar_shape(n: int, c: int, h: int, w: int):
 
 def conv3x3_pl(x1: torch.Tensor, x2: Optional[torch.Tensor], w_packed: torch.Tensor, bias: Optional[torch.Tensor], cout: int,
                relu: bool = True, pool: bool = False, want_y: bool = True,
-               head_w: Optional[torch.Tensor] = None, head_b: Optional[torch.Tensor] = None, want_logit: bool = False):
+               head_w: Optional[torch.Tensor] = None, head_b: Optional[torch.Tensor] = None, want_logit: bool = False,
+               range_flag: Optional[torch.Tensor] = None):
     """3x3 reflect conv (+ReLU, +2x2 max-pool, +1x1 head and sigmoid) on planar F16F8P activations (wsu_conv3x3_pl_fwd).
     x1 / x2: planar tensors (N, C/16, 4, H, W, 4); w_packed from pack_conv3x3(mode f16f8).  Returns y [, y_pool] or, with head_w,
     out [, logit][, y]."""
@@ -278,14 +279,15 @@ def conv3x3_pl(x1: torch.Tensor, x2: Optional[torch.Tensor], w_packed: torch.Ten
                            + 9 * (c1 + c2) * cout * 4)}
     check(_launch("conv3x3_pl", meta, lambda: lib.wsu_conv3x3_pl_fwd(
         x1.data_ptr(), _ptr(x2), w_packed.data_ptr(), _ptr(bias), _ptr(y), _ptr(yp), _ptr(hw2), _ptr(head_b), _ptr(out), _ptr(logit), hc,
-        n, h, w, c1, c2, cout, int(relu), _stream())), "wsu_conv3x3_pl_fwd")
+        n, h, w, c1, c2, cout, int(relu), _ptr(range_flag), _stream())), "wsu_conv3x3_pl_fwd")
     if hc:
         res = [out] + ([logit] if want_logit else []) + ([y] if want_y else [])
         return res[0] if len(res) == 1 else tuple(res)
     return (y, yp) if pool else y
 
 
-def convt2x2_pl(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor], cout: int) -> torch.Tensor:
+def convt2x2_pl(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor], cout: int,
+                range_flag: Optional[torch.Tensor] = None) -> torch.Tensor:
     """nn.ConvTranspose2d(k=2, s=2) + bias on planar F16F8P activations (wsu_convt2x2_pl_fwd); w_packed from pack_convt2x2(mode f16f8)."""
     lib = _lib.load()
     _dev_check(x, w_packed, bias)
@@ -295,11 +297,12 @@ def convt2x2_pl(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Te
     y = torch.empty(planar_shape(n, cout, 2 * h, 2 * w), dtype=torch.float32, device=x.device)
     meta = {"flops": 2.0 * 4 * cin * cout * n * h * w, "bytes": float(n * h * w * (cin + 4 * cout) * 4 + 4 * cin * cout * 4)}
     check(_launch("convt2x2_pl", meta, lambda: lib.wsu_convt2x2_pl_fwd(
-        x.data_ptr(), w_packed.data_ptr(), _ptr(bias), y.data_ptr(), n, h, w, cin, cout, _stream())), "wsu_convt2x2_pl_fwd")
+        x.data_ptr(), w_packed.data_ptr(), _ptr(bias), y.data_ptr(), n, h, w, cin, cout, _ptr(range_flag), _stream())), "wsu_convt2x2_pl_fwd")
     return y
 
 
-def conv3x3_first_pl(x_nchw: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], relu: bool = True) -> torch.Tensor:
+def conv3x3_first_pl(x_nchw: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], relu: bool = True,
+                     range_flag: Optional[torch.Tensor] = None) -> torch.Tensor:
     """First layer (N, cin <= 8, H, W) fp32 -> planar F16F8P tensor with w.shape[0] channels (wsu_conv3x3_first_pl_fwd)."""
     lib = _lib.load()
     w = w.detach().contiguous()
@@ -310,7 +313,7 @@ def conv3x3_first_pl(x_nchw: torch.Tensor, w: torch.Tensor, bias: Optional[torch
     y = torch.empty(planar_shape(n, cout, h, wd), dtype=torch.float32, device=x_nchw.device)
     meta = {"flops": 2.0 * 9 * cin * cout * n * h * wd, "bytes": float(n * h * wd * (cin * 4 + cout * 4))}
     check(_launch("conv3x3_first_pl", meta, lambda: lib.wsu_conv3x3_first_pl_fwd(
-        x_nchw.data_ptr(), w.data_ptr(), _ptr(bias), y.data_ptr(), n, h, wd, cin, cout, int(relu), _stream())), "wsu_conv3x3_first_pl_fwd")
+        x_nchw.data_ptr(), w.data_ptr(), _ptr(bias), y.data_ptr(), n, h, wd, cin, cout, int(relu), _ptr(range_flag), _stream())), "wsu_conv3x3_first_pl_fwd")
     return y
 
 
