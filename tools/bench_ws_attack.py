@@ -17,7 +17,7 @@ from ws_unet_amd.ws import estimate  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=32)
 ap.add_argument("--steps", type=int, default=10)
-ap.add_argument("--mode", default="f16f8")
+ap.add_argument("--mode", default="f16f8p")
 ap.add_argument("--correct-bias", action="store_true")
 a = ap.parse_args()
 dev = "cuda"
