@@ -125,11 +125,14 @@ int wsu_conv3x3_wino_fwd(const void* x1, const void* x2, const void* w_packed, c
  *      chunks and tiles (csrc/conv3x3_pl.hip).  Weights from wsu_conv3x3_pack(mode F16F8).  Outputs, each optional: y (planar),
  *      y_pool (2x2 max-pooled, planar), head (1x1 conv + sigmoid on cout == 64 channels; out / logit NCHW fp32).  range_flag (optional
  *      device word, all three planar entry points): bit 0 is OR-ed in when a stored activation exceeds +-448, where the e4m3 residual
- *      saturates and that value keeps only f16 accuracy (NaN / Inf set it too) -- the caller's signal to switch to BF16X3S.  Replaces the same
+ *      saturates and that value keeps only f16 accuracy (NaN / Inf set it too) -- the caller's signal to switch to BF16X3S.
+ *      x_residual = 0 (plain variant only): the inputs' residual plane is neither loaded nor multiplied -- w*x ~ f16(w)*f16(x) + e4m3(w - f16 w)*e4m3(x),
+ *      15 instead of 19 matrix units per chunk; the activation rounding of THIS layer's inputs then costs ~2.5e-5 MAE on the network output
+ *      (profiles/r02/conv3x3_units_probe.md), so a caller spends it on at most a few layers.  Replaces the same
  *      reference lines as wsu_conv3x3_fwd / wsu_conv3x3_head_fwd (unet.py:141-189). */
 int wsu_conv3x3_pl_fwd(const void* x1, const void* x2, const void* w_packed, const float* bias, void* y, void* y_pool,
                        const float* head_w, const float* head_b, float* head_out, float* head_logit, int head_cout,
-                       int n, int h, int w, int c1, int c2, int cout, int relu, unsigned* range_flag, void* stream);
+                       int n, int h, int w, int c1, int c2, int cout, int relu, int x_residual, unsigned* range_flag, void* stream);
 
 /* ---- K3p / K0p: the other two kernels of the planar (F16F8P) inference path (csrc/planar.hip).
  *      wsu_convt2x2_pl_fwd: nn.ConvTranspose2d(k2, s2) + bias (unet.py:125,130,177,183), x: cin channels at (h, w) planar -> y: cout channels at

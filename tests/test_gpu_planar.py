@@ -175,3 +175,36 @@ def test_range_flag_and_loud_fallback(caplog):
     sd = {k: v.detach().cpu() for k, v in big.state_dict().items()}
     ref = unet_ref.unet_forward(x.clone(), sd, 1)
     assert (yb.cpu() - ref).abs().max().item() <= 1e-4
+
+
+def test_conv3x3_pl_one_cross_term_variant():
+    """x_residual = 0: the inputs' residual plane is ignored -- the result is the conv of the f16-ROUNDED activations with the (f16 + residual)
+    weights, i.e. exact up to 2^-15 against an oracle fed f16-rounded inputs, and within f16's 2^-12 of the true conv."""
+    n, h, w = 2, 32, 64
+    x1, x2 = rand_act((n, 64, h, w), "plq/x1"), rand_act((n, 64, h, w), "plq/x2")
+    wt, b = _w("plq/w", (64, 128, 3, 3), (6.0 / 1152) ** 0.5), _w("plq/b", (64,), 0.1)
+    xin = torch.cat([x1, x2], 1)
+    ref = F.relu(unet_ref.conv3x3_reflect(xin, wt, b))
+    ref_h = F.relu(unet_ref.conv3x3_reflect(xin.half().float(), wt, b))
+    wp = ops.pack_conv3x3(wt.to(DEV), M)
+    y = ops.conv3x3_pl(planar_encode(x1), planar_encode(x2), wp, b.to(DEV), 64, x_residual=False)
+    got = planar_decode(y)
+    scale = ref.abs().max().item()
+    assert (got - ref_h).abs().max().item() <= 1e-4 * scale
+    assert (got - ref).abs().max().item() <= 6e-4 * scale
+    full = planar_decode(ops.conv3x3_pl(planar_encode(x1), planar_encode(x2), wp, b.to(DEV), 64))
+    assert (full - ref).abs().max().item() <= 1e-4 * scale and (full - got).abs().max().item() > 0
+
+
+def test_unet_mode_f16f8q_error_budget():
+    """'f16f8q' spends part of the 1e-4 MAE budget on two layers (plain-f16 activations into d31 / d41): predicted 3.9e-5 from the per-slot
+    table of profiles/r02/conv3x3_units_probe.md, measured 3.86e-5 on the bench batch; the exact modes stay at 4e-6."""
+    from gpu_util import gpu_model, images01, oracle_forward
+    _, x = images01(2, 256, 256, seed=77)
+    ref = oracle_forward(x, 2)
+    with torch.no_grad():
+        yq = gpu_model(2, "he", "f16f8q")(x.to(DEV)).cpu()
+        yp = gpu_model(2, "he", "f16f8p")(x.to(DEV)).cpu()
+    eq, ep = (yq - ref).abs(), (yp - ref).abs()
+    assert ep.mean().item() <= 1e-5 and ep.max().item() <= 1e-4
+    assert 1e-5 < eq.mean().item() <= 6e-5 and eq.max().item() <= 6e-4, (eq.mean().item(), eq.max().item())

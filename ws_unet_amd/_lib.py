@@ -21,8 +21,9 @@ _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "libwsu.so"
 
 MODE_F32, MODE_BF16X3, MODE_BF16, MODE_BF16X3S, MODE_F16F8, MODE_F16F8X = 0, 1, 2, 3, 4, 5
-MODE_F16F8P = 6          # host-side name only: the planar inference path has its own entry points (wsu_*_pl_fwd), no `mode` argument
-MODES = {"f32": MODE_F32, "bf16x3": MODE_BF16X3, "bf16": MODE_BF16, "bf16x3s": MODE_BF16X3S, "f16f8": MODE_F16F8, "f16f8x": MODE_F16F8X, "f16f8p": MODE_F16F8P}
+MODE_F16F8P = 6          # host-side names only: the planar inference path has its own entry points (wsu_*_pl_fwd), no `mode` argument
+MODE_F16F8Q = 7          # f16f8p with x_residual = 0 on the first conv of every decoder block
+MODES = {"f32": MODE_F32, "bf16x3": MODE_BF16X3, "bf16": MODE_BF16, "bf16x3s": MODE_BF16X3S, "f16f8": MODE_F16F8, "f16f8x": MODE_F16F8X, "f16f8p": MODE_F16F8P, "f16f8q": MODE_F16F8Q}
 
 
 class WsuError(RuntimeError):
@@ -46,7 +47,7 @@ SIGNATURES = {
     "wsu_conv3x3_wino_packed_bytes": (c_size_t, [c_int, c_int]),
     "wsu_conv3x3_wino_pack": (c_int, [_P, _P, c_int, c_int, _P]),
     "wsu_conv3x3_wino_fwd": (c_int, [_P] * 11 + [c_int] * 8 + [_P]),
-    "wsu_conv3x3_pl_fwd": (c_int, [_P] * 10 + [c_int] * 8 + [_P, _P]),
+    "wsu_conv3x3_pl_fwd": (c_int, [_P] * 10 + [c_int] * 9 + [_P, _P]),
     "wsu_convt2x2_pl_fwd": (c_int, [_P, _P, _P, _P] + [c_int] * 5 + [_P, _P]),
     "wsu_conv3x3_first_pl_fwd": (c_int, [_P, _P, _P, _P] + [c_int] * 6 + [_P, _P]),
     "wsu_conv3x3_first_fwd": (c_int, [_P, _P, _P, _P] + [c_int] * 7 + [_P]),

@@ -51,6 +51,7 @@ struct PlArgs {
     int tiles_x, tiles_y, ncb, nch1, nch;
     int relu;
     int ntiles;                                           // n * tiles_y * tiles_x * ncb
+    int xres;                                             // 0: the inputs' residual plane (plane 2) is not used (kernel variant XRES = false)
     unsigned* range_flag;                                 // optional: bit 0 is set when a stored activation exceeds the encodable range (|x| > 448)
     int ablate;                                           // timing-only experiments (WSU_PL_ABLATE; results wrong when != 0): 1 = no DMA after step 0
 };
@@ -83,7 +84,7 @@ __device__ __forceinline__ void plan_tile(const PlArgs& a, const Tile& t, int lw
         const int idx = seg * 64 + lane;
         const int r = idx / IW, c = idx - r * IW;
         const int yy = wsu_reflect(t.y0 - 1 + r, a.h), xx = wsu_reflect(t.x0 - 1 + c, a.w);
-        goff[k] = idx < NPIX ? plane * hw + yy * a.w + xx : -1;
+        goff[k] = (idx < NPIX && (a.xres || plane != 2)) ? plane * hw + yy * a.w + xx : -1;
     }
 }
 
@@ -144,7 +145,9 @@ __device__ __forceinline__ void swap32(uint32_t& upper_of, uint32_t& lower_of) {
 
 // HEAD / POOL are compile-time: the kernel sits at the 168-register step (three waves per SIMD), and the head's partial sums or the pool's
 // exchange registers would otherwise be carried -- and spilled -- by the variants that do not use them.
-template <int HC, bool POOL>            // HC = head planes compiled in: 0 (no head), 1 (the reference's single output plane) or 4 (1..4)
+// XRES = false: the activations' residual plane is neither loaded nor multiplied (one cross term per product, the weights' residual:
+// 9 f16 + 3 fp8 instructions = 15 instead of 19 matrix units per chunk, 30 instead of 40 input DMA pieces) -- `x_residual = 0`, see wsu.h.
+template <int HC, bool POOL, bool XRES = true>            // HC = head planes compiled in: 0 (no head), 1 (the reference's single output plane) or 4 (1..4)
 __global__ __launch_bounds__(NT) void conv3x3_pl_kernel(const PlArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -278,11 +281,40 @@ _Pragma("unroll")
         // Measured neutral on this section (gpurun_out/ab_prio.log, time_pl*.log): raising the priority of waves 4-7 for its second half so
         // that SIMD partners reach the barrier together; fetching fragments one unit ahead of their matrix instructions behind scheduling
         // fences (two ahead needs 190 registers).
-        WSU_STATIC_FOR(5, tp, {
-            cross(std::integral_constant<int, tp>{});
-            main_term(std::integral_constant<int, 2 * tp>{});
-            if constexpr (2 * tp + 1 < 9) main_term(std::integral_constant<int, 2 * tp + 1>{});
-        });
+        if constexpr (XRES) {
+            WSU_STATIC_FOR(5, tp, {
+                cross(std::integral_constant<int, tp>{});
+                main_term(std::integral_constant<int, 2 * tp>{});
+                if constexpr (2 * tp + 1 < 9) main_term(std::integral_constant<int, 2 * tp + 1>{});
+            });
+        } else {
+            // one cross term: residual(w) x e4m3(x), FOUR taps per fp8 instruction -- scale block b (registers 4b..4b+3), lane half hh carry
+            // the 16 channels of tap 4g + 2b + hh; both blocks use the scales (WLO, X); slots of taps > 8 pass zeros
+            auto cross1 = [&](auto g_c) __attribute__((always_inline)) {
+                constexpr int g = decltype(g_c)::value;
+                u32x4 ab[2][2], bb[2][2];                               // [block][m] / [block][q]
+                WSU_STATIC_FOR(2, b, {
+                    constexpr int ta = 4 * g + 2 * b, tb = ta + 1;      // tap of lanes 0-31 / 32-63
+                    constexpr int tac = ta < 9 ? ta : 8, tbc = tb < 9 ? tb : 8;
+                    const int aoff = ((hh ? tbc : tac) * 4 + 3) * 64 * 16;
+                    const int boff = 3 * PLANE + (hh ? ((tbc / 3) * IW + tbc % 3) : ((tac / 3) * IW + tac % 3)) * 16;
+                    const bool dead = hh ? tb > 8 : ta > 8;
+                    const u32x4 z = mk_u4(0, 0, 0, 0);
+_Pragma("unroll")
+                    for (int m = 0; m < 2; ++m) { ab[b][m] = *reinterpret_cast<const u32x4*>(ldsA + aoff + m * 32 * 16); if (dead) ab[b][m] = z; }
+_Pragma("unroll")
+                    for (int q = 0; q < 2; ++q) { bb[b][q] = *reinterpret_cast<const u32x4*>(ldsB + boff + q * IW * 16); if (dead) bb[b][q] = z; }
+                });
+_Pragma("unroll")
+                for (int m = 0; m < 2; ++m)
+_Pragma("unroll")
+                    for (int q = 0; q < 2; ++q) wsu_mfma_f8x2(ab[0][m], ab[1][m], bb[0][q], bb[1][q], WSU_F8_SCALE_WLO, WSU_F8_SCALE_X, acc[m][q]);
+            };
+            WSU_STATIC_FOR(3, g, {
+                cross1(std::integral_constant<int, g>{});
+                WSU_STATIC_FOR(4, i, { if constexpr (4 * g + i < 9) main_term(std::integral_constant<int, 4 * g + i>{}); });
+            });
+        }
 
         STAMP(s4);
         t_wait += s1 - s0; t_bar += s2 - s1; t_dma += s3 - s2; t_mma += s4 - s3;
@@ -429,7 +461,7 @@ int wsu_debug_read_pl_stamps(unsigned long long* host_dst, int nblocks) {
 // cout of 64.  Asynchronous on `stream`; allocates nothing.
 int wsu_conv3x3_pl_fwd(const void* x1, const void* x2, const void* w_packed, const float* bias, void* y, void* y_pool,
                        const float* head_w, const float* head_b, float* head_out, float* head_logit, int head_cout,
-                       int n, int h, int w, int c1, int c2, int cout, int relu, unsigned* range_flag, void* stream) {
+                       int n, int h, int w, int c1, int c2, int cout, int relu, int x_residual, unsigned* range_flag, void* stream) {
     WSU_REQUIRE(x1 && w_packed && (y || y_pool || head_w), "conv3x3_pl: null pointer");
     WSU_REQUIRE(n > 0 && h >= 2 && w >= 2, "conv3x3_pl: bad shape n=%d h=%d w=%d (reflect pad 1 needs h,w >= 2)", n, h, w);
     WSU_REQUIRE(c1 > 0 && c1 % 16 == 0 && c2 >= 0 && c2 % 16 == 0 && (c2 == 0) == (x2 == nullptr), "conv3x3_pl: c1=%d c2=%d must be multiples of 16", c1, c2);
@@ -437,12 +469,13 @@ int wsu_conv3x3_pl_fwd(const void* x1, const void* x2, const void* w_packed, con
     WSU_REQUIRE(!head_w || (head_out && cout == WSU_COB && head_cout >= 1 && head_cout <= 4), "conv3x3_pl: fused head needs cout == %d and 1..4 head planes", WSU_COB);
     WSU_REQUIRE(!y_pool || (h % 2 == 0 && w % 2 == 0), "conv3x3_pl: fused pool needs even h, w");
     WSU_REQUIRE(!(y_pool && head_w), "conv3x3_pl: the fused pool and the fused head exclude each other");
+    WSU_REQUIRE(x_residual || (!y_pool && !head_w), "conv3x3_pl: x_residual = 0 is built for the plain variant (no fused pool / head)");
     WSU_REQUIRE((long long)h * w * 4 < 0x7FFFFFFFLL, "conv3x3_pl: h*w too large");
     PlArgs a;
     a.x1 = (const char*)x1; a.x2 = (const char*)x2; a.wp = (const char*)w_packed; a.bias = bias;
     a.y = (char*)y; a.ypool = (char*)y_pool;
     a.head_w = head_w; a.head_b = head_b; a.head_out = head_out; a.head_logit = head_logit; a.head_cout = head_cout;
-    a.range_flag = range_flag;
+    a.range_flag = range_flag; a.xres = x_residual ? 1 : 0;
     a.n = n; a.h = h; a.w = w; a.c1 = c1; a.c2 = c2; a.cout = cout;
     a.tiles_x = (w + TW - 1) / TW; a.tiles_y = (h + TH - 1) / TH; a.ncb = cout / WSU_COB;
     a.nch1 = c1 / 16; a.nch = (c1 + c2) / 16; a.relu = relu;
@@ -458,8 +491,9 @@ int wsu_conv3x3_pl_fwd(const void* x1, const void* x2, const void* w_packed, con
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
             wsu_set_error("conv3x3_pl: cannot query the device"); return WSU_ERR_HIP;
         }
-        const void* fns[4] = {reinterpret_cast<const void*>(&conv3x3_pl_kernel<0, false>), reinterpret_cast<const void*>(&conv3x3_pl_kernel<0, true>),
-                              reinterpret_cast<const void*>(&conv3x3_pl_kernel<1, false>), reinterpret_cast<const void*>(&conv3x3_pl_kernel<4, false>)};
+        const void* fns[5] = {reinterpret_cast<const void*>(&conv3x3_pl_kernel<0, false>), reinterpret_cast<const void*>(&conv3x3_pl_kernel<0, true>),
+                              reinterpret_cast<const void*>(&conv3x3_pl_kernel<1, false>), reinterpret_cast<const void*>(&conv3x3_pl_kernel<4, false>),
+                              reinterpret_cast<const void*>(&conv3x3_pl_kernel<0, false, false>)};
         for (const void* fn : fns) {
             hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
             if (e != hipSuccess) { wsu_set_error("hipFuncSetAttribute(conv3x3_pl): %s", hipGetErrorString(e)); return WSU_ERR_HIP; }
@@ -471,6 +505,7 @@ int wsu_conv3x3_pl_fwd(const void* x1, const void* x2, const void* w_packed, con
     if (head_w && head_cout == 1) hipLaunchKernelGGL((conv3x3_pl_kernel<1, false>), dim3(grid), dim3(NT), LDS_TOTAL, s, a);
     else if (head_w) hipLaunchKernelGGL((conv3x3_pl_kernel<4, false>), dim3(grid), dim3(NT), LDS_TOTAL, s, a);
     else if (y_pool) hipLaunchKernelGGL((conv3x3_pl_kernel<0, true>), dim3(grid), dim3(NT), LDS_TOTAL, s, a);
+    else if (!x_residual) hipLaunchKernelGGL((conv3x3_pl_kernel<0, false, false>), dim3(grid), dim3(NT), LDS_TOTAL, s, a);
     else hipLaunchKernelGGL((conv3x3_pl_kernel<0, false>), dim3(grid), dim3(NT), LDS_TOTAL, s, a);
     return wsu_check_launch("conv3x3_pl_kernel");
 }

@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import MODES, MODE_BF16, MODE_BF16X3, MODE_BF16X3S, MODE_F16F8, MODE_F16F8X, MODE_F16F8P, check
+from ._lib import MODES, MODE_BF16, MODE_BF16X3, MODE_BF16X3S, MODE_F16F8, MODE_F16F8X, MODE_F16F8P, MODE_F16F8Q, check
 
 
 def _stream() -> int:
@@ -112,7 +112,7 @@ def _esz(mode: int) -> int:
 def weight_mode(mode: int) -> int:
     """The packed weights of 'bf16x3s' are the 'bf16x3' ones; 'f16f8' has its own packing, shared by 'f16f8x' (the same arithmetic on
     fp32 tensors: the training forward)."""
-    return MODE_BF16X3 if mode == MODE_BF16X3S else (MODE_F16F8 if mode in (MODE_F16F8X, MODE_F16F8P) else mode)
+    return MODE_BF16X3 if mode == MODE_BF16X3S else (MODE_F16F8 if mode in (MODE_F16F8X, MODE_F16F8P, MODE_F16F8Q) else mode)
 
 
 def first_layer_weight_mode(mode: int) -> int:
@@ -255,7 +255,7 @@ def planar_shape(n: int, c: int, h: int, w: int):
 def conv3x3_pl(x1: torch.Tensor, x2: Optional[torch.Tensor], w_packed: torch.Tensor, bias: Optional[torch.Tensor], cout: int,
                relu: bool = True, pool: bool = False, want_y: bool = True,
                head_w: Optional[torch.Tensor] = None, head_b: Optional[torch.Tensor] = None, want_logit: bool = False,
-               range_flag: Optional[torch.Tensor] = None):
+               range_flag: Optional[torch.Tensor] = None, x_residual: bool = True):
     """3x3 reflect conv (+ReLU, +2x2 max-pool, +1x1 head and sigmoid) on planar F16F8P activations (wsu_conv3x3_pl_fwd).
     x1 / x2: planar tensors (N, C/16, 4, H, W, 4); w_packed from pack_conv3x3(mode f16f8).  Returns y [, y_pool] or, with head_w,
     out [, logit][, y]."""
@@ -279,7 +279,7 @@ def conv3x3_pl(x1: torch.Tensor, x2: Optional[torch.Tensor], w_packed: torch.Ten
                            + 9 * (c1 + c2) * cout * 4)}
     check(_launch("conv3x3_pl", meta, lambda: lib.wsu_conv3x3_pl_fwd(
         x1.data_ptr(), _ptr(x2), w_packed.data_ptr(), _ptr(bias), _ptr(y), _ptr(yp), _ptr(hw2), _ptr(head_b), _ptr(out), _ptr(logit), hc,
-        n, h, w, c1, c2, cout, int(relu), _ptr(range_flag), _stream())), "wsu_conv3x3_pl_fwd")
+        n, h, w, c1, c2, cout, int(relu), int(x_residual), _ptr(range_flag), _stream())), "wsu_conv3x3_pl_fwd")
     if hc:
         res = [out] + ([logit] if want_logit else []) + ([y] if want_y else [])
         return res[0] if len(res) == 1 else tuple(res)
