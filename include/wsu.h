@@ -263,9 +263,22 @@ int wsu_l1ws_loss_fwd_bwd(const float* out, const float* covers, const float* in
                           int n, long long per_image, int use_l1, int use_ws, void* stream);
 
 /* K9: multi-tensor AdamW (decoupled weight decay), one launch for all parameters.
- * table: DEVICE array of ntensors records {float* p; const float* g; float* m; float* v; int64 n; int64 first_block}. */
+ * table: DEVICE array of ntensors records {float* p; const float* g; float* m; float* v; int64 n; int64 first_block}.
+ * skip_flag: optional device int; non-zero = the launch changes nothing. */
 int wsu_adamw_multi_tensor(const void* table, int ntensors, long long total_blocks,
-                           float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
+                           float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
+                           const int* skip_flag, void* stream);
+
+/* Helpers of the train step that keep its scalar arithmetic on the device and inside libwsu (reference: there is none -- PyTorch's
+ * GradScaler plays this role for fp16 training; pattern src/detector/train.py:88-95):
+ *   wsu_pow2_grad_scale     scale2 = {2^floor(2 - log2 max|x|), its reciprocal}: the power-of-two scale of the f16f8x backward chain
+ *   wsu_scale_f32           y = x * factor[0]
+ *   wsu_scale_multi_tensor  in-place, many tensors, one launch; table records {float* p; int64 n; int64 first_block}
+ *   wsu_nonfinite_flag      flag[0] = bucket holds inf / NaN, flag[1] += flag[0]; feed flag to wsu_adamw_multi_tensor(skip_flag) */
+int wsu_pow2_grad_scale(const float* x, long long n, float* scale2, void* workspace, void* stream);
+int wsu_scale_f32(const float* x, float* y, long long n, const float* factor, void* stream);
+int wsu_scale_multi_tensor(const void* table, int ntensors, long long total_blocks, const float* factor, void* stream);
+int wsu_nonfinite_flag(const float* g, long long n, int* flag, void* stream);
 
 #ifdef __cplusplus
 }

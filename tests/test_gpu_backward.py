@@ -227,7 +227,8 @@ def test_training_reduces_loss_and_checkpoints(tmp_path):
     loader = [(inputs[i:i + 4], (covers[i:i + 4], alphas[i:i + 4])) for i in (0, 4)]
     tr.fit(loader, loader, num_epochs=4)
     tags = {t for _, t, _ in tr.scalars}
-    assert tags == {"train/loss", "train/mae", "train/ws", "val/loss", "val/mae", "val/ws"}
+    assert tags == {"train/loss", "train/mae", "train/ws", "train/skipped_steps", "val/loss", "val/mae", "val/ws"}
+    assert tr.skipped_steps() == 0
     tl = [v for e, t, v in tr.scalars if t == "train/loss"]
     assert tl[-1] < tl[0]
     ck = torch.load(tmp_path / "run" / "model" / "best_model.pt.tar", weights_only=True)
@@ -342,3 +343,36 @@ def test_train_driver_replays_a_published_style_config(tmp_path):
     assert np.isfinite(best2) and len(list((tmp_path / "runs" / "LSBR").iterdir())) == 2
     with pytest.raises(Exception, match="no checkpoint"):
         train_mod.train({**cfg, "resume": "missing-run"})
+
+
+def test_train_step_helpers_and_finite_guard():
+    """wsu_pow2_grad_scale / wsu_scale_* against their torch definitions, and the finite guard: a poisoned gradient bucket leaves parameters
+    and AdamW moments untouched, the skipped step is counted, the next clean step proceeds (an inf must not reach the moments)."""
+    g = torch.Generator(device=DEV).manual_seed(3)
+    for mag in (3e-7, 1.0, 517.0, 0.0):
+        x = (torch.randn(3, 1, 33, 65, device=DEV, generator=g) * mag).contiguous()
+        s2 = ops.pow2_grad_scale(x)
+        ref = torch.exp2(torch.floor(2.0 - torch.log2(x.abs().max().clamp_min(1e-30))))
+        assert s2[0].item() == ref.item() and s2[0].item() * s2[1].item() == 1.0
+        if mag:
+            assert 4.0 <= (x.abs().max() * s2[0]).item() < 8.0
+        assert torch.equal(ops.scale_by(x, s2[0:1]), x * s2[0])
+    ts = [torch.randn(n, device=DEV, generator=g) for n in (5, 1024, 1025, 70000)]
+    want = [t * 0.125 for t in ts]
+    ops.scale_many_(ts + [None], torch.tensor([0.125], device=DEV))
+    assert all(torch.equal(a, b) for a, b in zip(ts, want))
+
+    model = gpu_model(0, "he", "f32")
+    cov_u8 = formula.synthetic_images(2, 32, 32, seed=41)
+    covers = torch.from_numpy(cov_u8.astype(np.float32) / np.float32(255.))[:, None].to(DEV)
+    alphas = torch.tensor([0.0, 0.0], device=DEV)
+    tr = Trainer(model, loss="l1ws", lr=1e-3)
+    tr.train_step(covers.clone(), covers, alphas)
+    before = tr.opt.flat_param.clone(); m0, v0 = tr.opt.exp_avg.clone(), tr.opt.exp_avg_sq.clone()
+    bad = covers.clone(); bad[0, 0, 3, 3] = float("inf")
+    tr.train_step(bad, covers, alphas)                                   # inf input -> NaN / inf gradients
+    assert not torch.isfinite(tr.opt.flat_grad).all()
+    assert torch.equal(tr.opt.flat_param, before) and torch.equal(tr.opt.exp_avg, m0) and torch.equal(tr.opt.exp_avg_sq, v0)
+    assert tr.skipped_steps() == 1
+    tr.train_step(covers.clone(), covers, alphas)
+    assert tr.skipped_steps() == 1 and not torch.equal(tr.opt.flat_param, before) and torch.isfinite(tr.opt.flat_param).all()

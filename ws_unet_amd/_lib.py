@@ -79,7 +79,11 @@ SIGNATURES = {
     "wsu_conv1x1_sigmoid_bwd": (c_int, [_P] * 8 + [c_size_t] + [c_int] * 6 + [_P]),
     "wsu_l1ws_loss_workspace_bytes": (c_size_t, [c_int]),
     "wsu_l1ws_loss_fwd_bwd": (c_int, [_P] * 9 + [c_size_t, c_int, c_longlong, c_int, c_int, _P]),
-    "wsu_adamw_multi_tensor": (c_int, [_P, c_int, c_longlong] + [c_float] * 5 + [c_int, c_float, _P]),
+    "wsu_adamw_multi_tensor": (c_int, [_P, c_int, c_longlong] + [c_float] * 5 + [c_int, c_float, _P, _P]),
+    "wsu_pow2_grad_scale": (c_int, [_P, c_longlong, _P, _P, _P]),
+    "wsu_scale_f32": (c_int, [_P, _P, c_longlong, _P, _P]),
+    "wsu_scale_multi_tensor": (c_int, [_P, c_int, c_longlong, _P, _P]),
+    "wsu_nonfinite_flag": (c_int, [_P, c_longlong, _P, _P]),
 }
 
 _lib = None

@@ -86,7 +86,8 @@ struct AdamTensor { float* p; const float* g; float* m; float* v; long long n; l
 
 __global__ __launch_bounds__(256) void adamw_kernel(const AdamTensor* __restrict__ tab, int ntensors,
                                                     float lr, float b1, float b2, float eps, float wd,
-                                                    float bc1, float bc2_sqrt, float grad_scale) {
+                                                    float bc1, float bc2_sqrt, float grad_scale, const int* __restrict__ skip_flag) {
+    if (skip_flag && skip_flag[0]) return;                          // a non-finite gradient bucket: leave parameters and moments alone
     // locate this block's tensor (tables are tiny: <= a few dozen entries)
     int t = 0;
     while (t + 1 < ntensors && (long long)blockIdx.x >= tab[t + 1].first_block) ++t;
@@ -107,9 +108,105 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamTensor* __restrict
     }
 }
 
+// ---- gradient scale of the f16f8x backward chain, finite guard, multi-tensor scaling ---------------------------------------------------
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long long n, unsigned* __restrict__ out_bits) {
+    float m = 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float v = fabsf(x[i]);
+        m = (v > m || v != v) ? v : m;                              // NaN propagates (its bit pattern wins the integer max below)
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float w = __shfl_xor(m, o, 64);
+        m = (w > m || w != w) ? w : m;
+    }
+    if ((threadIdx.x & 63) == 0) atomicMax(out_bits, __builtin_bit_cast(unsigned, m));     // non-negative floats order like their bits
+}
+
+// scale = 2^floor(2 - log2(max |x|)): max |x| * scale in [4, 8) -- 2^13 of headroom below f16's largest value for gradients that grow on the
+// way down the network, while values 2^-27 of that maximum still keep an absolute error below theirs (autograd.py)
+__global__ void pow2_scale_kernel(const unsigned* __restrict__ bits, float* __restrict__ scale2) {
+    float m = __builtin_bit_cast(float, bits[0]);
+    if (!(m >= 1e-30f)) m = 1e-30f;                                  // zero gradient (or NaN: the finite guard deals with that)
+    if (m > 1e30f) m = 1e30f;
+    const float s = exp2f(floorf(2.0f - log2f(m)));
+    scale2[0] = s; scale2[1] = 1.0f / s;
+}
+
+__global__ __launch_bounds__(256) void scale_kernel(const float* __restrict__ x, float* __restrict__ y, long long n, const float* __restrict__ factor) {
+    const float f = factor[0];
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) y[i] = x[i] * f;
+}
+
+struct ScaleTensor { float* p; long long n; long long first_block; };
+
+__global__ __launch_bounds__(256) void scale_multi_kernel(const ScaleTensor* __restrict__ tab, int ntensors, const float* __restrict__ factor) {
+    int t = 0;
+    while (t + 1 < ntensors && (long long)blockIdx.x >= tab[t + 1].first_block) ++t;
+    const ScaleTensor e = tab[t];
+    const float f = factor[0];
+    const long long i0 = ((long long)blockIdx.x - e.first_block) * 1024;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const long long i = i0 + threadIdx.x + k * 256;
+        if (i < e.n) e.p[i] *= f;
+    }
+}
+
+__global__ __launch_bounds__(256) void nonfinite_kernel(const float* __restrict__ g, long long n, int* __restrict__ flag) {
+    bool bad = false;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float v = g[i];
+        bad |= !(fabsf(v) <= 3.4028234e38f);                       // inf or NaN
+    }
+    if (__builtin_amdgcn_ballot_w64(bad) != 0 && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+__global__ void nonfinite_count_kernel(int* __restrict__ flag) { if (flag[0]) flag[1] += 1; }
+
 }  // namespace
 
 extern "C" {
+
+// Power-of-two scale of the f16f8x backward chain (model/autograd.py), computed on the device: scale2[0] = 2^floor(2 - log2 max|x|),
+// scale2[1] = its reciprocal.  workspace: 4 bytes.  Replaces the abs / max / log2 / floor / exp2 chain of ATen launches.
+int wsu_pow2_grad_scale(const float* x, long long n, float* scale2, void* workspace, void* stream) {
+    WSU_REQUIRE(x && scale2 && workspace && n > 0, "pow2_grad_scale: bad arguments");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(workspace, 0, 4, s) != hipSuccess) { wsu_set_error("pow2_grad_scale: memset failed"); return WSU_ERR_HIP; }
+    const unsigned nblk = (unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(absmax_kernel, dim3(nblk), dim3(256), 0, s, x, n, static_cast<unsigned*>(workspace));
+    hipLaunchKernelGGL(pow2_scale_kernel, dim3(1), dim3(1), 0, s, static_cast<const unsigned*>(workspace), scale2);
+    return wsu_check_launch("pow2_scale_kernel");
+}
+
+// y = x * factor[0] (factor on the device; y may alias x).
+int wsu_scale_f32(const float* x, float* y, long long n, const float* factor, void* stream) {
+    WSU_REQUIRE(x && y && factor && n > 0, "scale_f32: bad arguments");
+    const unsigned nblk = (unsigned)((n + 255) / 256 < 16384 ? (n + 255) / 256 : 16384);
+    hipLaunchKernelGGL(scale_kernel, dim3(nblk), dim3(256), 0, static_cast<hipStream_t>(stream), x, y, n, factor);
+    return wsu_check_launch("scale_kernel");
+}
+
+// In-place scaling of many tensors by factor[0] in ONE launch.  table: DEVICE array of records {float* p; int64 n; int64 first_block}
+// (first_block = prefix sum of ceil(n / 1024)), total_blocks = sum ceil(n / 1024).
+int wsu_scale_multi_tensor(const void* table, int ntensors, long long total_blocks, const float* factor, void* stream) {
+    WSU_REQUIRE(table && factor && ntensors > 0 && total_blocks > 0 && total_blocks < 0x7FFFFFFFLL, "scale_multi_tensor: bad arguments");
+    hipLaunchKernelGGL(scale_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const ScaleTensor*>(table), ntensors, factor);
+    return wsu_check_launch("scale_multi_kernel");
+}
+
+// Finite guard of the gradient bucket: flag[0] = 1 if g holds an inf / NaN else 0; flag[1] counts the flagged calls.  The flag is what
+// wsu_adamw_multi_tensor(skip_flag) reads -- no host synchronisation anywhere.
+int wsu_nonfinite_flag(const float* g, long long n, int* flag, void* stream) {
+    WSU_REQUIRE(g && flag && n > 0, "nonfinite_flag: bad arguments");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(flag, 0, 4, s) != hipSuccess) { wsu_set_error("nonfinite_flag: memset failed"); return WSU_ERR_HIP; }
+    const unsigned nblk = (unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+    hipLaunchKernelGGL(nonfinite_kernel, dim3(nblk), dim3(256), 0, s, g, n, flag);
+    hipLaunchKernelGGL(nonfinite_count_kernel, dim3(1), dim3(1), 0, s, flag);
+    return wsu_check_launch("nonfinite_kernel");
+}
 
 size_t wsu_l1ws_loss_workspace_bytes(int n) { return (size_t)n * (2 * sizeof(double) + sizeof(float)); }
 
@@ -139,14 +236,16 @@ int wsu_l1ws_loss_fwd_bwd(const float* out, const float* covers, const float* in
 
 // Multi-tensor AdamW.  `table` is a DEVICE array of ntensors records {p, g, m, v, n, first_block} (6 x 8 bytes each,
 // first_block = prefix sum of ceil(n/1024)), built once by the host side; total_blocks = sum ceil(n/1024).
-// step is the 1-based update count; grad_scale multiplies every gradient (1/world_size after a sum all-reduce).
+// step is the 1-based update count; grad_scale multiplies every gradient (1/world_size after a sum all-reduce); skip_flag (optional
+// device int, wsu_nonfinite_flag): when non-zero the launch changes nothing (a poisoned bucket must not reach the moments).
 int wsu_adamw_multi_tensor(const void* table, int ntensors, long long total_blocks,
-                           float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream) {
+                           float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
+                           const int* skip_flag, void* stream) {
     WSU_REQUIRE(table && ntensors > 0 && total_blocks > 0 && total_blocks < 0x7FFFFFFFLL && step >= 1, "adamw: bad arguments");
     const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));         // host double like torch's Python floats
     const float bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
     hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)total_blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       static_cast<const AdamTensor*>(table), ntensors, lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, grad_scale);
+                       static_cast<const AdamTensor*>(table), ntensors, lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, grad_scale, skip_flag);
     return wsu_check_launch("adamw_kernel");
 }
 

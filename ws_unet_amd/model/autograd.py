@@ -79,14 +79,15 @@ class _UNetFn(torch.autograd.Function):
         # data- and weight-gradient GEMMs of a split-bf16 run: f16f8 arithmetic on the fp32 tensors (model.train_bwd_mode).  Gradients of
         # a mean-reduced loss sit far below f16's normal range, so the whole backward chain runs on gradients scaled by a power of two
         # chosen from |dL/dout| (every kernel on the way is linear in the gradient; ReLU masks and pool routing ignore the scale) and all
-        # parameter / input gradients are scaled back at the end -- exact, and computed on the device (no host synchronisation).
+        # parameter / input gradients are scaled back at the end -- exact, and computed on the device by libwsu (wsu_pow2_grad_scale,
+        # wsu_scale_f32, wsu_scale_multi_tensor: no host synchronisation, no ATen arithmetic).
         mb, scale = m, None
         if m == ops.MODE_BF16X3 and (getattr(model, "train_bwd_mode", None) or "f16f8x") == "f16f8x":
             mb = ops.MODE_F16F8X
             # max |dout| * scale in [4, 8): 2^13 of headroom below f16's largest value for gradients that grow on the way down, while values
             # 2^-27 of that maximum still keep an absolute error below theirs (f16 subnormal spacing 2^-24 + the e4m3 residual)
-            scale = torch.exp2(torch.floor(2.0 - torch.log2(dout.abs().max().clamp_min(1e-30))))
-            dout = dout * scale
+            scale = ops.pow2_grad_scale(dout)                      # device {scale, 1 / scale}: one reduction + one thread, no ATen chain
+            dout = ops.scale_by(dout, scale[0:1])
 
         def conv_bwd(name, g, x1, x2, mask1, mask2, need_dx=True):
             layer = getattr(model, name)
@@ -122,9 +123,7 @@ class _UNetFn(torch.autograd.Function):
                 g, _ = conv_bwd(a, g, t[f"xp{lvl}"], None, None, None)           # pooled tensor: no ReLU of its own
         ctx.t = None
         if scale is not None:
-            inv = 1.0 / scale
-            grads = {k: v * inv for k, v in grads.items()}
-            dx = dx * inv if dx is not None else None
+            ops.scale_many_(list(grads.values()) + [dx], scale[1:2])     # every parameter / input gradient back to its true scale: ONE launch
         out = [None, dx if ctx.needs_input_grad[1] else None]
         for name, p in model.named_parameters():
             out.append(grads[name] if p.requires_grad else None)

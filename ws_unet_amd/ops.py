@@ -720,7 +720,55 @@ class AdamWTable:
     def matches(self, params, grads):
         return all(p.data_ptr() == r[0] and g.data_ptr() == r[1] for p, g, r in zip(params, grads, self.ptrs))
 
-    def step(self, step: int, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, grad_scale=1.0):
+    def step(self, step: int, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, grad_scale=1.0,
+             skip_flag: Optional[torch.Tensor] = None):
         lib = _lib.load()
         check(lib.wsu_adamw_multi_tensor(self.table.data_ptr(), self.ntensors, self.total_blocks, lr, betas[0], betas[1],
-                                         eps, weight_decay, step, grad_scale, _stream()), "wsu_adamw_multi_tensor")
+                                         eps, weight_decay, step, grad_scale, _ptr(skip_flag), _stream()), "wsu_adamw_multi_tensor")
+
+
+def pow2_grad_scale(x: torch.Tensor) -> torch.Tensor:
+    """Device-side {scale, 1/scale} with scale = 2^floor(2 - log2 max|x|) (wsu_pow2_grad_scale): no host sync, no ATen arithmetic."""
+    lib = _lib.load()
+    _dev_check(x)
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    out = torch.empty(2, dtype=torch.float32, device=x.device)
+    ws = workspace(16, x.device)
+    check(lib.wsu_pow2_grad_scale(x.data_ptr(), x.numel(), out.data_ptr(), ws.data_ptr(), _stream()), "wsu_pow2_grad_scale")
+    return out
+
+
+def scale_by(x: torch.Tensor, factor: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x * factor[0] with the factor on the device (wsu_scale_f32); ``out`` may be ``x`` itself."""
+    lib = _lib.load()
+    _dev_check(x, factor)
+    assert x.dtype == torch.float32 and x.is_contiguous() and factor.dtype == torch.float32
+    y = torch.empty_like(x) if out is None else out
+    check(lib.wsu_scale_f32(x.data_ptr(), y.data_ptr(), x.numel(), factor.data_ptr(), _stream()), "wsu_scale_f32")
+    return y
+
+
+def scale_many_(tensors, factor: torch.Tensor) -> None:
+    """In-place multiplication of every tensor by factor[0] in ONE launch (wsu_scale_multi_tensor)."""
+    import numpy as np
+    lib = _lib.load()
+    tensors = [t for t in tensors if t is not None]
+    if not tensors:
+        return
+    rows, first = [], 0
+    for t in tensors:
+        _dev_check(t)
+        assert t.dtype == torch.float32 and t.is_contiguous()
+        rows.append([t.data_ptr(), t.numel(), first])
+        first += (t.numel() + 1023) // 1024
+    table = torch.from_numpy(np.array(rows, dtype=np.int64)).to(tensors[0].device, non_blocking=True)
+    check(lib.wsu_scale_multi_tensor(table.data_ptr(), len(rows), first, factor.data_ptr(), _stream()), "wsu_scale_multi_tensor")
+
+
+def nonfinite_flag(g: torch.Tensor, flag: torch.Tensor) -> torch.Tensor:
+    """flag[0] = 1 if ``g`` holds an inf / NaN else 0, flag[1] += flag[0] (int32[2] on the device; wsu_nonfinite_flag)."""
+    lib = _lib.load()
+    _dev_check(g, flag)
+    assert g.dtype == torch.float32 and g.is_contiguous() and flag.dtype == torch.int32 and flag.numel() >= 2
+    check(lib.wsu_nonfinite_flag(g.data_ptr(), g.numel(), flag.data_ptr(), _stream()), "wsu_nonfinite_flag")
+    return flag

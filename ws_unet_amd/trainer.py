@@ -81,9 +81,9 @@ class FlatAdamW:
                 p.grad = self.flat_grad[off:off + k].view(p.shape)
             off += k
 
-    def step(self, grad_scale: float = 1.0):
+    def step(self, grad_scale: float = 1.0, skip_flag: Optional[torch.Tensor] = None):
         self.step_count += 1
-        self._table.step(self.step_count, self.lr, self.betas, self.eps, self.weight_decay, grad_scale)
+        self._table.step(self.step_count, self.lr, self.betas, self.eps, self.weight_decay, grad_scale, skip_flag)
         if hasattr(self.model, "invalidate_packed"):
             self.model.invalidate_packed()                               # flat update bypasses tensor version counters
 
@@ -111,6 +111,7 @@ class Trainer:
         self.best_val_loss = np.inf
         self.scalars = []                                                # (epoch, tag, value) rows, tags as in the tfevents
         self.epochs_run = 0
+        self._nonfinite = torch.zeros(2, dtype=torch.int32, device=self.opt.flat_param.device)   # [this step, skipped steps so far]
         self._last_l1 = None
         if self.out_dir and self.rank == 0:
             (self.out_dir / "model").mkdir(parents=True, exist_ok=True)
@@ -126,7 +127,10 @@ class Trainer:
         self._last_l1 = self.criterion.last_parts[0]
         loss.backward()
         scale = parallel.allreduce_flat_(self.opt.flat_grad)             # C1: one 7.45 MB fp32 bucket over xGMI
-        self.opt.step(grad_scale=scale)
+        # finite guard behind the all-reduce (so every rank takes the same decision): an overflowed f16f8x gradient chain or an inf / NaN
+        # input must not reach the AdamW moments -- the step is skipped on the device, counted, and reported once per epoch
+        ops.nonfinite_flag(self.opt.flat_grad, self._nonfinite)
+        self.opt.step(grad_scale=scale, skip_flag=self._nonfinite)
         return loss.detach(), outputs.detach()
 
     @torch.no_grad()
@@ -169,7 +173,13 @@ class Trainer:
         prefix = "train/" if train else "val/"
         for name in ("loss", "mae", "ws"):
             self.scalars.append((epoch, prefix + name, float(avg[name])))
+        if train:
+            self.scalars.append((epoch, "train/skipped_steps", float(self.skipped_steps())))
         return float(avg["loss"])
+
+    def skipped_steps(self) -> int:
+        """Optimiser steps skipped so far because the gradient bucket held an inf / NaN (one device read)."""
+        return int(self._nonfinite[1].item())
 
     def save_checkpoint(self, epoch: int, val_loss: float):
         """Checkpoint dict keys and files as src/detector/train.py:281-296 writes them."""
