@@ -355,7 +355,7 @@ def test_train_step_helpers_and_finite_guard():
         ref = torch.exp2(torch.floor(2.0 - torch.log2(x.abs().max().clamp_min(1e-30))))
         assert s2[0].item() == ref.item() and s2[0].item() * s2[1].item() == 1.0
         if mag:
-            assert 4.0 <= (x.abs().max() * s2[0]).item() < 8.0
+            assert 2.0 < (x.abs().max() * s2[0]).item() <= 4.0
         assert torch.equal(ops.scale_by(x, s2[0:1]), x * s2[0])
     ts = [torch.randn(n, device=DEV, generator=g) for n in (5, 1024, 1025, 70000)]
     want = [t * 0.125 for t in ts]

@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x
     if ((threadIdx.x & 63) == 0) atomicMax(out_bits, __builtin_bit_cast(unsigned, m));     // non-negative floats order like their bits
 }
 
-// scale = 2^floor(2 - log2(max |x|)): max |x| * scale in [4, 8) -- 2^13 of headroom below f16's largest value for gradients that grow on the
+// scale = 2^floor(2 - log2(max |x|)): max |x| * scale in (2, 4] -- 2^14 of headroom below f16's largest value for gradients that grow on the
 // way down the network, while values 2^-27 of that maximum still keep an absolute error below theirs (autograd.py)
 __global__ void pow2_scale_kernel(const unsigned* __restrict__ bits, float* __restrict__ scale2) {
     float m = __builtin_bit_cast(float, bits[0]);

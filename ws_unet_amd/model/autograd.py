@@ -84,7 +84,7 @@ class _UNetFn(torch.autograd.Function):
         mb, scale = m, None
         if m == ops.MODE_BF16X3 and (getattr(model, "train_bwd_mode", None) or "f16f8x") == "f16f8x":
             mb = ops.MODE_F16F8X
-            # max |dout| * scale in [4, 8): 2^13 of headroom below f16's largest value for gradients that grow on the way down, while values
+            # max |dout| * scale in (2, 4]: 2^14 of headroom below f16's largest value for gradients that grow on the way down, while values
             # 2^-27 of that maximum still keep an absolute error below theirs (f16 subnormal spacing 2^-24 + the e4m3 residual)
             scale = ops.pow2_grad_scale(dout)                      # device {scale, 1 / scale}: one reduction + one thread, no ATen chain
             dout = ops.scale_by(dout, scale[0:1])
