@@ -134,6 +134,13 @@ int wsu_conv3x3_pl_fwd(const void* x1, const void* x2, const void* w_packed, con
                        const float* head_w, const float* head_b, float* head_out, float* head_logit, int head_cout,
                        int n, int h, int w, int c1, int c2, int cout, int relu, int x_residual, unsigned* range_flag, void* stream);
 
+/* ---- K1p + K0p fused: e11 -> e12 (-> pool) of the planar path in one launch for single-plane inputs (unet.py:141-144).  The loader waves of
+ *      the persistent kernel compute e11's 64 channels from the image straight into the LDS stages (instead of fetching them); bitwise the
+ *      result of wsu_conv3x3_first_pl_fwd followed by wsu_conv3x3_pl_fwd, and xe11 never reaches HBM.  img (N,1,H,W) fp32, w1 (64,1,3,3),
+ *      b1 (64) or NULL; w_packed / bias: the second conv (cin = 64); y / y_pool (each optional, not both NULL) planar. */
+int wsu_conv3x3_pl_fused_first_fwd(const float* img, const float* w1, const float* b1, const void* w_packed, const float* bias,
+                                   void* y, void* y_pool, int n, int h, int w, int cout, int relu, unsigned* range_flag, void* stream);
+
 /* ---- K3p / K0p: the other two kernels of the planar (F16F8P) inference path (csrc/planar.hip).
  *      wsu_convt2x2_pl_fwd: nn.ConvTranspose2d(k2, s2) + bias (unet.py:125,130,177,183), x: cin channels at (h, w) planar -> y: cout channels at
  *      (2h, 2w) planar; weights from wsu_convt2x2_pack(mode F16F8); cin a multiple of 32, cout of 64.

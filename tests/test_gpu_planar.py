@@ -208,3 +208,42 @@ def test_unet_mode_f16f8q_error_budget():
     eq, ep = (yq - ref).abs(), (yp - ref).abs()
     assert ep.mean().item() <= 1e-5 and ep.max().item() <= 1e-4
     assert 1e-5 < eq.mean().item() <= 6e-5 and eq.max().item() <= 6e-4, (eq.mean().item(), eq.max().item())
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 64), (1, 40, 72), (3, 2, 2), (2, 18, 34)])
+def test_fused_first_layer_pl_is_bitwise_the_two_kernels(shape):
+    """wsu_conv3x3_pl_fused_first_fwd: the loader waves compute e11 into the LDS stages -- same fp32 FMA order and encodings as
+    first_pl_kernel, so the outputs equal first_pl + conv3x3_pl bit for bit (ragged tiles, the smallest image, a tile edge + 2)."""
+    n, h, w = shape
+    x = rand_act((n, 1, h, w), f"plff/x/{shape}", relu=False).to(DEV)
+    w1, b1 = _w("plff/w1", (64, 1, 3, 3), 0.5).to(DEV), _w("plff/b1", (64,), 0.1).to(DEV)
+    wt, b = _w("plff/w", (64, 64, 3, 3), (6.0 / 576) ** 0.5).to(DEV), _w("plff/b", (64,), 0.1).to(DEV)
+    wp = ops.pack_conv3x3(wt, M)
+    even = h % 2 == 0 and w % 2 == 0
+    ref = ops.conv3x3_pl(ops.conv3x3_first_pl(x, w1, b1), None, wp, b, 64, pool=even)
+    got = ops.conv3x3_pl_fused_first(x, w1, b1, wp, b, 64, pool=even)
+    for a_, b_ in zip(got if even else (got,), ref if even else (ref,)):
+        assert torch.equal(a_, b_)
+    for _ in range(20):                                                  # race screen of the loader-computed stages
+        again = ops.conv3x3_pl_fused_first(x, w1, b1, wp, b, 64, pool=even)
+        for a_, b_ in zip(again if even else (again,), got if even else (got,)):
+            assert torch.equal(a_, b_)
+
+
+def test_unet_planar_with_fused_first_layer():
+    """model.fuse_first_planar: same output as the unfused planar path bit for bit, and the range flag also sees the (never stored) xe11."""
+    from gpu_util import gpu_model, images01
+    _, x = images01(2, 64, 96, seed=12)
+    m = gpu_model(2, "he", "f16f8p")
+    with torch.no_grad():
+        y0 = m(x.to(DEV))
+        m.fuse_first_planar = True
+        y1 = m(x.to(DEV))
+    assert torch.equal(y0, y1)
+    big = gpu_model(1, "he", "f16f8p")
+    big.fuse_first_planar = True
+    with torch.no_grad():
+        big.e11.weight.mul_(3000.0); big.e11.bias.mul_(3000.0); big.e12.weight.div_(3000.0)
+        big.invalidate_packed()
+        big(x.to(DEV))
+    assert big.mode == "bf16x3s"

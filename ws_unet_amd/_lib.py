@@ -48,6 +48,7 @@ SIGNATURES = {
     "wsu_conv3x3_wino_pack": (c_int, [_P, _P, c_int, c_int, _P]),
     "wsu_conv3x3_wino_fwd": (c_int, [_P] * 11 + [c_int] * 8 + [_P]),
     "wsu_conv3x3_pl_fwd": (c_int, [_P] * 10 + [c_int] * 9 + [_P, _P]),
+    "wsu_conv3x3_pl_fused_first_fwd": (c_int, [_P] * 7 + [c_int] * 5 + [_P, _P]),
     "wsu_convt2x2_pl_fwd": (c_int, [_P, _P, _P, _P] + [c_int] * 5 + [_P, _P]),
     "wsu_conv3x3_first_pl_fwd": (c_int, [_P, _P, _P, _P] + [c_int] * 6 + [_P, _P]),
     "wsu_conv3x3_first_fwd": (c_int, [_P, _P, _P, _P] + [c_int] * 7 + [_P]),

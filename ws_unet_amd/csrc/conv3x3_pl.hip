@@ -29,7 +29,8 @@ constexpr int LDS_IN = WSU_GRAN * PLANE;                  // 39168
 constexpr int LDS_W = 9 * WSU_GRAN * WSU_COB * 16;        // 36864
 constexpr int STAGE = LDS_IN + LDS_W;                     // 76032
 constexpr int LDS_EXTRA = 2 * STAGE;                      // bias [1024] | head_w [4][64] | head_b [4]
-constexpr int LDS_TOTAL = LDS_EXTRA + 1024 * 4 + 4 * 64 * 4 + 16;
+constexpr int LDS_F1 = LDS_EXTRA + 1024 * 4 + 4 * 64 * 4 + 16;   // fused first layer: w1 tap-major [9][64] | b1 [64]
+constexpr int LDS_TOTAL = LDS_F1 + 9 * 64 * 4 + 64 * 4;
 constexpr int NWAVE = 8, NLOAD = 4, NT = (NWAVE + NLOAD) * 64;      // 8 matrix waves + 4 loader waves (one per SIMD)
 constexpr int IN_SEG = (NPIX + 63) / 64;                  // 10 wave-instructions per plane (the last one 36 lanes wide)
 constexpr int IN_SLOTS = WSU_GRAN * IN_SEG;               // 40
@@ -51,6 +52,7 @@ struct PlArgs {
     int tiles_x, tiles_y, ncb, nch1, nch;
     int relu;
     int ntiles;                                           // n * tiles_y * tiles_x * ncb
+    const float* img; const float* w1; const float* b1;   // fused first layer (kernel variant F1): the 64 input channels are computed by the loaders
     int xres;                                             // 0: the inputs' residual plane (plane 2) is not used (kernel variant XRES = false)
     unsigned* range_flag;                                 // optional: bit 0 is set when a stored activation exceeds the encodable range (|x| > 448)
     int ablate;                                           // timing-only experiments (WSU_PL_ABLATE; results wrong when != 0): 1 = no DMA after step 0
@@ -118,7 +120,15 @@ __device__ __forceinline__ void dma_slot(const DmaPlan& p, int lw8, const int (&
     }
 }
 
+template <bool WEIGHTS_ONLY = false>
 __device__ __forceinline__ void issue_dma(const PlArgs& a, int tn, int tcb, int c, char* st, int lw8, int lane, const int (&goff)[IN_PER_WAVE]) {
+    if constexpr (WEIGHTS_ONLY) {
+        DmaPlan p;
+        p.in_src = nullptr; p.st = st;
+        p.w_src = a.wp + ((size_t)tcb * a.nch + c) * LDS_W + lane * 16;
+        WSU_STATIC_FOR(W_PER_WAVE, k, { dma_slot<IN_PER_WAVE + k>(p, lw8, goff); });
+        return;
+    }
     const DmaPlan p = dma_plan(a, tn, tcb, c, st, lane);
     // weight and input pieces alternate, so that the first pieces of both operands land early
     WSU_STATIC_FOR(W_PER_WAVE, k, { dma_slot<k>(p, lw8, goff); dma_slot<IN_PER_WAVE + k>(p, lw8, goff); });
@@ -147,7 +157,7 @@ __device__ __forceinline__ void swap32(uint32_t& upper_of, uint32_t& lower_of) {
 // exchange registers would otherwise be carried -- and spilled -- by the variants that do not use them.
 // XRES = false: the activations' residual plane is neither loaded nor multiplied (one cross term per product, the weights' residual:
 // 9 f16 + 3 fp8 instructions = 15 instead of 19 matrix units per chunk, 30 instead of 40 input DMA pieces) -- `x_residual = 0`, see wsu.h.
-template <int HC, bool POOL, bool XRES = true>            // HC = head planes compiled in: 0 (no head), 1 (the reference's single output plane) or 4 (1..4)
+template <int HC, bool POOL, bool XRES = true, bool F1 = false>            // HC = head planes compiled in: 0 (no head), 1 (the reference's single output plane) or 4 (1..4)
 __global__ __launch_bounds__(NT) void conv3x3_pl_kernel(const PlArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -166,6 +176,12 @@ __global__ __launch_bounds__(NT) void conv3x3_pl_kernel(const PlArgs a) {
         for (int i = tid; i < a.head_cout * 64; i += NT) s_hw[i] = a.head_w[i];
         if (tid < 4) s_hb[tid] = (a.head_b && tid < a.head_cout) ? a.head_b[tid] : 0.f;
     }
+    float* s_w1 = reinterpret_cast<float*>(smem + LDS_F1);
+    float* s_b1 = s_w1 + 9 * 64;
+    if constexpr (F1) {
+        for (int i = tid; i < 9 * 64; i += NT) { const int tp = i >> 6, ch = i & 63; s_w1[i] = a.w1[ch * 9 + tp]; }     // tap-major
+        if (tid < 64) s_b1[tid] = a.b1 ? a.b1[tid] : 0.f;
+    }
     // (these plain loads have retired -- their values went into the LDS stores -- before the first vmcnt wait below; the barrier of
     // step 0 publishes them)
     unsigned long long t_wait = 0, t_bar = 0, t_dma = 0, t_mma = 0, t_epi = 0, t0 = 0, rt0 = 0;
@@ -180,14 +196,69 @@ __global__ __launch_bounds__(NT) void conv3x3_pl_kernel(const PlArgs a) {
         const int lw8 = wv - NWAVE;
         int goff[IN_PER_WAVE];
         Tile t = tile_of(a, lw);
+        // ---- fused first layer (F1): the loaders COMPUTE the input planes of a step instead of fetching them -- relu(b1 + w1 * 3x3 window of
+        // the image), fp32 FMAs in the tap order of first_pl_kernel, the same encodings, written where the DMA would have put them: the
+        // result is bitwise that of first_pl + this kernel, xe11 never exists in HBM.  Lane = 3 of the tile's 612 positions (fixed per
+        // tile, their 27 image values stay in registers over the 4 chunks); only the 36 weight pieces of a step still come by DMA.
+        constexpr int F1_PX = (NPIX + NLOAD * 64 - 1) / (NLOAD * 64);           // 3
+        float pimg[F1 ? F1_PX : 1][9];
+        float f1_max = 0.f;                                                     // range flag of the computed (never stored) xe11 values
+        auto f1_window = [&](const Tile& tt) __attribute__((always_inline)) {
+            if constexpr (F1) {
+                const float* img = a.img + (size_t)tt.n * a.h * a.w;
+#pragma unroll
+                for (int k = 0; k < F1_PX; ++k) {
+                    const int idx = min(lw8 * 64 + lane + NLOAD * 64 * k, NPIX - 1);
+                    const int r = idx / IW, cc = idx - r * IW;
+                    const int yy = wsu_reflect(tt.y0 - 1 + r, a.h), xx = wsu_reflect(tt.x0 - 1 + cc, a.w);
+#pragma unroll
+                    for (int tp = 0; tp < 9; ++tp)
+                        pimg[k][tp] = img[(size_t)wsu_reflect(yy + tp / 3 - 1, a.h) * a.w + wsu_reflect(xx + tp % 3 - 1, a.w)];
+                }
+            }
+        };
+        auto f1_chunk = [&](int c, char* st) __attribute__((always_inline)) {
+            if constexpr (F1) {
+#pragma unroll
+                for (int k = 0; k < F1_PX; ++k) {
+                    const int idx = lw8 * 64 + lane + NLOAD * 64 * k;
+                    f32x4 v[4];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) v[g] = *reinterpret_cast<const f32x4*>(s_b1 + c * 16 + 4 * g);
+#pragma unroll
+                    for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const f32x4 w4 = *reinterpret_cast<const f32x4*>(s_w1 + tp * 64 + c * 16 + 4 * g);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[g][e] = fmaf(pimg[k][tp], w4[e], v[g][e]);
+                        }
+                    uint32_t h[8], lo[4], x8[4];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v[g][e] = fmaxf(v[g][e], 0.f); f1_max = fmaxf(f1_max, v[g][e]); }
+                        wsu_split4_f16f8(v[g], WSU_F8_XLO_DIV, WSU_F8_X_DIV, h[2 * g], h[2 * g + 1], lo[g], x8[g]);
+                    }
+                    if (idx < NPIX) {
+                        char* d = st + idx * 16;
+                        *reinterpret_cast<u32x4*>(d) = mk_u4(h[0], h[1], h[2], h[3]);
+                        *reinterpret_cast<u32x4*>(d + PLANE) = mk_u4(h[4], h[5], h[6], h[7]);
+                        *reinterpret_cast<u32x4*>(d + 2 * PLANE) = mk_u4(lo[0], lo[1], lo[2], lo[3]);
+                        *reinterpret_cast<u32x4*>(d + 3 * PLANE) = mk_u4(x8[0], x8[1], x8[2], x8[3]);
+                    }
+                }
+            }
+        };
         if (J > 0) {
-            plan_tile(a, t, lw8, lane, goff);
-            issue_dma(a, t.n, t.cb, 0, smem, lw8, lane, goff);
+            if constexpr (F1) f1_window(t); else plan_tile(a, t, lw8, lane, goff);
+            issue_dma<F1>(a, t.n, t.cb, 0, smem, lw8, lane, goff);
+            f1_chunk(0, smem);
         }
         int c = 0, kt = 0;
         for (int j = 0; j < J; ++j) {
             STAMP(s0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // this wave's pieces of step j have landed
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");        // this wave's pieces (and computed planes) of step j are in LDS
             STAMP(s1);
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
@@ -196,12 +267,16 @@ __global__ __launch_bounds__(NT) void conv3x3_pl_kernel(const PlArgs a) {
                 if (++c == a.nch) {
                     c = 0; ++kt;
                     t = tile_of(a, lw + kt * G);
-                    plan_tile(a, t, lw8, lane, goff);
+                    if constexpr (F1) f1_window(t); else plan_tile(a, t, lw8, lane, goff);
                 }
-                issue_dma(a, t.n, t.cb, c, smem + ((j + 1) & 1) * STAGE, lw8, lane, goff);
+                issue_dma<F1>(a, t.n, t.cb, c, smem + ((j + 1) & 1) * STAGE, lw8, lane, goff);
+                f1_chunk(c, smem + ((j + 1) & 1) * STAGE);
             }
             STAMP(s3);
             t_wait += s1 - s0; t_bar += s2 - s1; t_dma += s3 - s2;
+        }
+        if constexpr (F1) {
+            if (a.range_flag && __builtin_amdgcn_ballot_w64(!(f1_max <= WSU_F8_RANGE)) != 0 && lane == 0) atomicOr(a.range_flag, 1u);
         }
 #ifdef WSU_PL_STAMPS
         if (lane == 0 && wv == NWAVE && blockIdx.x < 128) {
@@ -444,6 +519,40 @@ _Pragma("unroll")
 #endif
 }
 
+// one place that knows the instantiations: attributes once, then the variant the arguments select
+int pl_launch(PlArgs a, bool first, hipStream_t s) {
+    static int ablate = -1;
+    if (ablate < 0) { const char* e = getenv("WSU_PL_ABLATE"); ablate = e ? atoi(e) : 0; }
+    a.ablate = ablate;
+    static int ncu = 0;
+    if (ncu == 0) {
+        int dev = 0; hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+            wsu_set_error("conv3x3_pl: cannot query the device"); return WSU_ERR_HIP;
+        }
+        const void* fns[7] = {reinterpret_cast<const void*>(&conv3x3_pl_kernel<0, false>), reinterpret_cast<const void*>(&conv3x3_pl_kernel<0, true>),
+                              reinterpret_cast<const void*>(&conv3x3_pl_kernel<1, false>), reinterpret_cast<const void*>(&conv3x3_pl_kernel<4, false>),
+                              reinterpret_cast<const void*>(&conv3x3_pl_kernel<0, false, false>),
+                              reinterpret_cast<const void*>(&conv3x3_pl_kernel<0, false, true, true>), reinterpret_cast<const void*>(&conv3x3_pl_kernel<0, true, true, true>)};
+        for (const void* fn : fns) {
+            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
+            if (e != hipSuccess) { wsu_set_error("hipFuncSetAttribute(conv3x3_pl): %s", hipGetErrorString(e)); return WSU_ERR_HIP; }
+        }
+        ncu = prop.multiProcessorCount;
+    }
+    const int grid = a.ntiles < ncu ? a.ntiles : ncu;
+    const dim3 g(grid), b(NT);
+    if (first) {
+        if (a.ypool) hipLaunchKernelGGL((conv3x3_pl_kernel<0, true, true, true>), g, b, LDS_TOTAL, s, a);
+        else hipLaunchKernelGGL((conv3x3_pl_kernel<0, false, true, true>), g, b, LDS_TOTAL, s, a);
+    } else if (a.head_w && a.head_cout == 1) hipLaunchKernelGGL((conv3x3_pl_kernel<1, false>), g, b, LDS_TOTAL, s, a);
+    else if (a.head_w) hipLaunchKernelGGL((conv3x3_pl_kernel<4, false>), g, b, LDS_TOTAL, s, a);
+    else if (a.ypool) hipLaunchKernelGGL((conv3x3_pl_kernel<0, true>), g, b, LDS_TOTAL, s, a);
+    else if (!a.xres) hipLaunchKernelGGL((conv3x3_pl_kernel<0, false, false>), g, b, LDS_TOTAL, s, a);
+    else hipLaunchKernelGGL((conv3x3_pl_kernel<0, false>), g, b, LDS_TOTAL, s, a);
+    return wsu_check_launch("conv3x3_pl_kernel");
+}
+
 }  // namespace
 
 extern "C" {
@@ -482,32 +591,33 @@ int wsu_conv3x3_pl_fwd(const void* x1, const void* x2, const void* w_packed, con
     const long long nt = (long long)n * a.tiles_x * a.tiles_y * a.ncb;
     WSU_REQUIRE(nt > 0 && nt < 0x3FFFFFFFLL, "conv3x3_pl: %lld tiles out of range", nt);
     a.ntiles = (int)nt;
-    static int ablate = -1;
-    if (ablate < 0) { const char* e = getenv("WSU_PL_ABLATE"); ablate = e ? atoi(e) : 0; }
-    a.ablate = ablate;
-    static int ncu = 0;
-    if (ncu == 0) {
-        int dev = 0; hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
-            wsu_set_error("conv3x3_pl: cannot query the device"); return WSU_ERR_HIP;
-        }
-        const void* fns[5] = {reinterpret_cast<const void*>(&conv3x3_pl_kernel<0, false>), reinterpret_cast<const void*>(&conv3x3_pl_kernel<0, true>),
-                              reinterpret_cast<const void*>(&conv3x3_pl_kernel<1, false>), reinterpret_cast<const void*>(&conv3x3_pl_kernel<4, false>),
-                              reinterpret_cast<const void*>(&conv3x3_pl_kernel<0, false, false>)};
-        for (const void* fn : fns) {
-            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
-            if (e != hipSuccess) { wsu_set_error("hipFuncSetAttribute(conv3x3_pl): %s", hipGetErrorString(e)); return WSU_ERR_HIP; }
-        }
-        ncu = prop.multiProcessorCount;
-    }
-    const int grid = (int)(nt < ncu ? nt : ncu);
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    if (head_w && head_cout == 1) hipLaunchKernelGGL((conv3x3_pl_kernel<1, false>), dim3(grid), dim3(NT), LDS_TOTAL, s, a);
-    else if (head_w) hipLaunchKernelGGL((conv3x3_pl_kernel<4, false>), dim3(grid), dim3(NT), LDS_TOTAL, s, a);
-    else if (y_pool) hipLaunchKernelGGL((conv3x3_pl_kernel<0, true>), dim3(grid), dim3(NT), LDS_TOTAL, s, a);
-    else if (!x_residual) hipLaunchKernelGGL((conv3x3_pl_kernel<0, false, false>), dim3(grid), dim3(NT), LDS_TOTAL, s, a);
-    else hipLaunchKernelGGL((conv3x3_pl_kernel<0, false>), dim3(grid), dim3(NT), LDS_TOTAL, s, a);
-    return wsu_check_launch("conv3x3_pl_kernel");
+    a.img = nullptr; a.w1 = nullptr; a.b1 = nullptr;
+    return pl_launch(a, false, static_cast<hipStream_t>(stream));
+}
+
+// e11 + e12 (+pool) of the planar path in one launch (unet.py:141-144, single-plane inputs): img (N,1,H,W) fp32, w1 (64,1,3,3), b1 (64) or NULL;
+// the loader waves compute the 64 input channels of the 3x3 conv into the LDS stages (kernel variant F1), xe11 never reaches HBM.  Bitwise the
+// result of wsu_conv3x3_first_pl_fwd followed by wsu_conv3x3_pl_fwd.  w_packed / bias: the second conv (cin = 64); y / y_pool as there.
+int wsu_conv3x3_pl_fused_first_fwd(const float* img, const float* w1, const float* b1, const void* w_packed, const float* bias,
+                                   void* y, void* y_pool, int n, int h, int w, int cout, int relu, unsigned* range_flag, void* stream) {
+    WSU_REQUIRE(img && w1 && w_packed && (y || y_pool), "conv3x3_pl_fused_first: null pointer");
+    WSU_REQUIRE(n > 0 && h >= 2 && w >= 2, "conv3x3_pl_fused_first: bad shape n=%d h=%d w=%d (reflect pad 1 needs h,w >= 2)", n, h, w);
+    WSU_REQUIRE(cout > 0 && cout % WSU_COB == 0 && cout <= 1024, "conv3x3_pl_fused_first: cout=%d must be a multiple of %d (<= 1024)", cout, WSU_COB);
+    WSU_REQUIRE(!y_pool || (h % 2 == 0 && w % 2 == 0), "conv3x3_pl_fused_first: fused pool needs even h, w");
+    WSU_REQUIRE((long long)h * w * 4 < 0x7FFFFFFFLL, "conv3x3_pl_fused_first: h*w too large");
+    PlArgs a;
+    a.x1 = nullptr; a.x2 = nullptr; a.wp = (const char*)w_packed; a.bias = bias;
+    a.y = (char*)y; a.ypool = (char*)y_pool;
+    a.head_w = nullptr; a.head_b = nullptr; a.head_out = nullptr; a.head_logit = nullptr; a.head_cout = 0;
+    a.range_flag = range_flag; a.xres = 1;
+    a.img = img; a.w1 = w1; a.b1 = b1;
+    a.n = n; a.h = h; a.w = w; a.c1 = 64; a.c2 = 0; a.cout = cout;
+    a.tiles_x = (w + TW - 1) / TW; a.tiles_y = (h + TH - 1) / TH; a.ncb = cout / WSU_COB;
+    a.nch1 = 4; a.nch = 4; a.relu = relu;
+    const long long nt = (long long)n * a.tiles_x * a.tiles_y * a.ncb;
+    WSU_REQUIRE(nt > 0 && nt < 0x3FFFFFFFLL, "conv3x3_pl_fused_first: %lld tiles out of range", nt);
+    a.ntiles = (int)nt;
+    return pl_launch(a, true, static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

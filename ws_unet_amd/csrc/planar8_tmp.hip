@@ -1,0 +1,333 @@
+// The remaining kernels of the planar (F16F8P) inference path, next to the 3x3 conv of conv3x3_pl.hip:
+//   K3p  convt2x2_pl_kernel   nn.ConvTranspose2d(k=2, s=2) + bias (src/unet/model/unet.py:125,130,177,183) on planar activations, with the
+//                              machinery of conv3x3_pl: one persistent workgroup per CU, loader waves feeding two LDS stages by LDS-DMA,
+//                              matrix waves that only multiply, results from the accumulators straight to planar global memory
+//   K0p  first_pl_kernel       the first layer e11 (unet.py:82,141): 1..8 input planes (NCHW fp32, the model input) -> planar 16 k channels
+// Storage format and arithmetic: include/wsu.h (F16F8P), wsu_device.h.
+#include "wsu_device.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void glb_void;
+
+__device__ __forceinline__ void swap32(uint32_t& upper_of, uint32_t& lower_of) {
+    const auto r = __builtin_amdgcn_permlane32_swap(upper_of, lower_of, false, false);   // lanes 32-63 of the first <-> lanes 0-31 of the second
+    upper_of = r[0]; lower_of = r[1];
+}
+
+// X, Y = 4 + 4 values of one pixel (channels c0 + 4 hh .. and c0 + 8 + 4 hh ..; hh = lane >> 5): encode, gather whole 16-byte granules into
+// single lanes (conv3x3_pl.hip) and store the chunk's four planes: every instruction writes contiguous runs of 32 lanes x 16 B.
+__device__ __forceinline__ void store_chunk_px(const f32x4& X, const f32x4& Y, char* dst, size_t plane_bytes, int hh, bool ok) {
+    uint32_t xh0, xh1, xlo, xx8, yh0, yh1, ylo, yx8;
+    wsu_split4_f16f8(X, WSU_F8_XLO_DIV, WSU_F8_X_DIV, xh0, xh1, xlo, xx8);
+    wsu_split4_f16f8(Y, WSU_F8_XLO_DIV, WSU_F8_X_DIV, yh0, yh1, ylo, yx8);
+    swap32(xh0, yh0); swap32(xh1, yh1);
+    swap32(xlo, xx8); swap32(ylo, yx8);
+    if (ok) {
+        *reinterpret_cast<u32x4*>(dst + hh * plane_bytes) = mk_u4(xh0, xh1, yh0, yh1);
+        *reinterpret_cast<u32x4*>(dst + (2 + hh) * plane_bytes) = mk_u4(xlo, xx8, ylo, yx8);
+    }
+}
+
+// =====================================================================================================================================
+// K3p.  y[n, 2i+a, 2j+b, co] = bias[co] + sum_ci x[n, i, j, ci] * w[ci, co, a, b]: four 1-tap GEMMs that share their B operand.
+// Tile = 4 x 32 INPUT pixels x 64 co x 4 sub-positions.  Matrix wave w: output-row parity a = w & 1, input rows 2 (w>>1 & 1) + {0, 1}, output
+// channels 32 (w >> 2) + 0..31, BOTH column parities b: its lane l31 holds the output pixels 2 (x0 + l31) and 2 (x0 + l31) + 1, i.e. 32
+// contiguous bytes per plane -- the accumulators go straight to planar global memory (two 16-byte stores side by side).
+// A step = 2 chunks of 16 input channels (the fp8 instruction pairs two chunks: a sub-position has one tap); stage = 2 x (input 4 planes x
+// 128 px x 16 B + weights [4 sub-positions][4 planes][64 co][16 B]) = 48 KB, two stages; 48 DMA pieces per step over 4 loader waves.
+// =====================================================================================================================================
+namespace ct {
+constexpr int TW = 32, TH = 4, NPIX = TW * TH;            // 128 input pixels
+constexpr int PLANE = NPIX * 16;                          // 2048
+constexpr int IN1 = WSU_GRAN * PLANE;                     // 8192 per chunk
+constexpr int W1 = 4 * WSU_GRAN * WSU_COB * 16;           // 16384 per chunk (layout of wsu_convt2x2_pack, mode F16F8)
+constexpr int CHUNK = IN1 + W1;                           // 24576
+constexpr int STAGE = 2 * CHUNK;                          // 49152
+constexpr int LDS_EXTRA = 2 * STAGE;                      // bias [1024]
+constexpr int LDS_TOTAL = LDS_EXTRA + 1024 * 4;
+constexpr int NWAVE = 8, NLOAD = 8, NT = (NWAVE + NLOAD) * 64;
+constexpr int IN_SLOTS = 2 * WSU_GRAN * 2;                // 2 chunks x 4 planes x 2 segments of 64 pixels = 16
+constexpr int W_SLOTS = 2 * W1 / 1024;                    // 32
+constexpr int IN_PER = IN_SLOTS / NLOAD, W_PER = W_SLOTS / NLOAD;   // 4, 8
+}
+
+struct CtpArgs {
+    const char* x; const char* wp; const float* bias; char* y; unsigned* range_flag;
+    int n, h, w, cin, cout;
+    int tiles_x, tiles_y, ncb, nst;                       // nst = steps per tile = cin / 32
+    int ntiles;
+};
+
+struct CtTile { int n, y0, x0, cb; };
+__device__ __forceinline__ CtTile ct_tile_of(const CtpArgs& a, int t) {
+    CtTile r;
+    r.cb = t % a.ncb; t /= a.ncb;
+    const int tx = t % a.tiles_x; t /= a.tiles_x;
+    const int ty = t % a.tiles_y;
+    r.n = t / a.tiles_y; r.y0 = ty * ct::TH; r.x0 = tx * ct::TW;
+    return r;
+}
+
+__device__ __forceinline__ void ct_issue_dma(const CtpArgs& a, const CtTile& t, int step, char* st, int lw8, int lane) {
+    using namespace ct;
+    const size_t hw = (size_t)a.h * a.w;
+    const int nch = a.cin >> 4;
+    // input: slot = lw8 + 4 k -> (chunk-in-step, plane, segment); lane -> pixel of the tile (clamped: out-of-image lanes are never stored)
+#pragma unroll
+    for (int k = 0; k < IN_PER; ++k) {
+        const int slot = lw8 + NLOAD * k;
+        const int ck = slot >> 3, plane = (slot >> 1) & 3, seg = slot & 1;
+        const int pix = seg * 64 + lane;
+        const int yy = min(t.y0 + pix / TW, a.h - 1), xx = min(t.x0 + pix % TW, a.w - 1);
+        const char* src = a.x + ((((size_t)t.n * nch + 2 * step + ck) * 4 + plane) * hw + (size_t)yy * a.w + xx) * 16;
+        __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(st + ck * CHUNK + plane * PLANE + seg * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int k = 0; k < W_PER; ++k) {
+        const int slot = lw8 + NLOAD * k;
+        const int ck = slot >> 4, piece = slot & 15;
+        const char* src = a.wp + ((size_t)t.cb * nch + 2 * step + ck) * W1 + piece * 1024 + lane * 16;
+        __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(st + ck * CHUNK + IN1 + piece * 1024), 16, 0, 0);
+    }
+}
+
+__global__ __launch_bounds__(ct::NT) void convt2x2_pl_kernel(const CtpArgs a) {
+    using namespace ct;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+    const int G = gridDim.x;
+    const int lw = (int)wsu_xcd_remap(blockIdx.x, G);
+    const int K = a.ntiles > lw ? (a.ntiles - lw + G - 1) / G : 0;
+    const int J = K * a.nst;
+    float* s_bias = reinterpret_cast<float*>(smem + LDS_EXTRA);
+    for (int i = tid; i < a.cout; i += NT) s_bias[i] = a.bias ? a.bias[i] : 0.f;
+
+    if (wv >= NWAVE) {
+        // ---- loader waves ----------------------------------------------------------------------------------------------------------
+        const int lw8 = wv - NWAVE;
+        CtTile t = ct_tile_of(a, lw);
+        if (J > 0) ct_issue_dma(a, t, 0, smem, lw8, lane);
+        int c = 0, kt = 0;
+        for (int j = 0; j < J; ++j) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (j + 1 < J) {
+                if (++c == a.nst) { c = 0; ++kt; t = ct_tile_of(a, lw + kt * G); }
+                ct_issue_dma(a, t, c, smem + ((j + 1) & 1) * STAGE, lw8, lane);
+            }
+        }
+        return;
+    }
+
+    // ---- matrix waves --------------------------------------------------------------------------------------------------------------
+    const int pa = wv & 1, half = (wv >> 1) & 1, mh = wv >> 2;
+    CtTile cur = ct_tile_of(a, lw);
+    f32x16 acc[2][2];                                                   // [b][q]
+    const int sc_a = hh ? WSU_F8_SCALE_WLO : WSU_F8_SCALE_W, sc_b = hh ? WSU_F8_SCALE_X : WSU_F8_SCALE_XLO;
+    int c = 0, kt = 0;
+    for (int j = 0; j < J; ++j) {
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const char* st = smem + (j & 1) * STAGE;
+        if (c == 0) {
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[b][q][r] = 0.f;
+        }
+        // A: st + ck*CHUNK + IN1 + (((2 pa + b) * 4 + g) * 64 + mh*32 + l31) * 16;  B: st + ck*CHUNK + g*PLANE + ((2 half + q) * 32 + l31) * 16
+        const char* ldsA = st + IN1 + ((2 * pa * 4) * 64 + mh * 32 + l31) * 16;
+        const char* ldsB = st + ((2 * half) * TW + l31) * 16;
+        u32x4 a0[2], a1[2], b0[2], b1[2];                              // fp8 operands: this lane half's chunk of the pair
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            a0[b] = *reinterpret_cast<const u32x4*>(ldsA + hh * CHUNK + ((b * 4 + 2) * 64) * 16);
+            a1[b] = *reinterpret_cast<const u32x4*>(ldsA + hh * CHUNK + ((b * 4 + 3) * 64) * 16);
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            b0[q] = *reinterpret_cast<const u32x4*>(ldsB + hh * CHUNK + 2 * PLANE + q * TW * 16);
+            b1[q] = *reinterpret_cast<const u32x4*>(ldsB + hh * CHUNK + 3 * PLANE + q * TW * 16);
+        }
+#pragma unroll
+        for (int ck = 0; ck < 2; ++ck) {
+            u32x4 ah[2], bh[2];
+#pragma unroll
+            for (int b = 0; b < 2; ++b) ah[b] = *reinterpret_cast<const u32x4*>(ldsA + ck * CHUNK + ((b * 4 + hh) * 64) * 16);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) bh[q] = *reinterpret_cast<const u32x4*>(ldsB + ck * CHUNK + hh * PLANE + q * TW * 16);
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) wsu_mfma_f16(ah[b], bh[q], acc[b][q]);
+        }
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) wsu_mfma_f8x2(a0[b], a1[b], b0[q], b1[q], sc_a, sc_b, acc[b][q]);
+
+        if (c + 1 == a.nst) {
+            // ---- epilogue: this lane's pixels 2 (x0 + l31) + b of output rows 2 (y0 + 2 half + q) + pa, channels cb*64 + mh*32 + ... --------
+            const int oh = 2 * a.h, ow = 2 * a.w;
+            const size_t ohw = (size_t)oh * ow;
+            const int nco = a.cout >> 4;
+            const int icol = cur.x0 + l31;
+            float vmax = 0.f;
+#pragma unroll
+            for (int cp = 0; cp < 2; ++cp) {
+                const int oc = cur.cb * 4 + mh * 2 + cp;
+                const int co0 = oc * 16 + 4 * hh;
+                const f32x4 bx = *reinterpret_cast<const f32x4*>(s_bias + co0), by = *reinterpret_cast<const f32x4*>(s_bias + co0 + 8);
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int irow = cur.y0 + 2 * half + q;
+                    const bool ok = irow < a.h && icol < a.w;
+                    char* dst = a.y + ((((size_t)cur.n * nco + oc) * 4) * ohw + (size_t)(2 * irow + pa) * ow + 2 * icol) * 16;
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        f32x4 X, Y;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            X[e] = acc[b][q][8 * cp + e] + bx[e]; Y[e] = acc[b][q][8 * cp + 4 + e] + by[e];
+                            vmax = fmaxf(vmax, fmaxf(fabsf(X[e]), fabsf(Y[e])));
+                        }
+                        store_chunk_px(X, Y, dst + b * 16, ohw * 16, hh, ok);
+                    }
+                }
+            }
+            if (a.range_flag && __builtin_amdgcn_ballot_w64(!(vmax <= WSU_F8_RANGE)) != 0 && lane == 0) atomicOr(a.range_flag, 1u);
+            ++kt; c = 0;
+            if (j + 1 < J) cur = ct_tile_of(a, lw + kt * G);
+        } else {
+            ++c;
+        }
+    }
+}
+
+// =====================================================================================================================================
+// K0p.  First layer: y = relu(conv3x3_reflect(x) + b), x (N, cin <= 8, H, W) fp32 NCHW, y planar with cout = 16 k channels.  One thread per
+// pixel (consecutive lanes = consecutive pixels of a row: every store instruction writes 64 x 16 contiguous bytes), 16 output channels at a
+// time from tap-major weights in LDS; fp32 FMAs in the tap order of conv3x3_first_kernel (pointwise.hip), so the values before encoding are
+// bitwise those of the NHWC first-layer kernel.  HBM-write bound: 4 bytes per output element.
+// =====================================================================================================================================
+struct FirstPlArgs { const float* x; const float* w; const float* b; char* y; unsigned* range_flag; int n, h, w_, cin, cout, relu; };
+
+__global__ __launch_bounds__(256) void first_pl_kernel(const FirstPlArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* wl = reinterpret_cast<float*>(smem);                         // [ci][tap][cout]
+    float* bl = wl + a.cin * 9 * a.cout;
+    for (int i = threadIdx.x; i < a.cin * 9 * a.cout; i += blockDim.x) {
+        const int co = i % a.cout, tap = (i / a.cout) % 9, ci = i / (9 * a.cout);
+        wl[i] = a.w[((size_t)co * a.cin + ci) * 9 + tap];
+    }
+    for (int i = threadIdx.x; i < a.cout; i += blockDim.x) bl[i] = a.b ? a.b[i] : 0.f;
+    __syncthreads();
+    const size_t hw = (size_t)a.h * a.w_;
+    const long long total = (long long)a.n * hw;
+    const int nco = a.cout >> 4;
+    float vmax = 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % a.w_); long long t = i / a.w_;
+        const int y = (int)(t % a.h); const int img = (int)(t / a.h);
+        float p[8][9];
+#pragma unroll
+        for (int ci = 0; ci < 8; ++ci)
+            if (ci < a.cin) {
+                const float* src = a.x + ((size_t)img * a.cin + ci) * hw;
+#pragma unroll
+                for (int tp = 0; tp < 9; ++tp)
+                    p[ci][tp] = src[(size_t)wsu_reflect(y + tp / 3 - 1, a.h) * a.w_ + wsu_reflect(x + tp % 3 - 1, a.w_)];
+            }
+        for (int oc = 0; oc < nco; ++oc) {
+            f32x4 v[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) v[g] = *reinterpret_cast<const f32x4*>(bl + oc * 16 + 4 * g);
+#pragma unroll
+            for (int ci = 0; ci < 8; ++ci)
+                if (ci < a.cin)
+#pragma unroll
+                    for (int tp = 0; tp < 9; ++tp) {
+                        const float* wr = wl + (ci * 9 + tp) * a.cout + oc * 16;
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const f32x4 w4 = *reinterpret_cast<const f32x4*>(wr + 4 * g);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[g][e] = fmaf(p[ci][tp], w4[e], v[g][e]);
+                        }
+                    }
+            uint32_t h[8], lo[4], x8[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (a.relu) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[g][e] = fmaxf(v[g][e], 0.f);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) vmax = fmaxf(vmax, fabsf(v[g][e]));
+                wsu_split4_f16f8(v[g], WSU_F8_XLO_DIV, WSU_F8_X_DIV, h[2 * g], h[2 * g + 1], lo[g], x8[g]);
+            }
+            char* dst = a.y + ((((size_t)img * nco + oc) * 4) * hw + (size_t)y * a.w_ + x) * 16;
+            *reinterpret_cast<u32x4*>(dst) = mk_u4(h[0], h[1], h[2], h[3]);
+            *reinterpret_cast<u32x4*>(dst + hw * 16) = mk_u4(h[4], h[5], h[6], h[7]);
+            *reinterpret_cast<u32x4*>(dst + 2 * hw * 16) = mk_u4(lo[0], lo[1], lo[2], lo[3]);
+            *reinterpret_cast<u32x4*>(dst + 3 * hw * 16) = mk_u4(x8[0], x8[1], x8[2], x8[3]);
+        }
+    }
+    if (a.range_flag && !(vmax <= WSU_F8_RANGE)) atomicOr(a.range_flag, 1u);      // rare: at most one atomic per lane
+}
+
+}  // namespace
+
+extern "C" {
+
+// K3p: transposed 2x2 stride-2 conv + bias on planar F16F8P activations.  x: cin channels at (h, w); y: cout channels at (2h, 2w); weights from
+// wsu_convt2x2_pack(mode F16F8).  cin a multiple of 32, cout of 64.
+int wsu_convt2x2_pl_fwd(const void* x, const void* w_packed, const float* bias, void* y, int n, int h, int w, int cin, int cout,
+                        unsigned* range_flag, void* stream) {
+    WSU_REQUIRE(x && w_packed && y, "convt2x2_pl: null pointer");
+    WSU_REQUIRE(n > 0 && h > 0 && w > 0, "convt2x2_pl: bad shape n=%d h=%d w=%d", n, h, w);
+    WSU_REQUIRE(cin > 0 && cin % 32 == 0, "convt2x2_pl: cin=%d must be a multiple of 32", cin);
+    WSU_REQUIRE(cout > 0 && cout % WSU_COB == 0 && cout <= 1024, "convt2x2_pl: cout=%d must be a multiple of %d (<= 1024)", cout, WSU_COB);
+    WSU_REQUIRE((long long)h * w * 16 < 0x7FFFFFFFLL, "convt2x2_pl: h*w too large");
+    CtpArgs a;
+    a.x = (const char*)x; a.wp = (const char*)w_packed; a.bias = bias; a.y = (char*)y; a.range_flag = range_flag;
+    a.n = n; a.h = h; a.w = w; a.cin = cin; a.cout = cout;
+    a.tiles_x = (w + ct::TW - 1) / ct::TW; a.tiles_y = (h + ct::TH - 1) / ct::TH; a.ncb = cout / WSU_COB; a.nst = cin / 32;
+    const long long nt = (long long)n * a.tiles_x * a.tiles_y * a.ncb;
+    WSU_REQUIRE(nt > 0 && nt < 0x3FFFFFFFLL, "convt2x2_pl: %lld tiles out of range", nt);
+    a.ntiles = (int)nt;
+    static int ncu = 0;
+    if (ncu == 0) {
+        int dev = 0; hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+            wsu_set_error("convt2x2_pl: cannot query the device"); return WSU_ERR_HIP;
+        }
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&convt2x2_pl_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, ct::LDS_TOTAL);
+        if (e != hipSuccess) { wsu_set_error("hipFuncSetAttribute(convt2x2_pl): %s", hipGetErrorString(e)); return WSU_ERR_HIP; }
+        ncu = prop.multiProcessorCount;
+    }
+    const int grid = (int)(nt < ncu ? nt : ncu);
+    hipLaunchKernelGGL(convt2x2_pl_kernel, dim3(grid), dim3(ct::NT), ct::LDS_TOTAL, static_cast<hipStream_t>(stream), a);
+    return wsu_check_launch("convt2x2_pl_kernel");
+}
+
+// K0p: first layer into planar storage.  x_nchw: (N, cin, H, W) fp32, cin 1..8; w_oihw: (cout, cin, 3, 3); cout a multiple of 16 (<= 128).
+int wsu_conv3x3_first_pl_fwd(const float* x_nchw, const float* w_oihw, const float* bias, void* y, int n, int h, int w, int cin, int cout,
+                             int relu, unsigned* range_flag, void* stream) {
+    WSU_REQUIRE(x_nchw && w_oihw && y, "conv3x3_first_pl: null pointer");
+    WSU_REQUIRE(n > 0 && h >= 2 && w >= 2 && cin >= 1 && cin <= 8 && cout > 0 && cout % 16 == 0 && cout <= 128, "conv3x3_first_pl: bad shape");
+    FirstPlArgs a{x_nchw, w_oihw, bias, (char*)y, range_flag, n, h, w, cin, cout, relu};
+    const long long total = (long long)n * h * w;
+    const unsigned nblk = (unsigned)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    const size_t lds = ((size_t)cin * 9 * cout + cout) * sizeof(float);
+    hipLaunchKernelGGL(first_pl_kernel, dim3(nblk), dim3(256), lds, static_cast<hipStream_t>(stream), a);
+    return wsu_check_launch("first_pl_kernel");
+}
+
+}  // extern "C"

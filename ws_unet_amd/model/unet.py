@@ -88,6 +88,9 @@ class UNet(nn.Module):
         self.mode = mode or os.environ.get("WSU_MODE", "f16f8p")
         self.fuse_head = os.environ.get("WSU_FUSE_HEAD", "1") != "0"  # fold outconv + sigmoid into the last 3x3 conv
         self.fuse_first = os.environ.get("WSU_FUSE_FIRST", "1") != "0"  # fold e11 into e12's input staging
+        # planar path: e11 computed by the loader waves of e12's kernel (wsu_conv3x3_pl_fused_first_fwd).  Off by default: xe11 never
+        # reaches HBM (-2.1 GB at batch 32) but the loaders' VALU work makes them the critical path -- e11 + e12 1.82 -> 1.60 ms, +0.8 % images/s
+        self.fuse_first_planar = os.environ.get("WSU_FUSE_FIRST_PL", "0") != "0"
         # arithmetic of the autograd path: exact fp32 MFMA for an 'f32' model, split-bf16 (fp32 storage and accumulation,
         # ~2^-16 relative per product -- finer than the TF32 convs PyTorch trains with by default on the reference's GPUs) otherwise
         self.train_mode = os.environ.get("WSU_TRAIN_MODE") or ("f32" if self.mode == "f32" else "bf16x3")
@@ -285,11 +288,22 @@ class UNet(nn.Module):
         tag = ops.set_layer
         e11 = self.e11
         rf = self._range_flag_tensor(x.device)
-        tag("e11")
-        cur = ops.conv3x3_first_pl(x, e11.weight, e11.bias.detach(), range_flag=rf)
+        # e11 is folded into e12 (its 64 channels are computed by the loader waves of the persistent kernel) for single-plane inputs
+        fuse_first = self.fuse_first_planar and e11.in_channels == 1 and e11.out_channels == 64 and self.nsteps >= 1
+        cur = None
+        if not fuse_first:
+            tag("e11")
+            cur = ops.conv3x3_first_pl(x, e11.weight, e11.bias.detach(), range_flag=rf)
         skips: List[torch.Tensor] = []
         for lvl in range(self.nsteps + 1):
             a, b = ENC[lvl]
+            if lvl == 0 and fuse_first:
+                lb = self.e12
+                tag("e11+e12")
+                full, cur = ops.conv3x3_pl_fused_first(x, e11.weight, e11.bias.detach(), self._packed("e12", W, "conv"), lb.bias.detach(),
+                                                       lb.out_channels, pool=True, range_flag=rf)
+                skips.append(full)
+                continue
             if lvl >= 1:
                 la = getattr(self, a)
                 tag(a)

@@ -286,6 +286,25 @@ def conv3x3_pl(x1: torch.Tensor, x2: Optional[torch.Tensor], w_packed: torch.Ten
     return (y, yp) if pool else y
 
 
+def conv3x3_pl_fused_first(x_nchw: torch.Tensor, w1: torch.Tensor, b1: Optional[torch.Tensor], w_packed: torch.Tensor,
+                           bias: Optional[torch.Tensor], cout: int, relu: bool = True, pool: bool = False,
+                           range_flag: Optional[torch.Tensor] = None):
+    """e11 + e12 (+pool) of the planar path in one launch (wsu_conv3x3_pl_fused_first_fwd): x_nchw (N,1,H,W) fp32 -> y planar [, y_pool]."""
+    lib = _lib.load()
+    w1 = w1.detach().contiguous()
+    _dev_check(x_nchw, w1, b1, w_packed, bias)
+    n, cin, h, w = x_nchw.shape
+    assert cin == 1 and tuple(w1.shape) == (64, 1, 3, 3) and x_nchw.dtype == torch.float32 and x_nchw.is_contiguous()
+    y = torch.empty(planar_shape(n, cout, h, w), dtype=torch.float32, device=x_nchw.device)
+    yp = torch.empty(planar_shape(n, cout, h // 2, w // 2), dtype=torch.float32, device=x_nchw.device) if pool else None
+    meta = {"flops": 2.0 * 9 * 64 * cout * n * h * w,
+            "bytes": float(n * h * w * (4 + cout * 4) + (n * (h // 2) * (w // 2) * cout * 4 if pool else 0) + 9 * 64 * cout * 4)}
+    check(_launch("conv3x3_pl", meta, lambda: lib.wsu_conv3x3_pl_fused_first_fwd(
+        x_nchw.data_ptr(), w1.data_ptr(), _ptr(b1), w_packed.data_ptr(), _ptr(bias), y.data_ptr(), _ptr(yp),
+        n, h, w, cout, int(relu), _ptr(range_flag), _stream())), "wsu_conv3x3_pl_fused_first_fwd")
+    return (y, yp) if pool else y
+
+
 def convt2x2_pl(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor], cout: int,
                 range_flag: Optional[torch.Tensor] = None) -> torch.Tensor:
     """nn.ConvTranspose2d(k=2, s=2) + bias on planar F16F8P activations (wsu_convt2x2_pl_fwd); w_packed from pack_convt2x2(mode f16f8)."""
