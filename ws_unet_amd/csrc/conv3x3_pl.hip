@@ -289,6 +289,9 @@ __global__ __launch_bounds__(NT) void conv3x3_pl_kernel(const PlArgs a) {
     }
 
     // ================= matrix waves ===================================================================================================
+#ifdef WSU_PL_MATRIX_PRIO
+    __builtin_amdgcn_s_setprio(WSU_PL_MATRIX_PRIO);                           // experiment: matrix waves above the loader wave of their SIMD
+#endif
     Tile cur = tile_of(a, lw);
     f32x16 acc[2][2];
     const int sc_a = hh ? WSU_F8_SCALE_WLO : WSU_F8_SCALE_W, sc_b = hh ? WSU_F8_SCALE_X : WSU_F8_SCALE_XLO;
