@@ -119,10 +119,10 @@ int wsu_conv3x3_wino_fwd(const void* x1, const void* x2, const void* w_packed, c
                          int n, int h, int w, int c1, int c2, int cout, int relu, void* stream);
 
 /* ---- K1p: the same forward conv in the f16f8 arithmetic on PLANAR activations ("F16F8P" storage, forward inference only): a tensor of C
- *      channels is [n][C/16 chunks][4 planes][H][W][16 B] with, per pixel and 16-channel chunk, plane 0 = f16 ch 0-7, plane 1 = f16 ch
- *      8-15, plane 2 = e4m3((x - f16 x) * 2^12) ch 0-15, plane 3 = e4m3(x / 4) ch 0-15 (4 bytes per element).  The planes are the LDS
- *      image of the matrix kernel, so staging is a pure LDS-DMA (global_load_lds) and a persistent workgroup per CU pipelines it across
- *      chunks and tiles (csrc/conv3x3_pl.hip).  Weights from wsu_conv3x3_pack(mode F16F8).  Outputs, each optional: y (planar),
+ *      channels is [n][C/16 chunks][3 planes][H][W][16 B] with, per pixel and 16-channel chunk, plane 0 = f16 ch 0-7, plane 1 = f16 ch
+ *      8-15, plane 2 = e4m3((x - f16 x) * 2^12) ch 0-15 (3 bytes per element).  The planes are three of the four LDS planes of the matrix
+ *      kernel (the fourth, e4m3(x / 4), is derived from the f16 planes by the loader wave that fetched them), so staging is a pure LDS-DMA
+ *      (global_load_lds) and a persistent workgroup per CU pipelines it across chunks and tiles (csrc/conv3x3_pl.hip).  Weights from wsu_conv3x3_pack(mode F16F8).  Outputs, each optional: y (planar),
  *      y_pool (2x2 max-pooled, planar), head (1x1 conv + sigmoid on cout == 64 channels; out / logit NCHW fp32).  range_flag (optional
  *      device word, all three planar entry points): bit 0 is OR-ed in when a stored activation exceeds +-448, where the e4m3 residual
  *      saturates and that value keeps only f16 accuracy (NaN / Inf set it too) -- the caller's signal to switch to BF16X3S.

@@ -5,7 +5,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from gpu_util import DEV, rand_act, planar_encode, planar_decode, planar_x8
+from gpu_util import DEV, rand_act, planar_encode, planar_decode
 from ws_unet_amd import formula, ops
 from oracle import unet_ref
 
@@ -39,9 +39,6 @@ def test_conv3x3_pl_matches_oracle(shape):
     scale = ref.abs().max().item()
     got = planar_decode(y)
     assert (got - ref).abs().max().item() <= 1e-4 * scale, (got - ref).abs().max().item() / scale
-    # the e4m3 copy plane carries e4m3(y / 4): 3 mantissa bits -> within 2^-4 relative (or the e4m3 subnormal step) of the value
-    x8 = planar_x8(y)
-    assert ((x8 - ref).abs() <= ref.abs() / 16 + 4 * 2.0 ** -9 + 1e-4 * scale).all()
     if even:
         refp = F.max_pool2d(ref, 2, 2)
         gotp = planar_decode(yp)

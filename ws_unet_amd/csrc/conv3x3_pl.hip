@@ -5,8 +5,9 @@
 // the part `a` that does not overlap the matrix pipe (register staging: global loads at 48 used bytes per 192..768-byte pixel stride, the
 // ds_write commit with its fp8 derivation, two barriers per chunk, the LDS round trip of the epilogue, an exposed prologue per tile) is
 // 45-50 % of every layer.  Here none of that work exists:
-//   * activations are stored planar, [n][C/16 chunks][4 planes][H][W][16 B] (planes: f16 ch 0-7 | f16 ch 8-15 | e4m3 residuals ch 0-15 |
-//     e4m3 copies ch 0-15 = exactly the four LDS planes of a chunk), so an input-tile row is one contiguous 544-byte run per plane and
+//   * activations are stored planar, [n][C/16 chunks][3 planes][H][W][16 B] (planes: f16 ch 0-7 | f16 ch 8-15 | e4m3 residuals ch 0-15 =
+//     three of the four LDS planes of a chunk; the fourth, the e4m3 copies e4m3(x / 4), is derived from the f16 planes by the loader that
+//     fetched them), so an input-tile row is one contiguous 544-byte run per plane and
 //     `global_load_lds_dwordx4` moves it into the granule-planar LDS image with no registers, no VALU and no ds_write;
 //   * two LDS stages (input tile 18 x 34 pixels x 64 B + the 36 KB weight slice = 76 KB each): the DMA of chunk c+1 -- or of the NEXT
 //     tile's first chunk -- is in flight while chunk c is multiplied; ONE raw s_barrier per chunk;
@@ -33,16 +34,17 @@ constexpr int LDS_F1 = LDS_EXTRA + 1024 * 4 + 4 * 64 * 4 + 16;   // fused first 
 constexpr int LDS_TOTAL = LDS_F1 + 9 * 64 * 4 + 64 * 4;
 constexpr int NWAVE = 8, NLOAD = 4, NT = (NWAVE + NLOAD) * 64;      // 8 matrix waves + 4 loader waves (one per SIMD)
 constexpr int IN_SEG = (NPIX + 63) / 64;                  // 10 wave-instructions per plane (the last one 36 lanes wide)
-constexpr int IN_SLOTS = WSU_GRAN * IN_SEG;               // 40
+constexpr int HBM_PLANES = 3;                             // stored planes per chunk: f16 ch 0-7 | f16 ch 8-15 | e4m3 residuals; LDS plane 3 is derived
+constexpr int IN_SLOTS = HBM_PLANES * IN_SEG;             // 30
 // The DMA of a step is issued by two dedicated LOADER waves (waves 8, 9: 38 pieces each), the matrix waves never touch the vector-memory
 // pipe inside the loop.  Measured on the way (profiles/r02/conv3x3_pl_stamps.md): a piece costs its issuing wave ~150 cycles in the
 // queue, so (v1) all eight waves issuing their pieces after the barrier idled the matrix pipe for 2-3 k cycles per step, (v2/v4)
 // threading the pieces through the matrix section stalled the in-order waves just as long, (v3) giving them to one wave per SIMD let its
 // partner run alone (68 % pipe time).  A wave that only loads costs 168 instead of 256 registers per matrix wave -- nothing else.
-constexpr int IN_PER_WAVE = IN_SLOTS / NLOAD;             // 20
+constexpr int IN_PER_WAVE = (IN_SLOTS + NLOAD - 1) / NLOAD;   // 8 (slots 30, 31 do not exist)
 constexpr int W_SLOTS = LDS_W / 1024;                     // 36
-constexpr int W_PER_WAVE = W_SLOTS / NLOAD;               // 18
-static_assert(IN_SLOTS % NLOAD == 0 && W_SLOTS % NLOAD == 0, "DMA slots divide over the loader waves");
+constexpr int W_PER_WAVE = W_SLOTS / NLOAD;               // 9
+static_assert(W_SLOTS % NLOAD == 0, "weight DMA slots divide over the loader waves");
 
 struct PlArgs {
     const char* x1; const char* x2; const char* wp; const float* bias;
@@ -86,7 +88,7 @@ __device__ __forceinline__ void plan_tile(const PlArgs& a, const Tile& t, int lw
         const int idx = seg * 64 + lane;
         const int r = idx / IW, c = idx - r * IW;
         const int yy = wsu_reflect(t.y0 - 1 + r, a.h), xx = wsu_reflect(t.x0 - 1 + c, a.w);
-        goff[k] = (idx < NPIX && (a.xres || plane != 2)) ? plane * hw + yy * a.w + xx : -1;
+        goff[k] = (slot < IN_SLOTS && idx < NPIX && (a.xres || plane != 2)) ? plane * hw + yy * a.w + xx : -1;
     }
 }
 
@@ -97,7 +99,7 @@ __device__ __forceinline__ void plan_tile(const PlArgs& a, const Tile& t, int lw
 struct DmaPlan { const char* in_src; const char* w_src; char* st; };
 
 __device__ __forceinline__ DmaPlan dma_plan(const PlArgs& a, int tn, int tcb, int c, char* st, int lane) {
-    const size_t plane4 = (size_t)a.h * a.w * 64;                       // bytes of one chunk of one image (4 planes)
+    const size_t plane4 = (size_t)a.h * a.w * 16 * HBM_PLANES;         // bytes of one chunk of one image (3 stored planes)
     DmaPlan p;
     p.in_src = c < a.nch1 ? a.x1 + ((size_t)tn * a.nch1 + c) * plane4
                           : a.x2 + ((size_t)tn * (a.nch - a.nch1) + (c - a.nch1)) * plane4;
@@ -131,8 +133,8 @@ __device__ __forceinline__ void issue_dma(const PlArgs& a, int tn, int tcb, int 
     }
     const DmaPlan p = dma_plan(a, tn, tcb, c, st, lane);
     // weight and input pieces alternate, so that the first pieces of both operands land early
-    WSU_STATIC_FOR(W_PER_WAVE, k, { dma_slot<k>(p, lw8, goff); dma_slot<IN_PER_WAVE + k>(p, lw8, goff); });
-    WSU_STATIC_FOR(IN_PER_WAVE - W_PER_WAVE, k, { dma_slot<W_PER_WAVE + k>(p, lw8, goff); });
+    WSU_STATIC_FOR(IN_PER_WAVE, k, { dma_slot<k>(p, lw8, goff); dma_slot<IN_PER_WAVE + k>(p, lw8, goff); });
+    WSU_STATIC_FOR(W_PER_WAVE - IN_PER_WAVE, k, { dma_slot<2 * IN_PER_WAVE + k>(p, lw8, goff); });
 }
 
 // value of lane ^ 1 by a DPP quad permutation (a VALU modifier: no LDS crossbar round trip like ds_bpermute)
@@ -233,19 +235,37 @@ __global__ __launch_bounds__(NT) void conv3x3_pl_kernel(const PlArgs a) {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[g][e] = fmaf(pimg[k][tp], w4[e], v[g][e]);
                         }
-                    uint32_t h[8], lo[4], x8[4];
+                    uint32_t h[8], lo[4];
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { v[g][e] = fmaxf(v[g][e], 0.f); f1_max = fmaxf(f1_max, v[g][e]); }
-                        wsu_split4_f16f8(v[g], WSU_F8_XLO_DIV, WSU_F8_X_DIV, h[2 * g], h[2 * g + 1], lo[g], x8[g]);
+                        wsu_split4_f16r8(v[g], WSU_F8_XLO_DIV, h[2 * g], h[2 * g + 1], lo[g]);
                     }
+                    // the e4m3 copies from the f16 values, exactly as derive_x8 makes them for fetched planes
+                    const u32x2 xa = wsu_f16x8_to_fp8(mk_u4(h[0], h[1], h[2], h[3])), xb = wsu_f16x8_to_fp8(mk_u4(h[4], h[5], h[6], h[7]));
                     if (idx < NPIX) {
                         char* d = st + idx * 16;
                         *reinterpret_cast<u32x4*>(d) = mk_u4(h[0], h[1], h[2], h[3]);
                         *reinterpret_cast<u32x4*>(d + PLANE) = mk_u4(h[4], h[5], h[6], h[7]);
                         *reinterpret_cast<u32x4*>(d + 2 * PLANE) = mk_u4(lo[0], lo[1], lo[2], lo[3]);
-                        *reinterpret_cast<u32x4*>(d + 3 * PLANE) = mk_u4(x8[0], x8[1], x8[2], x8[3]);
+                        *reinterpret_cast<u32x4*>(d + 3 * PLANE) = mk_u4(xa.x, xa.y, xb.x, xb.y);
+                    }
+                }
+            }
+        };
+        // LDS plane 3 (the e4m3 copies e4m3(x / 4) of the second cross term) is not stored in HBM: each loader derives it from the f16 granules
+        // IT fetched (same lane, after its own vmcnt wait -- no cross-wave dependency), 3 instructions per pair of values.
+        auto derive_x8 = [&](char* st) __attribute__((always_inline)) {
+            if constexpr (!F1) {
+#pragma unroll
+                for (int k = 0; k < IN_PER_WAVE; ++k) {
+                    const int slot = lw8 + NLOAD * k;
+                    const int plane = slot / IN_SEG, seg = slot - plane * IN_SEG;
+                    const int idx = seg * 64 + lane;
+                    if (plane < 2 && idx < NPIX) {
+                        const u32x4 hgr = *reinterpret_cast<const u32x4*>(st + plane * PLANE + idx * 16);
+                        *reinterpret_cast<u32x2*>(st + 3 * PLANE + idx * 16 + plane * 8) = wsu_f16x8_to_fp8(hgr);
                     }
                 }
             }
@@ -258,7 +278,9 @@ __global__ __launch_bounds__(NT) void conv3x3_pl_kernel(const PlArgs a) {
         int c = 0, kt = 0;
         for (int j = 0; j < J; ++j) {
             STAMP(s0);
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");        // this wave's pieces (and computed planes) of step j are in LDS
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // this wave's pieces of step j have landed
+            derive_x8(smem + (j & 1) * STAGE);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                // ... and its derived / computed planes are written
             STAMP(s1);
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
@@ -439,22 +461,22 @@ _Pragma("unroll")
                     // addresses = wave-uniform 64-bit base (image, output chunk) + 32-bit lane offset (pixel, plane): the stores take the
                     // SGPR-base form and the epilogue carries no 64-bit address registers (it sits at the 168-register step)
                     auto store_px = [&](const f32x4& X, const f32x4& Y, char* base, uint32_t off, uint32_t plane_bytes, bool ok) __attribute__((always_inline)) {
-                        uint32_t xh0, xh1, xlo, xx8, yh0, yh1, ylo, yx8;
-                        wsu_split4_f16f8(X, WSU_F8_XLO_DIV, WSU_F8_X_DIV, xh0, xh1, xlo, xx8);
-                        wsu_split4_f16f8(Y, WSU_F8_XLO_DIV, WSU_F8_X_DIV, yh0, yh1, ylo, yx8);
+                        uint32_t xh0, xh1, xlo, yh0, yh1, ylo;
+                        wsu_split4_f16r8(X, WSU_F8_XLO_DIV, xh0, xh1, xlo);
+                        wsu_split4_f16r8(Y, WSU_F8_XLO_DIV, yh0, yh1, ylo);
                         swap32(xh0, yh0); swap32(xh1, yh1);                     // lanes 0-31: f16 ch 0-7, lanes 32-63: f16 ch 8-15
-                        swap32(xlo, xx8); swap32(ylo, yx8);                     // lanes 0-31: residuals ch 0-15, lanes 32-63: e4m3 copies
+                        uint32_t xlp = xlo, ylp = ylo;
+                        swap32(xlo, xlp); swap32(ylo, ylp);                     // lanes 0-31: xlp / ylp = the partner lane's residuals (ch 4-7 / 12-15)
                         if (ok) {
-                            const uint32_t o1 = off + hh * plane_bytes;
-                            *reinterpret_cast<u32x4*>(base + o1) = mk_u4(xh0, xh1, yh0, yh1);
-                            *reinterpret_cast<u32x4*>(base + o1 + 2 * plane_bytes) = mk_u4(xlo, xx8, ylo, yx8);
+                            *reinterpret_cast<u32x4*>(base + off + hh * plane_bytes) = mk_u4(xh0, xh1, yh0, yh1);
+                            if (!hh) *reinterpret_cast<u32x4*>(base + off + 2 * plane_bytes) = mk_u4(xlo, xlp, ylo, ylp);
                         }
                     };
                     if (a.y) {
 #pragma unroll
                         for (int q = 0; q < 2; ++q) {
                             const int row = cur.y0 + 2 * wv + q;
-                            char* base = a.y + (((size_t)cur.n * nco + oc) * 4) * hw * 16;
+                            char* base = a.y + (((size_t)cur.n * nco + oc) * HBM_PLANES) * hw * 16;
                             store_px(vx[q], vy[q], base, (uint32_t)(row * a.w + col) * 16u, (uint32_t)hw * 16u, row < a.h && col < a.w);
                         }
                     }
@@ -475,7 +497,7 @@ _Pragma("unroll")
                         }
                         const int hp = a.h >> 1, wp2 = a.w >> 1;
                         const int gy = (cur.y0 >> 1) + wv, gx = (cur.x0 >> 1) + (l31 >> 1);
-                        char* base = a.ypool + (((size_t)cur.n * nco + oc) * 4) * hp * wp2 * 16;
+                        char* base = a.ypool + (((size_t)cur.n * nco + oc) * HBM_PLANES) * hp * wp2 * 16;
                         store_px(px, py, base, (uint32_t)(gy * wp2 + gx) * 16u, (uint32_t)(hp * wp2) * 16u, !(l31 & 1) && gy < hp && gx < wp2);
                     }
                 }

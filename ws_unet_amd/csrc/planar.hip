@@ -17,16 +17,17 @@ __device__ __forceinline__ void swap32(uint32_t& upper_of, uint32_t& lower_of) {
 }
 
 // X, Y = 4 + 4 values of one pixel (channels c0 + 4 hh .. and c0 + 8 + 4 hh ..; hh = lane >> 5): encode, gather whole 16-byte granules into
-// single lanes (conv3x3_pl.hip) and store the chunk's four planes: every instruction writes contiguous runs of 32 lanes x 16 B.
+// single lanes (conv3x3_pl.hip) and store the chunk's three planes (f16 | f16 | residuals): every instruction writes contiguous runs of 32 lanes x 16 B.
 __device__ __forceinline__ void store_chunk_px(const f32x4& X, const f32x4& Y, char* dst, size_t plane_bytes, int hh, bool ok) {
-    uint32_t xh0, xh1, xlo, xx8, yh0, yh1, ylo, yx8;
-    wsu_split4_f16f8(X, WSU_F8_XLO_DIV, WSU_F8_X_DIV, xh0, xh1, xlo, xx8);
-    wsu_split4_f16f8(Y, WSU_F8_XLO_DIV, WSU_F8_X_DIV, yh0, yh1, ylo, yx8);
+    uint32_t xh0, xh1, xlo, yh0, yh1, ylo;
+    wsu_split4_f16r8(X, WSU_F8_XLO_DIV, xh0, xh1, xlo);
+    wsu_split4_f16r8(Y, WSU_F8_XLO_DIV, yh0, yh1, ylo);
     swap32(xh0, yh0); swap32(xh1, yh1);
-    swap32(xlo, xx8); swap32(ylo, yx8);
+    uint32_t xlp = xlo, ylp = ylo;
+    swap32(xlo, xlp); swap32(ylo, ylp);                                  // lanes 0-31 collect all 16 residuals of the chunk
     if (ok) {
         *reinterpret_cast<u32x4*>(dst + hh * plane_bytes) = mk_u4(xh0, xh1, yh0, yh1);
-        *reinterpret_cast<u32x4*>(dst + (2 + hh) * plane_bytes) = mk_u4(xlo, xx8, ylo, yx8);
+        if (!hh) *reinterpret_cast<u32x4*>(dst + 2 * plane_bytes) = mk_u4(xlo, xlp, ylo, ylp);
     }
 }
 
@@ -48,9 +49,10 @@ constexpr int STAGE = 2 * CHUNK;                          // 49152
 constexpr int LDS_EXTRA = 2 * STAGE;                      // bias [1024]
 constexpr int LDS_TOTAL = LDS_EXTRA + 1024 * 4;
 constexpr int NWAVE = 8, NLOAD = 4, NT = (NWAVE + NLOAD) * 64;
-constexpr int IN_SLOTS = 2 * WSU_GRAN * 2;                // 2 chunks x 4 planes x 2 segments of 64 pixels = 16
+constexpr int HBM_PLANES = 3;                             // stored planes per chunk (LDS plane 3 is derived by the loaders)
+constexpr int IN_SLOTS = 2 * HBM_PLANES * 2;              // 2 chunks x 3 planes x 2 segments of 64 pixels = 12
 constexpr int W_SLOTS = 2 * W1 / 1024;                    // 32
-constexpr int IN_PER = IN_SLOTS / NLOAD, W_PER = W_SLOTS / NLOAD;   // 4, 8
+constexpr int IN_PER = IN_SLOTS / NLOAD, W_PER = W_SLOTS / NLOAD;   // 3, 8
 }
 
 struct CtpArgs {
@@ -78,10 +80,10 @@ __device__ __forceinline__ void ct_issue_dma(const CtpArgs& a, const CtTile& t, 
 #pragma unroll
     for (int k = 0; k < IN_PER; ++k) {
         const int slot = lw8 + NLOAD * k;
-        const int ck = slot >> 3, plane = (slot >> 1) & 3, seg = slot & 1;
+        const int ck = slot / 6, plane = (slot % 6) >> 1, seg = slot & 1;
         const int pix = seg * 64 + lane;
         const int yy = min(t.y0 + pix / TW, a.h - 1), xx = min(t.x0 + pix % TW, a.w - 1);
-        const char* src = a.x + ((((size_t)t.n * nch + 2 * step + ck) * 4 + plane) * hw + (size_t)yy * a.w + xx) * 16;
+        const char* src = a.x + ((((size_t)t.n * nch + 2 * step + ck) * HBM_PLANES + plane) * hw + (size_t)yy * a.w + xx) * 16;
         __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(st + ck * CHUNK + plane * PLANE + seg * 1024), 16, 0, 0);
     }
 #pragma unroll
@@ -113,6 +115,20 @@ __global__ __launch_bounds__(ct::NT) void convt2x2_pl_kernel(const CtpArgs a) {
         int c = 0, kt = 0;
         for (int j = 0; j < J; ++j) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            {   // LDS plane 3 = e4m3 copies of the f16 granules this wave fetched (same lanes: no cross-wave dependency)
+                char* st = smem + (j & 1) * STAGE;
+#pragma unroll
+                for (int k = 0; k < IN_PER; ++k) {
+                    const int slot = lw8 + NLOAD * k;
+                    const int ck = slot / 6, plane = (slot % 6) >> 1, seg = slot & 1;
+                    if (plane < 2) {
+                        const int pix = seg * 64 + lane;
+                        const u32x4 hgr = *reinterpret_cast<const u32x4*>(st + ck * CHUNK + plane * PLANE + pix * 16);
+                        *reinterpret_cast<u32x2*>(st + ck * CHUNK + 3 * PLANE + pix * 16 + plane * 8) = wsu_f16x8_to_fp8(hgr);
+                    }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             if (j + 1 < J) {
@@ -188,7 +204,7 @@ __global__ __launch_bounds__(ct::NT) void convt2x2_pl_kernel(const CtpArgs a) {
                 for (int q = 0; q < 2; ++q) {
                     const int irow = cur.y0 + 2 * half + q;
                     const bool ok = irow < a.h && icol < a.w;
-                    char* dst = a.y + ((((size_t)cur.n * nco + oc) * 4) * ohw + (size_t)(2 * irow + pa) * ow + 2 * icol) * 16;
+                    char* dst = a.y + ((((size_t)cur.n * nco + oc) * HBM_PLANES) * ohw + (size_t)(2 * irow + pa) * ow + 2 * icol) * 16;
 #pragma unroll
                     for (int b = 0; b < 2; ++b) {
                         f32x4 X, Y;
@@ -261,7 +277,7 @@ __global__ __launch_bounds__(256) void first_pl_kernel(const FirstPlArgs a) {
                             for (int e = 0; e < 4; ++e) v[g][e] = fmaf(p[ci][tp], w4[e], v[g][e]);
                         }
                     }
-            uint32_t h[8], lo[4], x8[4];
+            uint32_t h[8], lo[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 if (a.relu) {
@@ -270,13 +286,12 @@ __global__ __launch_bounds__(256) void first_pl_kernel(const FirstPlArgs a) {
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) vmax = fmaxf(vmax, fabsf(v[g][e]));
-                wsu_split4_f16f8(v[g], WSU_F8_XLO_DIV, WSU_F8_X_DIV, h[2 * g], h[2 * g + 1], lo[g], x8[g]);
+                wsu_split4_f16r8(v[g], WSU_F8_XLO_DIV, h[2 * g], h[2 * g + 1], lo[g]);
             }
-            char* dst = a.y + ((((size_t)img * nco + oc) * 4) * hw + (size_t)y * a.w_ + x) * 16;
+            char* dst = a.y + ((((size_t)img * nco + oc) * 3) * hw + (size_t)y * a.w_ + x) * 16;
             *reinterpret_cast<u32x4*>(dst) = mk_u4(h[0], h[1], h[2], h[3]);
             *reinterpret_cast<u32x4*>(dst + hw * 16) = mk_u4(h[4], h[5], h[6], h[7]);
             *reinterpret_cast<u32x4*>(dst + 2 * hw * 16) = mk_u4(lo[0], lo[1], lo[2], lo[3]);
-            *reinterpret_cast<u32x4*>(dst + 3 * hw * 16) = mk_u4(x8[0], x8[1], x8[2], x8[3]);
         }
     }
     if (a.range_flag && !(vmax <= WSU_F8_RANGE)) atomicOr(a.range_flag, 1u);      // rare: at most one atomic per lane

@@ -111,6 +111,19 @@ __device__ __forceinline__ void wsu_split4_f16f8(const f32x4& v, float div_lo, f
     x = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(x, __builtin_amdgcn_fmed3f(v[2], -lim_x, lim_x), __builtin_amdgcn_fmed3f(v[3], -lim_x, lim_x), div_x, true);
     lo = __builtin_bit_cast(uint32_t, l); x8 = __builtin_bit_cast(uint32_t, x);
 }
+// the same without the e4m3 copy (planar storage keeps f16 + residual; the copy is derived from the f16 part by the consumer's loader waves)
+__device__ __forceinline__ void wsu_split4_f16r8(const f32x4& v, float div_lo, uint32_t& h01, uint32_t& h23, uint32_t& lo) {
+    const f32x2 a = {v[0], v[1]}, b = {v[2], v[3]};
+    const f16x2 ha = __builtin_convertvector(a, f16x2), hb = __builtin_convertvector(b, f16x2);
+    h01 = __builtin_bit_cast(uint32_t, ha); h23 = __builtin_bit_cast(uint32_t, hb);
+    const float lim_lo = 448.f * div_lo;
+    const float r0 = __builtin_amdgcn_fmed3f(v[0] - (float)ha[0], -lim_lo, lim_lo), r1 = __builtin_amdgcn_fmed3f(v[1] - (float)ha[1], -lim_lo, lim_lo);
+    const float r2 = __builtin_amdgcn_fmed3f(v[2] - (float)hb[0], -lim_lo, lim_lo), r3 = __builtin_amdgcn_fmed3f(v[3] - (float)hb[1], -lim_lo, lim_lo);
+    i16x2 l = {0, 0};
+    l = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(l, r0, r1, div_lo, false);
+    l = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(l, r2, r3, div_lo, true);
+    lo = __builtin_bit_cast(uint32_t, l);
+}
 // 16 channels of one pixel -> the 3 x 16 B of a stored F16F8 chunk (the e4m3 copy is derived from the f16 part while staging)
 __device__ __forceinline__ void wsu_split16_f16f8(const f32x4& q0, const f32x4& q1, const f32x4& q2, const f32x4& q3,
                                                   u32x4& hi0, u32x4& hi1, u32x4& lo8) {

@@ -247,9 +247,12 @@ def conv3x3_fused_first(x_nchw: torch.Tensor, w1: torch.Tensor, b1: Optional[tor
     return y
 
 
+PLANAR_PLANES = 3            # stored planes per 16-channel chunk: f16 ch 0-7 | f16 ch 8-15 | e4m3 residuals ch 0-15
+
+
 def planar_shape(n: int, c: int, h: int, w: int):
-    """Allocation shape (float32-typed) of a planar 'F16F8P' activation tensor: [n][C/16][4 planes][H][W][16 B] (include/wsu.h)."""
-    return (n, c // 16, 4, h, w, 4)
+    """Allocation shape (float32-typed) of a planar 'F16F8P' activation tensor: [n][C/16][3 planes][H][W][16 B] (include/wsu.h)."""
+    return (n, c // 16, PLANAR_PLANES, h, w, 4)
 
 
 def conv3x3_pl(x1: torch.Tensor, x2: Optional[torch.Tensor], w_packed: torch.Tensor, bias: Optional[torch.Tensor], cout: int,
@@ -262,7 +265,7 @@ def conv3x3_pl(x1: torch.Tensor, x2: Optional[torch.Tensor], w_packed: torch.Ten
     lib = _lib.load()
     hw2 = None if head_w is None else head_w.detach().reshape(head_w.shape[0], -1).contiguous()
     _dev_check(x1, x2, w_packed, bias, hw2, head_b)
-    assert x1.dtype == torch.float32 and x1.dim() == 6 and x1.shape[2] == 4 and x1.shape[5] == 4 and x1.is_contiguous()
+    assert x1.dtype == torch.float32 and x1.dim() == 6 and x1.shape[2] == PLANAR_PLANES and x1.shape[5] == 4 and x1.is_contiguous()
     n, nch1, _, h, w, _ = x1.shape
     c1 = nch1 * 16
     c2 = 0
@@ -275,7 +278,7 @@ def conv3x3_pl(x1: torch.Tensor, x2: Optional[torch.Tensor], w_packed: torch.Ten
     out = torch.empty((n, hc, h, w), dtype=torch.float32, device=x1.device) if hc else None
     logit = torch.empty_like(out) if (hc and want_logit) else None
     meta = {"flops": 2.0 * 9 * (c1 + c2) * cout * n * h * w,
-            "bytes": float(n * h * w * ((c1 + c2) * 4 + (cout * 4 if want_y else 0) + hc * 4) + (n * (h // 2) * (w // 2) * cout * 4 if pool else 0)
+            "bytes": float(n * h * w * ((c1 + c2) * 3 + (cout * 3 if want_y else 0) + hc * 4) + (n * (h // 2) * (w // 2) * cout * 3 if pool else 0)
                            + 9 * (c1 + c2) * cout * 4)}
     check(_launch("conv3x3_pl", meta, lambda: lib.wsu_conv3x3_pl_fwd(
         x1.data_ptr(), _ptr(x2), w_packed.data_ptr(), _ptr(bias), _ptr(y), _ptr(yp), _ptr(hw2), _ptr(head_b), _ptr(out), _ptr(logit), hc,
@@ -298,7 +301,7 @@ def conv3x3_pl_fused_first(x_nchw: torch.Tensor, w1: torch.Tensor, b1: Optional[
     y = torch.empty(planar_shape(n, cout, h, w), dtype=torch.float32, device=x_nchw.device)
     yp = torch.empty(planar_shape(n, cout, h // 2, w // 2), dtype=torch.float32, device=x_nchw.device) if pool else None
     meta = {"flops": 2.0 * 9 * 64 * cout * n * h * w,
-            "bytes": float(n * h * w * (4 + cout * 4) + (n * (h // 2) * (w // 2) * cout * 4 if pool else 0) + 9 * 64 * cout * 4)}
+            "bytes": float(n * h * w * (4 + cout * 3) + (n * (h // 2) * (w // 2) * cout * 3 if pool else 0) + 9 * 64 * cout * 4)}
     check(_launch("conv3x3_pl", meta, lambda: lib.wsu_conv3x3_pl_fused_first_fwd(
         x_nchw.data_ptr(), w1.data_ptr(), _ptr(b1), w_packed.data_ptr(), _ptr(bias), y.data_ptr(), _ptr(yp),
         n, h, w, cout, int(relu), _ptr(range_flag), _stream())), "wsu_conv3x3_pl_fused_first_fwd")
@@ -310,11 +313,11 @@ def convt2x2_pl(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Te
     """nn.ConvTranspose2d(k=2, s=2) + bias on planar F16F8P activations (wsu_convt2x2_pl_fwd); w_packed from pack_convt2x2(mode f16f8)."""
     lib = _lib.load()
     _dev_check(x, w_packed, bias)
-    assert x.dtype == torch.float32 and x.dim() == 6 and x.shape[2] == 4 and x.shape[5] == 4 and x.is_contiguous()
+    assert x.dtype == torch.float32 and x.dim() == 6 and x.shape[2] == PLANAR_PLANES and x.shape[5] == 4 and x.is_contiguous()
     n, nch, _, h, w, _ = x.shape
     cin = nch * 16
     y = torch.empty(planar_shape(n, cout, 2 * h, 2 * w), dtype=torch.float32, device=x.device)
-    meta = {"flops": 2.0 * 4 * cin * cout * n * h * w, "bytes": float(n * h * w * (cin + 4 * cout) * 4 + 4 * cin * cout * 4)}
+    meta = {"flops": 2.0 * 4 * cin * cout * n * h * w, "bytes": float(n * h * w * (cin + 4 * cout) * 3 + 4 * cin * cout * 4)}
     check(_launch("convt2x2_pl", meta, lambda: lib.wsu_convt2x2_pl_fwd(
         x.data_ptr(), w_packed.data_ptr(), _ptr(bias), y.data_ptr(), n, h, w, cin, cout, _ptr(range_flag), _stream())), "wsu_convt2x2_pl_fwd")
     return y
@@ -330,7 +333,7 @@ def conv3x3_first_pl(x_nchw: torch.Tensor, w: torch.Tensor, bias: Optional[torch
     cout = w.shape[0]
     assert x_nchw.dtype == torch.float32 and x_nchw.is_contiguous() and w.shape[1] == cin
     y = torch.empty(planar_shape(n, cout, h, wd), dtype=torch.float32, device=x_nchw.device)
-    meta = {"flops": 2.0 * 9 * cin * cout * n * h * wd, "bytes": float(n * h * wd * (cin * 4 + cout * 4))}
+    meta = {"flops": 2.0 * 9 * cin * cout * n * h * wd, "bytes": float(n * h * wd * (cin * 4 + cout * 3))}
     check(_launch("conv3x3_first_pl", meta, lambda: lib.wsu_conv3x3_first_pl_fwd(
         x_nchw.data_ptr(), w.data_ptr(), _ptr(bias), y.data_ptr(), n, h, wd, cin, cout, int(relu), _ptr(range_flag), _stream())), "wsu_conv3x3_first_pl_fwd")
     return y
