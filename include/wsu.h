@@ -141,6 +141,21 @@ int wsu_conv3x3_pl_fwd(const void* x1, const void* x2, const void* w_packed, con
 int wsu_conv3x3_pl_fused_first_fwd(const float* img, const float* w1, const float* b1, const void* w_packed, const float* bias,
                                    void* y, void* y_pool, int n, int h, int w, int cout, int relu, unsigned* range_flag, void* stream);
 
+/* ---- K7p: data gradient of the 3x3 reflect conv on PLANAR tensors (csrc/conv3x3_pl.hip kernel variant GRAD + csrc/train_pl.hip; autograd of
+ *      unet.py:141-189).  Gradients use the F16F8P layout with the gradient's residual scaling: planes f16 | f16 | e4m3((g - f16 g) * 2^14),
+ *      values pre-scaled by a power of two (wsu_pow2_grad_scale).  g: pre-activation gradient (cout channels); w_packed_dgrad from
+ *      wsu_conv3x3_pack_dgrad(mode F16F8); dx1 = input channels [0, csplit), dx2 (NULL iff csplit == cin) the rest (fused concat); mask1 /
+ *      mask2 (optional): planar ACTIVATIONS shaped like dx1 / dx2 -- the input of this conv as the producing layer stored it -- whose sign is
+ *      that layer's ReLU mask (relu'(0) = 0).  pad_zero = 0: reflect padding; the border ring of the adjoint is one more launch of the same
+ *      kernel over strips of g's border rows / columns with the four 1x3 weight sets of wsu_conv3x3_pack_ring (4 x
+ *      wsu_conv3x3_packed_bytes(cin, cout, F16F8) bytes) in `workspace` (>= wsu_conv3x3_pl_bwd_data_workspace_bytes).  pad_zero = 1: the
+ *      adjoint of the zero-padded conv (ring arguments unused).  cin, csplit multiples of 64, cout of 16. */
+size_t wsu_conv3x3_pl_bwd_data_workspace_bytes(int n, int h, int w, int cin, int cout);
+int wsu_conv3x3_pack_ring(const float* w_oihw, void* w_packed, int cin, int cout, void* stream);
+int wsu_conv3x3_pl_bwd_data(const void* g, const void* w_packed_dgrad, const void* w_packed_ring, void* workspace, size_t workspace_bytes,
+                            void* dx1, void* dx2, int csplit, const void* mask1, const void* mask2,
+                            int n, int h, int w, int cin, int cout, int pad_zero, void* stream);
+
 /* ---- K3p / K0p: the other two kernels of the planar (F16F8P) inference path (csrc/planar.hip).
  *      wsu_convt2x2_pl_fwd: nn.ConvTranspose2d(k2, s2) + bias (unet.py:125,130,177,183), x: cin channels at (h, w) planar -> y: cout channels at
  *      (2h, 2w) planar; weights from wsu_convt2x2_pack(mode F16F8); cin a multiple of 32, cout of 64.

@@ -88,23 +88,26 @@ def unsplit_f16f8(t_nhwc: torch.Tensor) -> torch.Tensor:
     return torch.from_numpy((hi + lo).reshape(n, h, w, c).copy())
 
 
-def planar_encode(x_nchw: torch.Tensor) -> torch.Tensor:
+def planar_encode(x_nchw: torch.Tensor, lo_scale: float = 4096.0) -> torch.Tensor:
     """fp32 NCHW (any device) -> planar 'F16F8P' storage on the device (test-side restatement of include/wsu.h: [n][C/16][3 planes][H][W]
-    [16 B]; plane 0/1 = f16 of channels 0-7 / 8-15, plane 2 = e4m3((x - f16 x) * 2^12) of channels 0-15)."""
+    [16 B]; plane 0/1 = f16 of channels 0-7 / 8-15, plane 2 = e4m3((x - f16 x) * 2^12) of channels 0-15; gradients: lo_scale = 2^14)."""
     x = x_nchw.to(DEV).float()
     n, c, h, w = x.shape
     xc = x.reshape(n, c // 16, 16, h, w).permute(0, 1, 3, 4, 2).contiguous()              # (n, chunk, h, w, 16)
     hi = xc.to(torch.float16)
-    lo = ((xc - hi.float()) * 4096.0).clamp(-448, 448).to(torch.float8_e4m3fn)
+    lo = ((xc - hi.float()) * lo_scale).clamp(-448, 448).to(torch.float8_e4m3fn)
     hb = hi.view(torch.uint8).reshape(n, c // 16, h, w, 2, 16)                            # two 16-byte f16 granules
     planes = torch.stack([hb[..., 0, :], hb[..., 1, :], lo.view(torch.uint8)], dim=2)     # (n, chunk, 3, h, w, 16)
     return planes.contiguous().view(torch.float32)
 
 
-def planar_decode(t: torch.Tensor) -> torch.Tensor:
+GRAD_LO = 16384.0          # residual scaling of planar gradients
+
+
+def planar_decode(t: torch.Tensor, lo_scale: float = 4096.0) -> torch.Tensor:
     """planar 'F16F8P' storage -> fp32 NCHW on the CPU (f16 part + residual part)."""
     raw = t.detach().contiguous().view(torch.uint8)                                        # (n, chunk, 3, h, w, 16)
     n, nch, _, h, w, _ = raw.shape
     hi = torch.stack([raw[:, :, 0], raw[:, :, 1]], dim=-2).contiguous().view(torch.float16).reshape(n, nch, h, w, 16).float()
-    lo = raw[:, :, 2].contiguous().view(torch.float8_e4m3fn).float() / 4096.0
+    lo = raw[:, :, 2].contiguous().view(torch.float8_e4m3fn).float() / lo_scale
     return (hi + lo).permute(0, 1, 4, 2, 3).reshape(n, nch * 16, h, w).cpu()

@@ -1534,7 +1534,14 @@ __global__ void pack_conv3x3_f16f8_kernel(const float* __restrict__ w, char* __r
         for (int e = 0; e < 16; ++e) {
             const int ci = c * 16 + e, m = cb * WSU_COB + co, u = tap / 3, v = tap % 3;
             float val;
-            if (transpose_flip == 2) val = w[(((size_t)ci * cin + m) * 3 + (2 - v)) * 3 + (2 - u)];
+            if (transpose_flip >= 3) {
+                // border-ring sets of the reflect adjoint (train_pl.hip): a 1x3 filter in the middle tap row, applied along a strip of the
+                // gradient's first / last row (3: top, 4: bottom) or first / last column (5: left, 6: right)
+                const int ky = transpose_flip == 3 ? 0 : transpose_flip == 4 ? 2 : 2 - v;
+                const int kx = transpose_flip == 5 ? 0 : transpose_flip == 6 ? 2 : 2 - v;
+                val = u == 1 ? w[(((size_t)ci * cin + m) * 3 + ky) * 3 + kx] : 0.f;
+            }
+            else if (transpose_flip == 2) val = w[(((size_t)ci * cin + m) * 3 + (2 - v)) * 3 + (2 - u)];
             else if (transpose_flip) val = w[(((size_t)ci * cin + m) * 3 + (2 - u)) * 3 + (2 - v)];
             else                     val = w[(((size_t)m * cin + ci) * 3 + u) * 3 + v];
             q[e >> 2][e & 3] = val;
@@ -1593,6 +1600,17 @@ int wsu_conv3x3_pack_dgrad_swapped(const float* w_oihw, void* w_packed, int cin,
 
 int wsu_conv3x3_pack_dgrad(const float* w_oihw, void* w_packed, int cin, int cout, int mode, void* stream) {
     return pack_impl(w_oihw, w_packed, cin, cout, mode, 1, stream);
+}
+
+// The four border-ring weight sets (top, bottom, left, right) of the planar data gradient, 4 x wsu_conv3x3_packed_bytes(cin, cout, F16F8)
+// bytes: wsu_conv3x3_pl_bwd_data runs them over strips of the gradient's border rows / columns (reflect-padding adjoint).
+int wsu_conv3x3_pack_ring(const float* w_oihw, void* w_packed, int cin, int cout, void* stream) {
+    const size_t set = (size_t)cin * cout * 9 * 4;
+    for (int k = 0; k < 4; ++k) {
+        int rc = pack_impl(w_oihw, (char*)w_packed + k * set, cin, cout, WSU_MODE_F16F8, 3 + k, stream);
+        if (rc) return rc;
+    }
+    return 0;
 }
 
 // Extended launcher shared by the forward op and the data-gradient op (wsu_conv3x3_bwd_data in conv3x3_bwd.hip).

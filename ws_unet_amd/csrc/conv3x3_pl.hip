@@ -58,7 +58,15 @@ struct PlArgs {
     int xres;                                             // 0: the inputs' residual plane (plane 2) is not used (kernel variant XRES = false)
     unsigned* range_flag;                                 // optional: bit 0 is set when a stored activation exceeds the encodable range (|x| > 448)
     int ablate;                                           // timing-only experiments (WSU_PL_ABLATE; results wrong when != 0): 1 = no DMA after step 0
+    // data-gradient variant (GRAD): zero padding, gradient encodings, no bias / ReLU; output chunks < nco1 go to y, the others to y2 (fused
+    // concat: one gradient per source); mask / mask2 (optional, planar activations shaped like y / y2): the ReLU mask (x > 0) of the layer
+    // that produced this conv's input, applied to the result; images n >= k * imgs_per_wset take weight set k (ring strips)
+    char* y2; int nco1;
+    const char* mask; const char* mask2;
+    int imgs_per_wset; size_t wset_bytes;
 };
+
+__device__ __attribute__((aligned(16))) unsigned g_zero16[4];   // source of the zero-padding DMA pieces of the GRAD variant
 
 struct Tile { int n, y0, x0, cb; };
 
@@ -79,6 +87,7 @@ typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void glb_void;
 
 // source offsets (in 16-byte units, inside one chunk's 4 planes of one image) of this lane's 5 input DMA slots; -1 = lane idle
+template <bool GRAD = false>
 __device__ __forceinline__ void plan_tile(const PlArgs& a, const Tile& t, int lw8, int lane, int (&goff)[IN_PER_WAVE]) {
     const int hw = a.h * a.w;
 #pragma unroll
@@ -87,8 +96,14 @@ __device__ __forceinline__ void plan_tile(const PlArgs& a, const Tile& t, int lw
         const int plane = slot / IN_SEG, seg = slot - plane * IN_SEG;
         const int idx = seg * 64 + lane;
         const int r = idx / IW, c = idx - r * IW;
-        const int yy = wsu_reflect(t.y0 - 1 + r, a.h), xx = wsu_reflect(t.x0 - 1 + c, a.w);
-        goff[k] = (slot < IN_SLOTS && idx < NPIX && (a.xres || plane != 2)) ? plane * hw + yy * a.w + xx : -1;
+        if constexpr (GRAD) {                                  // zero padding: pixels outside the image come from a block of zeros (-2)
+            const int yy = t.y0 - 1 + r, xx = t.x0 - 1 + c;
+            const bool inside = yy >= 0 && yy < a.h && xx >= 0 && xx < a.w;
+            goff[k] = (slot < IN_SLOTS && idx < NPIX) ? (inside ? plane * hw + yy * a.w + xx : -2) : -1;
+        } else {
+            const int yy = wsu_reflect(t.y0 - 1 + r, a.h), xx = wsu_reflect(t.x0 - 1 + c, a.w);
+            goff[k] = (slot < IN_SLOTS && idx < NPIX && (a.xres || plane != 2)) ? plane * hw + yy * a.w + xx : -1;
+        }
     }
 }
 
@@ -104,6 +119,7 @@ __device__ __forceinline__ DmaPlan dma_plan(const PlArgs& a, int tn, int tcb, in
     p.in_src = c < a.nch1 ? a.x1 + ((size_t)tn * a.nch1 + c) * plane4
                           : a.x2 + ((size_t)tn * (a.nch - a.nch1) + (c - a.nch1)) * plane4;
     p.w_src = a.wp + ((size_t)tcb * a.nch + c) * LDS_W + lane * 16;
+    if (a.imgs_per_wset > 0) p.w_src += (size_t)(tn / a.imgs_per_wset) * a.wset_bytes;
     p.st = st;
     return p;
 }
@@ -113,8 +129,10 @@ __device__ __forceinline__ void dma_slot(const DmaPlan& p, int lw8, const int (&
     if constexpr (K < IN_PER_WAVE) {
         const int slot = lw8 + NLOAD * K;
         const int plane = slot / IN_SEG, seg = slot - plane * IN_SEG;
-        if (goff[K] >= 0)
-            __builtin_amdgcn_global_load_lds((glb_void*)(p.in_src + (size_t)goff[K] * 16), (lds_void*)(p.st + plane * PLANE + seg * 1024), 16, 0, 0);
+        if (goff[K] != -1) {
+            const char* src = goff[K] >= 0 ? p.in_src + (size_t)goff[K] * 16 : reinterpret_cast<const char*>(g_zero16);
+            __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(p.st + plane * PLANE + seg * 1024), 16, 0, 0);
+        }
     } else {
         const int slot = lw8 + NLOAD * (K - IN_PER_WAVE);
         if (slot < W_SLOTS)
@@ -159,7 +177,11 @@ __device__ __forceinline__ void swap32(uint32_t& upper_of, uint32_t& lower_of) {
 // exchange registers would otherwise be carried -- and spilled -- by the variants that do not use them.
 // XRES = false: the activations' residual plane is neither loaded nor multiplied (one cross term per product, the weights' residual:
 // 9 f16 + 3 fp8 instructions = 15 instead of 19 matrix units per chunk, 30 instead of 40 input DMA pieces) -- `x_residual = 0`, see wsu.h.
-template <int HC, bool POOL, bool XRES = true, bool F1 = false>            // HC = head planes compiled in: 0 (no head), 1 (the reference's single output plane) or 4 (1..4)
+// GRAD: the data gradient of the conv (K7p, autograd of unet.py:141-189): the same pipeline over the pre-activation gradient with the
+// transposed / flipped weights (wsu_conv3x3_pack_dgrad) -- zero padding, the gradient's e4m3 scalings, no bias / ReLU, the ReLU mask of
+// the producing layer applied from a bit image that the loader waves build in LDS from that layer's stored f16 planes.  The reflect
+// adjoint's border ring is added by the caller (train_pl.hip).
+template <int HC, bool POOL, bool XRES = true, bool F1 = false, bool GRAD = false>   // HC = head planes compiled in: 0 (no head), 1 (the reference's single output plane) or 4 (1..4)
 __global__ __launch_bounds__(NT) void conv3x3_pl_kernel(const PlArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -172,7 +194,8 @@ __global__ __launch_bounds__(NT) void conv3x3_pl_kernel(const PlArgs a) {
     float* s_bias = reinterpret_cast<float*>(smem + LDS_EXTRA);
     float* s_hw = s_bias + 1024;
     float* s_hb = s_hw + 4 * 64;
-    for (int i = tid; i < a.cout; i += NT) s_bias[i] = a.bias ? a.bias[i] : 0.f;
+    if constexpr (!GRAD) { for (int i = tid; i < a.cout; i += NT) s_bias[i] = a.bias ? a.bias[i] : 0.f; }
+    unsigned char* s_mask = reinterpret_cast<unsigned char*>(smem + LDS_EXTRA);   // GRAD: [4 output chunks][2 f16 planes][512 px] bytes of 8 mask bits (the bias slot)
     constexpr bool HEAD = HC > 0;
     if constexpr (HEAD) {
         for (int i = tid; i < a.head_cout * 64; i += NT) s_hw[i] = a.head_w[i];
@@ -265,13 +288,50 @@ __global__ __launch_bounds__(NT) void conv3x3_pl_kernel(const PlArgs a) {
                     const int idx = seg * 64 + lane;
                     if (plane < 2 && idx < NPIX) {
                         const u32x4 hgr = *reinterpret_cast<const u32x4*>(st + plane * PLANE + idx * 16);
-                        *reinterpret_cast<u32x2*>(st + 3 * PLANE + idx * 16 + plane * 8) = wsu_f16x8_to_fp8(hgr);
+                        *reinterpret_cast<u32x2*>(st + 3 * PLANE + idx * 16 + plane * 8) = GRAD ? wsu_f16x8_to_fp8_grad(hgr) : wsu_f16x8_to_fp8(hgr);
                     }
                 }
             }
         };
+        // GRAD: the ReLU mask of the tile = sign test of the producing layer's f16 planes at the tile's 512 pixels x 64 output channels:
+        // 16 granules per loader lane, fetched during the tile's first step and committed as one byte each before its second barrier
+        // (the epilogue reads them after the last one; needs nch >= 2).
+        constexpr int MK = GRAD ? 16 : 1;
+        u32x4 mreg[MK];
+        bool mask_pending = false;
+        auto mask_issue = [&](const Tile& tt) __attribute__((always_inline)) {
+            if constexpr (GRAD) {
+                const bool d1 = tt.cb * 4 < a.nco1;
+                const char* mk = d1 ? a.mask : a.mask2;
+                if (mk == nullptr) return;
+                const int ncm = d1 ? a.nco1 : (a.cout >> 4) - a.nco1, oc0 = d1 ? tt.cb * 4 : tt.cb * 4 - a.nco1;
+                const size_t hw = (size_t)a.h * a.w;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const int combo = k >> 1, pix = (k & 1) * 256 + lw8 * 64 + lane;          // combo = output chunk * 2 + plane
+                    const int yy = min(tt.y0 + (pix >> 5), a.h - 1), xx = min(tt.x0 + (pix & 31), a.w - 1);
+                    mreg[k] = *reinterpret_cast<const u32x4*>(mk + ((((size_t)tt.n * ncm + oc0 + (combo >> 1)) * HBM_PLANES + (combo & 1)) * hw + (size_t)yy * a.w + xx) * 16);
+                }
+                mask_pending = true;
+            }
+        };
+        auto mask_commit = [&]() __attribute__((always_inline)) {
+            if constexpr (GRAD) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    unsigned bits = 0;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {                                             // f16 > 0 <=> its 16 bits > 0 as a signed integer
+                        const int wd = (int)mreg[k][e];
+                        bits |= ((short)(wd & 0xFFFF) > 0 ? 1u : 0u) << (2 * e);
+                        bits |= (wd >= 0x10000 ? 1u : 0u) << (2 * e + 1);
+                    }
+                    s_mask[(k >> 1) * 512 + (k & 1) * 256 + lw8 * 64 + lane] = (unsigned char)bits;
+                }
+            }
+        };
         if (J > 0) {
-            if constexpr (F1) f1_window(t); else plan_tile(a, t, lw8, lane, goff);
+            if constexpr (F1) f1_window(t); else plan_tile<GRAD>(a, t, lw8, lane, goff);
             issue_dma<F1>(a, t.n, t.cb, 0, smem, lw8, lane, goff);
             f1_chunk(0, smem);
         }
@@ -280,20 +340,24 @@ __global__ __launch_bounds__(NT) void conv3x3_pl_kernel(const PlArgs a) {
             STAMP(s0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // this wave's pieces of step j have landed
             derive_x8(smem + (j & 1) * STAGE);
+            if (mask_pending) { mask_commit(); mask_pending = false; }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                // ... and its derived / computed planes are written
             STAMP(s1);
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             STAMP(s2);
+            const bool first_chunk = c == 0;
+            const Tile tj = t;
             if (j + 1 < J && !(a.ablate & 1)) {
                 if (++c == a.nch) {
                     c = 0; ++kt;
                     t = tile_of(a, lw + kt * G);
-                    if constexpr (F1) f1_window(t); else plan_tile(a, t, lw8, lane, goff);
+                    if constexpr (F1) f1_window(t); else plan_tile<GRAD>(a, t, lw8, lane, goff);
                 }
                 issue_dma<F1>(a, t.n, t.cb, c, smem + ((j + 1) & 1) * STAGE, lw8, lane, goff);
                 f1_chunk(c, smem + ((j + 1) & 1) * STAGE);
             }
+            if (GRAD && first_chunk) mask_issue(tj);
             STAMP(s3);
             t_wait += s1 - s0; t_bar += s2 - s1; t_dma += s3 - s2;
         }
@@ -316,7 +380,8 @@ __global__ __launch_bounds__(NT) void conv3x3_pl_kernel(const PlArgs a) {
 #endif
     Tile cur = tile_of(a, lw);
     f32x16 acc[2][2];
-    const int sc_a = hh ? WSU_F8_SCALE_WLO : WSU_F8_SCALE_W, sc_b = hh ? WSU_F8_SCALE_X : WSU_F8_SCALE_XLO;
+    const int sc_a = hh ? WSU_F8_SCALE_WLO : WSU_F8_SCALE_W;
+    const int sc_b = GRAD ? (hh ? WSU_F8_SCALE_G : WSU_F8_SCALE_GLO) : (hh ? WSU_F8_SCALE_X : WSU_F8_SCALE_XLO);
     int c = 0, kt = 0;                                                        // chunk inside the tile, tile counter
     for (int j = 0; j < J; ++j) {
         // ---- step j: its DMA (issued by the loaders one step ago) has had a whole matrix section to land -----------------------
@@ -435,8 +500,26 @@ _Pragma("unroll")
                 for (int cp = 0; cp < 2; ++cp) {                               // 16 output channels = accumulator groups g4 = 2cp, 2cp+1
                     const int oc = cur.cb * 4 + m * 2 + cp;
                     const int co0 = oc * 16 + 4 * hh;                          // this lane: channels co0..co0+3 (X) and co0+8..co0+11 (Y)
-                    const f32x4 bx = *reinterpret_cast<const f32x4*>(s_bias + co0), by = *reinterpret_cast<const f32x4*>(s_bias + co0 + 8);
                     f32x4 vx[2], vy[2];
+                    if constexpr (GRAD) {
+                        const bool d1 = oc < a.nco1;                           // wave-uniform
+                        const bool masked = (d1 ? a.mask : a.mask2) != nullptr;
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            unsigned mx = 0xFu, my = 0xFu;
+                            if (masked) {
+                                const int pix = (2 * wv + q) * 32 + l31;
+                                mx = s_mask[((m * 2 + cp) * 2 + 0) * 512 + pix] >> (4 * hh);
+                                my = s_mask[((m * 2 + cp) * 2 + 1) * 512 + pix] >> (4 * hh);
+                            }
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                vx[q][e] = ((mx >> e) & 1u) ? acc[m][q][8 * cp + e] : 0.f;
+                                vy[q][e] = ((my >> e) & 1u) ? acc[m][q][8 * cp + 4 + e] : 0.f;
+                            }
+                        }
+                    } else {
+                    const f32x4 bx = *reinterpret_cast<const f32x4*>(s_bias + co0), by = *reinterpret_cast<const f32x4*>(s_bias + co0 + 8);
 #pragma unroll
                     for (int q = 0; q < 2; ++q) {
 #pragma unroll
@@ -446,6 +529,7 @@ _Pragma("unroll")
                             vx[q][e] = x; vy[q][e] = y;
                             vmax = fmaxf(vmax, fmaxf(fabsf(x), fabsf(y)));
                         }
+                    }
                     }
                     if constexpr (HEAD) {
                         const int lc = (m * 2 + cp) * 16 + 4 * hh;             // channel inside the 64-wide block
@@ -462,8 +546,8 @@ _Pragma("unroll")
                     // SGPR-base form and the epilogue carries no 64-bit address registers (it sits at the 168-register step)
                     auto store_px = [&](const f32x4& X, const f32x4& Y, char* base, uint32_t off, uint32_t plane_bytes, bool ok) __attribute__((always_inline)) {
                         uint32_t xh0, xh1, xlo, yh0, yh1, ylo;
-                        wsu_split4_f16r8(X, WSU_F8_XLO_DIV, xh0, xh1, xlo);
-                        wsu_split4_f16r8(Y, WSU_F8_XLO_DIV, yh0, yh1, ylo);
+                        wsu_split4_f16r8(X, GRAD ? WSU_F8_GLO_DIV : WSU_F8_XLO_DIV, xh0, xh1, xlo);
+                        wsu_split4_f16r8(Y, GRAD ? WSU_F8_GLO_DIV : WSU_F8_XLO_DIV, yh0, yh1, ylo);
                         swap32(xh0, yh0); swap32(xh1, yh1);                     // lanes 0-31: f16 ch 0-7, lanes 32-63: f16 ch 8-15
                         uint32_t xlp = xlo, ylp = ylo;
                         swap32(xlo, xlp); swap32(ylo, ylp);                     // lanes 0-31: xlp / ylp = the partner lane's residuals (ch 4-7 / 12-15)
@@ -472,6 +556,16 @@ _Pragma("unroll")
                             if (!hh) *reinterpret_cast<u32x4*>(base + off + 2 * plane_bytes) = mk_u4(xlo, xlp, ylo, ylp);
                         }
                     };
+                    if constexpr (GRAD) {
+                        const bool d1 = oc < a.nco1;
+                        char* base = d1 ? a.y + (((size_t)cur.n * a.nco1 + oc) * HBM_PLANES) * hw * 16
+                                        : a.y2 + (((size_t)cur.n * (nco - a.nco1) + (oc - a.nco1)) * HBM_PLANES) * hw * 16;
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const int row = cur.y0 + 2 * wv + q;
+                            store_px(vx[q], vy[q], base, (uint32_t)(row * a.w + col) * 16u, (uint32_t)hw * 16u, row < a.h && col < a.w);
+                        }
+                    } else
                     if (a.y) {
 #pragma unroll
                         for (int q = 0; q < 2; ++q) {
@@ -523,7 +617,7 @@ _Pragma("unroll")
                 }
             }
             // beyond +-448 the e4m3 residual saturates (plain f16 accuracy), beyond +-65504 the f16 part overflows: tell the caller once
-            if (a.range_flag && (a.y || POOL) && __builtin_amdgcn_ballot_w64(!(vmax <= WSU_F8_RANGE)) != 0 && lane == 0)
+            if (!GRAD && a.range_flag && (a.y || POOL) && __builtin_amdgcn_ballot_w64(!(vmax <= WSU_F8_RANGE)) != 0 && lane == 0)
                 atomicOr(a.range_flag, 1u);
             ++kt;
             c = 0;
@@ -545,7 +639,7 @@ _Pragma("unroll")
 }
 
 // one place that knows the instantiations: attributes once, then the variant the arguments select
-int pl_launch(PlArgs a, bool first, hipStream_t s) {
+int pl_launch(PlArgs a, bool first, hipStream_t s, bool grad = false) {
     static int ablate = -1;
     if (ablate < 0) { const char* e = getenv("WSU_PL_ABLATE"); ablate = e ? atoi(e) : 0; }
     a.ablate = ablate;
@@ -555,7 +649,7 @@ int pl_launch(PlArgs a, bool first, hipStream_t s) {
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
             wsu_set_error("conv3x3_pl: cannot query the device"); return WSU_ERR_HIP;
         }
-        const void* fns[7] = {reinterpret_cast<const void*>(&conv3x3_pl_kernel<0, false>), reinterpret_cast<const void*>(&conv3x3_pl_kernel<0, true>),
+        const void* fns[8] = {reinterpret_cast<const void*>(&conv3x3_pl_kernel<0, false, true, false, true>),reinterpret_cast<const void*>(&conv3x3_pl_kernel<0, false>), reinterpret_cast<const void*>(&conv3x3_pl_kernel<0, true>),
                               reinterpret_cast<const void*>(&conv3x3_pl_kernel<1, false>), reinterpret_cast<const void*>(&conv3x3_pl_kernel<4, false>),
                               reinterpret_cast<const void*>(&conv3x3_pl_kernel<0, false, false>),
                               reinterpret_cast<const void*>(&conv3x3_pl_kernel<0, false, true, true>), reinterpret_cast<const void*>(&conv3x3_pl_kernel<0, true, true, true>)};
@@ -567,7 +661,8 @@ int pl_launch(PlArgs a, bool first, hipStream_t s) {
     }
     const int grid = a.ntiles < ncu ? a.ntiles : ncu;
     const dim3 g(grid), b(NT);
-    if (first) {
+    if (grad) hipLaunchKernelGGL((conv3x3_pl_kernel<0, false, true, false, true>), g, b, LDS_TOTAL, s, a);
+    else if (first) {
         if (a.ypool) hipLaunchKernelGGL((conv3x3_pl_kernel<0, true, true, true>), g, b, LDS_TOTAL, s, a);
         else hipLaunchKernelGGL((conv3x3_pl_kernel<0, false, true, true>), g, b, LDS_TOTAL, s, a);
     } else if (a.head_w && a.head_cout == 1) hipLaunchKernelGGL((conv3x3_pl_kernel<1, false>), g, b, LDS_TOTAL, s, a);
@@ -617,6 +712,7 @@ int wsu_conv3x3_pl_fwd(const void* x1, const void* x2, const void* w_packed, con
     WSU_REQUIRE(nt > 0 && nt < 0x3FFFFFFFLL, "conv3x3_pl: %lld tiles out of range", nt);
     a.ntiles = (int)nt;
     a.img = nullptr; a.w1 = nullptr; a.b1 = nullptr;
+    a.y2 = nullptr; a.nco1 = cout / 16; a.mask = nullptr; a.mask2 = nullptr; a.imgs_per_wset = 0; a.wset_bytes = 0;
     return pl_launch(a, false, static_cast<hipStream_t>(stream));
 }
 
@@ -642,7 +738,68 @@ int wsu_conv3x3_pl_fused_first_fwd(const float* img, const float* w1, const floa
     const long long nt = (long long)n * a.tiles_x * a.tiles_y * a.ncb;
     WSU_REQUIRE(nt > 0 && nt < 0x3FFFFFFFLL, "conv3x3_pl_fused_first: %lld tiles out of range", nt);
     a.ntiles = (int)nt;
+    a.y2 = nullptr; a.nco1 = cout / 16; a.mask = nullptr; a.mask2 = nullptr; a.imgs_per_wset = 0; a.wset_bytes = 0;
     return pl_launch(a, true, static_cast<hipStream_t>(stream));
+}
+
+// K7p: data gradient of the 3x3 reflect conv on planar tensors (autograd of unet.py:141-189).  g: the pre-activation gradient, cout channels,
+// planar with the gradient encodings (power-of-two scaled, model/autograd.py); w_packed_dgrad from wsu_conv3x3_pack_dgrad(mode F16F8);
+// dx1 gets input channels [0, csplit), dx2 (optional, fused concat) the rest; mask1 / mask2 (optional): planar ACTIVATIONS shaped like dx1 /
+// dx2 whose sign is the ReLU mask of the layer that produced that input (relu'(0) = 0).  pad_zero = 0: reflect padding -- the border ring of
+// the adjoint runs as one more launch over strips of g's border rows / columns with the weight sets of wsu_conv3x3_pack_ring (w_packed_ring)
+// in `workspace` (wsu_conv3x3_pl_bwd_data_workspace_bytes); pad_zero = 1: zero padding (ring arguments unused).
+size_t wsu_conv3x3_pl_bwd_data_workspace_bytes(int n, int h, int w, int cin, int cout) {
+    if (n <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0) return 0;
+    const size_t L = (size_t)(h > w ? h : w);
+    return (size_t)4 * n * (L + 2) * 3 * (size_t)(cin + cout);
+}
+
+int wsu_ring_gather_pl(const void* g, void* strips, int n, int h, int w, int c, int L, void* stream);
+int wsu_ring_fold_pl(const void* strips_out, void* dx1, void* dx2, const void* mask1, const void* mask2,
+                     int n, int h, int w, int cin, int csplit, int L, void* stream);
+
+int wsu_conv3x3_pl_bwd_data(const void* g, const void* w_packed_dgrad, const void* w_packed_ring, void* workspace, size_t workspace_bytes,
+                            void* dx1, void* dx2, int csplit, const void* mask1, const void* mask2,
+                            int n, int h, int w, int cin, int cout, int pad_zero, void* stream) {
+    WSU_REQUIRE(g && w_packed_dgrad && dx1, "conv3x3_pl_bwd_data: null pointer");
+    WSU_REQUIRE(n > 0 && h >= 2 && w >= 2, "conv3x3_pl_bwd_data: bad shape n=%d h=%d w=%d", n, h, w);
+    WSU_REQUIRE(cout >= 32 && cout % 16 == 0, "conv3x3_pl_bwd_data: cout=%d must be a multiple of 16 (>= 32)", cout);
+    WSU_REQUIRE(cin > 0 && cin % WSU_COB == 0 && cin <= 1024, "conv3x3_pl_bwd_data: cin=%d must be a multiple of %d (<= 1024)", cin, WSU_COB);
+    WSU_REQUIRE(csplit > 0 && csplit <= cin && csplit % WSU_COB == 0 && (csplit < cin) == (dx2 != nullptr), "conv3x3_pl_bwd_data: csplit=%d (cin=%d) must be a multiple of %d, dx2 given iff csplit < cin", csplit, cin, WSU_COB);
+    WSU_REQUIRE(!mask2 || dx2, "conv3x3_pl_bwd_data: mask2 without dx2");
+    WSU_REQUIRE((long long)h * w * 4 < 0x7FFFFFFFLL, "conv3x3_pl_bwd_data: h*w too large");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    PlArgs a;
+    a.x1 = (const char*)g; a.x2 = nullptr; a.wp = (const char*)w_packed_dgrad; a.bias = nullptr;
+    a.y = (char*)dx1; a.ypool = nullptr; a.y2 = (char*)dx2; a.nco1 = csplit / 16; a.mask = (const char*)mask1; a.mask2 = (const char*)mask2;
+    a.head_w = nullptr; a.head_b = nullptr; a.head_out = nullptr; a.head_logit = nullptr; a.head_cout = 0;
+    a.range_flag = nullptr; a.xres = 1; a.img = nullptr; a.w1 = nullptr; a.b1 = nullptr;
+    a.imgs_per_wset = 0; a.wset_bytes = 0;
+    a.n = n; a.h = h; a.w = w; a.c1 = cout; a.c2 = 0; a.cout = cin;
+    a.tiles_x = (w + TW - 1) / TW; a.tiles_y = (h + TH - 1) / TH; a.ncb = cin / WSU_COB;
+    a.nch1 = cout / 16; a.nch = cout / 16; a.relu = 0;
+    const long long nt = (long long)n * a.tiles_x * a.tiles_y * a.ncb;
+    WSU_REQUIRE(nt > 0 && nt < 0x3FFFFFFFLL, "conv3x3_pl_bwd_data: %lld tiles out of range", nt);
+    a.ntiles = (int)nt;
+    int rc = pl_launch(a, false, s, true);
+    if (rc || pad_zero) return rc;
+    // ---- reflect adjoint: what the padded border ring folds back (train_pl.hip) ----
+    WSU_REQUIRE(w_packed_ring && workspace, "conv3x3_pl_bwd_data: reflect padding needs the ring weights and a workspace");
+    WSU_REQUIRE(workspace_bytes >= wsu_conv3x3_pl_bwd_data_workspace_bytes(n, h, w, cin, cout), "conv3x3_pl_bwd_data: workspace of %zu bytes too small", workspace_bytes);
+    const int L = h > w ? h : w;
+    char* strips_in = (char*)workspace;
+    char* strips_out = strips_in + (size_t)4 * n * (L + 2) * 3 * cout;
+    rc = wsu_ring_gather_pl(g, strips_in, n, h, w, cout, L, stream);
+    if (rc) return rc;
+    PlArgs r = a;
+    r.x1 = strips_in; r.wp = (const char*)w_packed_ring; r.y = strips_out; r.y2 = nullptr; r.nco1 = cin / 16; r.mask = nullptr; r.mask2 = nullptr;
+    r.imgs_per_wset = 1; r.wset_bytes = (size_t)cin * cout * 9 * 4;
+    r.n = 4; r.h = n; r.w = L + 2;
+    r.tiles_x = (r.w + TW - 1) / TW; r.tiles_y = (r.h + TH - 1) / TH;
+    r.ntiles = 4 * r.tiles_x * r.tiles_y * r.ncb;
+    rc = pl_launch(r, false, s, true);
+    if (rc) return rc;
+    return wsu_ring_fold_pl(strips_out, dx1, dx2, mask1, mask2, n, h, w, cin, csplit, L, stream);
 }
 
 }  // extern "C"

@@ -90,6 +90,12 @@ typedef __attribute__((ext_vector_type(8))) int i32x8;
 #define WSU_F8_SCALE_X 129
 #define WSU_F8_SCALE_W 121
 #define WSU_F8_SCALE_WLO 109
+// gradients (pre-scaled by a power of two so that max |dL/dout| lies in (2, 4], model/autograd.py):
+//   g_lo8 = e4m3((g - f16 g) * 2^14) -> 113      g8 = e4m3(g * 4) -> 125
+#define WSU_F8_GLO_DIV 0x1p-14f
+#define WSU_F8_G_DIV 0.25f
+#define WSU_F8_SCALE_GLO 113
+#define WSU_F8_SCALE_G 125
 #define WSU_F8_RANGE 448.f             // |x| beyond this: the e4m3 residual (x - f16 x) * 2^12 saturates -> plain f16 accuracy for that value
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
@@ -143,6 +149,18 @@ __device__ __forceinline__ u32x2 wsu_f16x8_to_fp8(const u32x4& h) {
     lo = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(lo, __builtin_shufflevector(c, c, 2, 3), WSU_F8_X_DIV, true);
     hi = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(hi, __builtin_shufflevector(c, c, 4, 5), WSU_F8_X_DIV, false);
     hi = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(hi, __builtin_shufflevector(c, c, 6, 7), WSU_F8_X_DIV, true);
+    return mk_u2(__builtin_bit_cast(uint32_t, lo), __builtin_bit_cast(uint32_t, hi));
+}
+// the same for a stored GRADIENT granule: e4m3(g * 4)
+__device__ __forceinline__ u32x2 wsu_f16x8_to_fp8_grad(const u32x4& h) {
+    const _Float16 m = (_Float16)112.f;
+    const f16x8 lim = {m, m, m, m, m, m, m, m};
+    const f16x8 c = __builtin_elementwise_max(__builtin_elementwise_min(__builtin_bit_cast(f16x8, h), lim), -lim);
+    i16x2 lo = {0, 0}, hi = {0, 0};
+    lo = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(lo, __builtin_shufflevector(c, c, 0, 1), WSU_F8_G_DIV, false);
+    lo = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(lo, __builtin_shufflevector(c, c, 2, 3), WSU_F8_G_DIV, true);
+    hi = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(hi, __builtin_shufflevector(c, c, 4, 5), WSU_F8_G_DIV, false);
+    hi = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(hi, __builtin_shufflevector(c, c, 6, 7), WSU_F8_G_DIV, true);
     return mk_u2(__builtin_bit_cast(uint32_t, lo), __builtin_bit_cast(uint32_t, hi));
 }
 // hi*hi on the f16 pipe; (a8, b8) = {block 0: e4m3(w) x residual(x), block 1: residual(w) x e4m3(x)} on the block-scaled fp8 pipe.

@@ -339,6 +339,37 @@ def conv3x3_first_pl(x_nchw: torch.Tensor, w: torch.Tensor, bias: Optional[torch
     return y
 
 
+def pack_conv3x3_ring(w: torch.Tensor) -> torch.Tensor:
+    """The four border-ring weight sets of the planar data gradient (wsu_conv3x3_pack_ring)."""
+    lib = _lib.load()
+    w = w.detach()
+    _dev_check(w)
+    cout, cin = w.shape[:2]
+    out = torch.empty(4 * lib.wsu_conv3x3_packed_bytes(cin, cout, MODE_F16F8), dtype=torch.uint8, device=w.device)
+    check(lib.wsu_conv3x3_pack_ring(w.data_ptr(), out.data_ptr(), cin, cout, _stream()), "wsu_conv3x3_pack_ring")
+    return out
+
+
+def conv3x3_pl_bwd_data(g: torch.Tensor, w_packed_dgrad: torch.Tensor, w_packed_ring: Optional[torch.Tensor], cin: int, csplit: int,
+                        mask1: Optional[torch.Tensor] = None, mask2: Optional[torch.Tensor] = None, pad_zero: bool = False):
+    """Data gradient of the 3x3 conv on planar tensors (wsu_conv3x3_pl_bwd_data).  g: planar gradient (N, Cout/16, 3, H, W, 4); returns
+    dx1 (csplit channels) and dx2 (cin - csplit channels, or None), planar gradients."""
+    lib = _lib.load()
+    _dev_check(g, w_packed_dgrad, w_packed_ring, mask1, mask2)
+    assert g.dtype == torch.float32 and g.dim() == 6 and g.shape[2] == PLANAR_PLANES and g.is_contiguous()
+    n, nch, _, h, w, _ = g.shape
+    cout = nch * 16
+    dx1 = torch.empty(planar_shape(n, csplit, h, w), dtype=torch.float32, device=g.device)
+    dx2 = torch.empty(planar_shape(n, cin - csplit, h, w), dtype=torch.float32, device=g.device) if csplit < cin else None
+    nbytes = 0 if pad_zero else lib.wsu_conv3x3_pl_bwd_data_workspace_bytes(n, h, w, cin, cout)
+    ws = workspace(nbytes, g.device) if nbytes else None
+    meta = {"flops": 2.0 * 9 * cin * cout * n * h * w, "bytes": float(n * h * w * (cin * 5 + cout * 3))}
+    check(_launch("conv3x3_pl_bwd_data", meta, lambda: lib.wsu_conv3x3_pl_bwd_data(
+        g.data_ptr(), w_packed_dgrad.data_ptr(), _ptr(w_packed_ring), _ptr(ws), 0 if ws is None else ws.numel() * 4,
+        dx1.data_ptr(), _ptr(dx2), csplit, _ptr(mask1), _ptr(mask2), n, h, w, cin, cout, int(pad_zero), _stream())), "wsu_conv3x3_pl_bwd_data")
+    return dx1, dx2
+
+
 def pack_conv3x3_wino(w: torch.Tensor) -> torch.Tensor:
     """OIHW fp32 -> Winograd F(2,3) packed weights of wsu_conv3x3_wino_fwd (mode bf16x3)."""
     lib = _lib.load()
