@@ -156,6 +156,16 @@ int wsu_conv3x3_pl_bwd_data(const void* g, const void* w_packed_dgrad, const voi
                             void* dx1, void* dx2, int csplit, const void* mask1, const void* mask2,
                             int n, int h, int w, int cin, int cout, int pad_zero, void* stream);
 
+/* ---- K7p: weight / bias gradients on PLANAR operands (csrc/wgrad.hip wgrad_pl_kernel: the split-K MFMA GEMM over pixels of
+ *      wsu_conv3x3_bwd_weight with planar staging -- one stored f16 granule + half a residual granule per (pixel, 8 channels), no split arithmetic).
+ *      conv: g (cout channels, planar gradient), x1 / x2 (the layer's saved planar inputs, c1 / c2 channels), dw (cout, c1 + c2, 3, 3), db (cout) or
+ *      NULL (sum of the decoded gradient values, fixed order).  Transposed conv: x (cin channels at h x w), dy (cout channels, planar gradient at
+ *      2h x 2w), dw (cin, cout, 2, 2).  All channel counts multiples of 64; workspace >= wsu_wgrad_workspace_bytes.  Deterministic. */
+int wsu_conv3x3_pl_bwd_weight(const void* g, const void* x1, const void* x2, float* dw, float* db, float* workspace, size_t workspace_bytes,
+                              int n, int h, int w, int c1, int c2, int cout, void* stream);
+int wsu_convt2x2_pl_bwd_weight(const void* x, const void* dy, float* dw, float* workspace, size_t workspace_bytes,
+                               int n, int h, int w, int cin, int cout, void* stream);
+
 /* ---- K3p / K0p: the other two kernels of the planar (F16F8P) inference path (csrc/planar.hip).
  *      wsu_convt2x2_pl_fwd: nn.ConvTranspose2d(k2, s2) + bias (unet.py:125,130,177,183), x: cin channels at (h, w) planar -> y: cout channels at
  *      (2h, 2w) planar; weights from wsu_convt2x2_pack(mode F16F8); cin a multiple of 32, cout of 64.

@@ -70,3 +70,39 @@ def test_conv3x3_pl_bwd_data(n, h, w, cin, csplit, cout, masked, pad_zero):
     assert float((got - ref).abs().max()) < 2e-3 * float(ref.abs().max())
     if masked:
         assert float(got[(act <= 0)].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("n,h,w,c1,c2,cout", [
+    (2, 16, 32, 64, 0, 64),
+    (1, 37, 70, 64, 0, 128),            # partial tiles, several tiles per image column (rolling row window)
+    (2, 24, 40, 64, 64, 64),            # fused concat
+    (3, 10, 33, 128, 0, 64),
+])
+def test_conv3x3_pl_bwd_weight(n, h, w, c1, c2, cout):
+    ops = _ops()
+    cin = c1 + c2
+    x = _q(torch.relu(_rand((n, cin, h, w), 5)), 4096.0)
+    g = _q(_rand((n, cout, h, w), 6), GRAD_LO)
+    wgt = torch.zeros((cout, cin, 3, 3), requires_grad=True)
+    b = torch.zeros(cout, requires_grad=True)
+    F.conv2d(F.pad(x, (1, 1, 1, 1), mode="reflect"), wgt, b).backward(g)
+    x1 = planar_encode(x[:, :c1])
+    x2 = planar_encode(x[:, c1:]) if c2 else None
+    dw, db = ops.conv3x3_pl_bwd_weight(planar_encode(g, GRAD_LO), x1, x2)
+    torch.cuda.synchronize()
+    assert rel_l2(dw.cpu(), wgt.grad) < REL_L2, rel_l2(dw.cpu(), wgt.grad)
+    assert rel_l2(db.cpu(), b.grad) < 2e-6, rel_l2(db.cpu(), b.grad)
+    dw2, _ = ops.conv3x3_pl_bwd_weight(planar_encode(g, GRAD_LO), x1, x2)
+    assert torch.equal(dw, dw2)                                        # fixed-order reduction
+
+
+@pytest.mark.parametrize("n,h,w,cin,cout", [(2, 8, 32, 64, 64), (1, 13, 40, 128, 64), (2, 5, 7, 64, 128)])
+def test_convt2x2_pl_bwd_weight(n, h, w, cin, cout):
+    ops = _ops()
+    x = _q(torch.relu(_rand((n, cin, h, w), 7)), 4096.0)
+    dy = _q(_rand((n, cout, 2 * h, 2 * w), 8), GRAD_LO)
+    wgt = torch.zeros((cin, cout, 2, 2), requires_grad=True)
+    F.conv_transpose2d(x, wgt, stride=2).backward(dy)
+    dw = ops.convt2x2_pl_bwd_weight(planar_encode(x), planar_encode(dy, GRAD_LO))
+    torch.cuda.synchronize()
+    assert rel_l2(dw.cpu(), wgt.grad) < REL_L2, rel_l2(dw.cpu(), wgt.grad)

@@ -427,6 +427,215 @@ __global__ __launch_bounds__(NT, 2) void wgrad_x3_kernel(const WgArgs a) {
     }
 }
 
+// ---- PLANAR operands (mode F16F8P training path): the same workgroup shape, LDS images, matrix section and partial slabs as
+// wgrad_x3_kernel<KIND, true>, but U / V arrive in the planar three-plane layout ([n][C/16][3][H][W][16 B]: f16 ch 0-7 | f16 ch 8-15 | e4m3
+// residuals; gradients with the 2^14 residual scaling): a staging item = (pixel, 8-channel group) is one stored 16-byte f16 granule + 8 bytes
+// of the residual granule -- no fp32 loads, no split arithmetic (the e4m3 copies are 3 instructions per pair from the f16 granule), and
+// consecutive lanes fetch consecutive pixels of one plane (contiguous 512-byte runs).  The bias gradient (KIND 0) is the sum of the DECODED
+// gradient values, accumulated per thread and 8-channel group while staging (fixed order -> deterministic).
+struct WgPlArgs {
+    const char* u; const char* v1; const char* v2;
+    float* part; float* bpart;
+    int n, hu, wu, cu, cv1, cv2;
+    int tiles_x, tiles_y, ntiles, nsplit, nmb, nnb, tiles_per_split;
+};
+
+template <int KIND>
+__global__ __launch_bounds__(NT, 2) void wgrad_pl_kernel(const WgPlArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using G = GeoX3<KIND>;
+    constexpr int NTAPS = G::NTAPS, TH = G::TH, VH = G::VH, VW = G::VW;
+    char* u_hi = smem;
+    char* u_lo = smem + G::U_BYTES;                        // e4m3 copy image, then (u_l8) the residual image
+    char* u_l8 = u_lo + G::U8_BYTES;
+    char* v_hi = smem + G::U_BYTES + 2 * G::U8_BYTES;
+    char* v_lo = v_hi + G::V_BYTES;
+    char* v_l8 = v_lo + G::V8_BYTES;
+    constexpr bool UGRAD = KIND == 0;                      // which operand is the gradient
+
+    const int tid = threadIdx.x;
+    int b = blockIdx.x;
+    const int nb = b % a.nnb; b /= a.nnb;
+    const int mb = b % a.nmb;
+    const int split = b / a.nmb;
+    const int hv = KIND == 0 ? a.hu : 2 * a.hu, wv = KIND == 0 ? a.wu : 2 * a.wu;
+    const char* vsrc; int cv, vch0;
+    if (nb * 64 < a.cv1) { vsrc = a.v1; cv = a.cv1; vch0 = nb * 64; }
+    else                 { vsrc = a.v2; cv = a.cv2; vch0 = nb * 64 - a.cv1; }
+    const size_t hwu = (size_t)a.hu * a.wu, hwv = (size_t)hv * wv;
+
+    const int wv_ = tid >> 6, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+    const int wm = wv_ >> 1, wn = wv_ & 1;
+    const int colA = (wm * 32 + ((lane >> 4) & 1) * 16) * 2;
+    const int colB = (wn * 32 + ((lane >> 4) & 1) * 16) * 2;
+    f32x16 acc[NTAPS];
+#pragma unroll
+    for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    constexpr bool ROLL = KIND == 0;
+    // staging items: thread = (8-channel group cg = tid >> 5, pixel lane tid & 31); its k-th item is pixel (tid & 31) + 32 k of the (sub)tile --
+    // 32 consecutive lanes fetch 32 consecutive pixels of one plane, and a thread keeps ONE channel group (8 bias sums)
+    constexpr int U_IT = G::U_PIX / 32;                                // 2 (KIND 0), 1 (KIND 1)
+    constexpr int VN_ROW0 = ROLL ? VH - TH : 0;
+    constexpr int VN_PIX = (VH - VN_ROW0) * VW;                        // 68 (KIND 0), 128 (KIND 1)
+    constexpr int VN_IT = (VN_PIX + 31) / 32;                          // 3 (KIND 0), 4 (KIND 1)
+    constexpr int V_IT = (G::V_PIX + 31) / 32;                         // 5 (KIND 0), 4 (KIND 1)
+    static_assert(NT == 256 && G::U_PIX % 32 == 0, "8 channel groups x 32 pixel lanes");
+    const int scg = tid >> 5, spx = tid & 31;
+    const bool bias_on = KIND == 0 && a.bpart != nullptr && nb == 0;
+    float bs[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bs[e] = 0.f;
+
+    struct Item { u32x4 h; u32x2 r; };
+    Item pu[U_IT], pv[VN_IT];
+    bool have_pref = false;
+    int rot = 0;
+
+    const int t0 = split * a.tiles_per_split;
+    const int t1 = min(t0 + a.tiles_per_split, a.ntiles);
+    auto decode = [&](int tile, int& n, int& y0, int& x0) __attribute__((always_inline)) {
+        int tt = tile;
+        if (ROLL) { const int ty = tt % a.tiles_y; tt /= a.tiles_y; const int tx = tt % a.tiles_x; n = tt / a.tiles_x; y0 = ty * TH; x0 = tx * TW; }
+        else      { const int tx = tt % a.tiles_x; tt /= a.tiles_x; const int ty = tt % a.tiles_y; n = tt / a.tiles_y; y0 = ty * TH; x0 = tx * TW; }
+    };
+    auto u_load = [&](int n, int y0, int x0, int p) __attribute__((always_inline)) {
+        const int cg = scg, r = p / TW, c = p % TW;
+        Item it; it.h = mk_u4(0, 0, 0, 0); it.r = mk_u2(0, 0);
+        if (y0 + r < a.hu && x0 + c < a.wu) {
+            const char* base = a.u + (((size_t)n * (a.cu >> 4) + mb * 4 + (cg >> 1)) * 3) * hwu * 16 + ((size_t)(y0 + r) * a.wu + x0 + c) * 16;
+            it.h = *reinterpret_cast<const u32x4*>(base + (cg & 1) * hwu * 16);
+            it.r = *reinterpret_cast<const u32x2*>(base + 2 * hwu * 16 + (cg & 1) * 8);
+        }
+        return it;
+    };
+    auto v_load = [&](int n, int y0, int x0, int p, int cg) __attribute__((always_inline)) {
+        const int r = p / VW, c = p % VW;
+        int yy, xx;
+        if (KIND == 0) { yy = wsu_reflect(y0 - 1 + r, hv); xx = wsu_reflect(x0 - 1 + c, wv); }
+        else           { yy = min(2 * y0 + r, hv - 1);     xx = min(2 * x0 + c, wv - 1); }
+        const char* base = vsrc + (((size_t)n * (cv >> 4) + (vch0 >> 4) + (cg >> 1)) * 3) * hwv * 16 + ((size_t)yy * wv + xx) * 16;
+        Item it;
+        it.h = *reinterpret_cast<const u32x4*>(base + (cg & 1) * hwv * 16);
+        it.r = *reinterpret_cast<const u32x2*>(base + 2 * hwv * 16 + (cg & 1) * 8);
+        return it;
+    };
+    auto put = [&](char* hi, char* c8, char* l8, int p, int cg, const Item& it, bool grad) __attribute__((always_inline)) {
+        *reinterpret_cast<u32x4*>(hi + p * X3_ROW + cg * 16) = it.h;
+        *reinterpret_cast<u32x2*>(c8 + p * F8_ROW + cg * 8) = grad ? wsu_f16x8_to_fp8_grad(it.h) : wsu_f16x8_to_fp8(it.h);
+        *reinterpret_cast<u32x2*>(l8 + p * F8_ROW + cg * 8) = it.r;
+    };
+    auto bias_add = [&](float (&s)[8], const Item& it) __attribute__((always_inline)) {
+        const f16x8 hv8 = __builtin_bit_cast(f16x8, it.h);
+        const int r0 = (int)it.r.x, r1 = (int)it.r.y;
+        s[0] += (float)hv8[0] + __builtin_amdgcn_cvt_f32_fp8(r0, 0) * WSU_F8_GLO_DIV;
+        s[1] += (float)hv8[1] + __builtin_amdgcn_cvt_f32_fp8(r0, 1) * WSU_F8_GLO_DIV;
+        s[2] += (float)hv8[2] + __builtin_amdgcn_cvt_f32_fp8(r0, 2) * WSU_F8_GLO_DIV;
+        s[3] += (float)hv8[3] + __builtin_amdgcn_cvt_f32_fp8(r0, 3) * WSU_F8_GLO_DIV;
+        s[4] += (float)hv8[4] + __builtin_amdgcn_cvt_f32_fp8(r1, 0) * WSU_F8_GLO_DIV;
+        s[5] += (float)hv8[5] + __builtin_amdgcn_cvt_f32_fp8(r1, 1) * WSU_F8_GLO_DIV;
+        s[6] += (float)hv8[6] + __builtin_amdgcn_cvt_f32_fp8(r1, 2) * WSU_F8_GLO_DIV;
+        s[7] += (float)hv8[7] + __builtin_amdgcn_cvt_f32_fp8(r1, 3) * WSU_F8_GLO_DIV;
+    };
+
+    for (int tile = t0; tile < t1; ++tile) {
+        int n, y0, x0;
+        decode(tile, n, y0, x0);
+        __syncthreads();
+        if (!have_pref) {
+            rot = 0;
+#pragma unroll
+            for (int k = 0; k < U_IT; ++k) {
+                const int p = spx + 32 * k;
+                const Item it = u_load(n, y0, x0, p);
+                if (bias_on) bias_add(bs, it);
+                put(u_hi, u_lo, u_l8, p, scg, it, UGRAD);
+            }
+#pragma unroll
+            for (int k = 0; k < V_IT; ++k) {
+                const int p = spx + 32 * k;
+                if (p < G::V_PIX) put(v_hi, v_lo, v_l8, p, scg, v_load(n, y0, x0, p, scg), !UGRAD);
+            }
+        } else {
+            if (ROLL) rot = (rot + TH) & (VH - 1);
+#pragma unroll
+            for (int k = 0; k < U_IT; ++k) {
+                if (bias_on) bias_add(bs, pu[k]);
+                put(u_hi, u_lo, u_l8, spx + 32 * k, scg, pu[k], UGRAD);
+            }
+#pragma unroll
+            for (int k = 0; k < VN_IT; ++k) {
+                const int pn = spx + 32 * k;
+                if (pn < VN_PIX) {
+                    const int rn = pn / VW, c = pn % VW;
+                    const int slot = (VN_ROW0 + rn + rot) & (VH - 1);
+                    put(v_hi, v_lo, v_l8, slot * VW + c, scg, pv[k], !UGRAD);
+                }
+            }
+        }
+        __syncthreads();
+        {
+            have_pref = tile + 1 < t1 && (!ROLL || (tile + 1) % a.tiles_y != 0);
+            if (have_pref) {
+                int n2, y2, x2;
+                decode(tile + 1, n2, y2, x2);
+#pragma unroll
+                for (int k = 0; k < U_IT; ++k) pu[k] = u_load(n2, y2, x2, spx + 32 * k);
+#pragma unroll
+                for (int k = 0; k < VN_IT; ++k) {
+                    const int pn = spx + 32 * k;
+                    if (pn < VN_PIX) pv[k] = v_load(n2, y2, x2, VN_ROW0 * VW + pn, scg);
+                }
+            }
+        }
+        {
+            const int colA8 = wm * 32 + ((lane >> 4) & 1) * 16, colB8 = wn * 32 + ((lane >> 4) & 1) * 16;
+            constexpr int SU8 = UGRAD ? WSU_F8_SCALE_G : WSU_F8_SCALE_X, SUL = UGRAD ? WSU_F8_SCALE_GLO : WSU_F8_SCALE_XLO;
+            constexpr int SV8 = UGRAD ? WSU_F8_SCALE_X : WSU_F8_SCALE_G, SVL = UGRAD ? WSU_F8_SCALE_XLO : WSU_F8_SCALE_GLO;
+            const int sc_a = hh ? SUL : SU8, sc_b = hh ? SV8 : SVL;
+#pragma unroll 1
+            for (int r = 0; r < TH; ++r) {
+                const u32x4 a8 = f8_frag(u_lo, r * TW + 16 * hh, 1, colA8), al8 = f8_frag(u_l8, r * TW + 16 * hh, 1, colA8);
+                const u32x4 ah0 = x3_frag(u_hi, r * TW + 8 * hh, 1, colA), ah1 = x3_frag(u_hi, r * TW + 16 + 8 * hh, 1, colA);
+#pragma unroll
+                for (int t = 0; t < NTAPS; ++t) {
+                    int vrow, vstep;
+                    if (KIND == 0) { vrow = ((r + t / 3 + rot) & (VH - 1)) * VW + t % 3; vstep = 1; }
+                    else           { vrow = (2 * r + (t >> 1)) * VW + (t & 1); vstep = 2; }
+                    const u32x4 bl8 = f8_frag(v_l8, vrow + vstep * 16 * hh, vstep, colB8), b8 = f8_frag(v_lo, vrow + vstep * 16 * hh, vstep, colB8);
+                    wsu_mfma_f8x2(a8, al8, bl8, b8, sc_a, sc_b, acc[t]);
+                    const u32x4 bh0 = x3_frag(v_hi, vrow + vstep * 8 * hh, vstep, colB), bh1 = x3_frag(v_hi, vrow + vstep * (16 + 8 * hh), vstep, colB);
+                    wsu_mfma_f16(ah0, bh0, acc[t]);
+                    wsu_mfma_f16(ah1, bh1, acc[t]);
+                }
+            }
+        }
+    }
+    float* dst = a.part + ((size_t)((split * a.nmb + mb) * a.nnb + nb) * NTAPS) * 4096;
+#pragma unroll
+    for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            dst[(size_t)t * 4096 + m * 64 + wn * 32 + l31] = acc[t][r];
+        }
+    if (bias_on) {                                                     // uniform per workgroup
+        float* red = reinterpret_cast<float*>(smem);                   // [256 threads][8]: the 32 threads of a channel group meet here
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[tid * 8 + e] = bs[e];
+        __syncthreads();
+        if (tid < 64) {
+            const int cg = tid >> 3, e = tid & 7;
+            float sum = 0.f;
+            for (int j = 0; j < 32; ++j) sum += red[(cg * 32 + j) * 8 + e];
+            a.bpart[(size_t)split * (a.nmb * 64) + mb * 64 + tid] = sum;
+        }
+    }
+}
+
 // dW (conv: OIHW [M = co][Ntot = ci][3][3]; convT: IOHW [M = ci][Ntot = co][2][2]) = sum over splits, fixed order
 template <int KIND>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bpart,
@@ -545,9 +754,66 @@ int run_wgrad(WgArgs a, float* dw, float* db, float* workspace, size_t workspace
     return wsu_check_launch("wgrad_reduce_kernel");
 }
 
+template <int KIND>
+int run_wgrad_pl(WgPlArgs a, float* dw, float* db, float* workspace, size_t workspace_bytes, hipStream_t s) {
+    using G = Geo<KIND>;
+    a.tiles_x = (a.wu + TW - 1) / TW; a.tiles_y = (a.hu + G::TH - 1) / G::TH;
+    a.ntiles = a.n * a.tiles_x * a.tiles_y;
+    a.nmb = a.cu / 64; a.nnb = (a.cv1 + a.cv2) / 64;
+    int nsplit = (512 + a.nmb * a.nnb - 1) / (a.nmb * a.nnb);
+    nsplit = max(1, min(nsplit, a.ntiles));
+    const size_t slab = (size_t)a.nmb * a.nnb * G::NTAPS * 4096 * sizeof(float);
+    const size_t bslab = (size_t)a.nmb * 64 * sizeof(float);
+    while (nsplit > 1 && nsplit * (slab + bslab) > workspace_bytes) --nsplit;
+    if (nsplit * (slab + bslab) > workspace_bytes) {
+        wsu_set_error("wgrad_pl: workspace of %zu bytes too small (need >= %zu)", workspace_bytes, slab + bslab);
+        return WSU_ERR_ARG;
+    }
+    a.nsplit = nsplit;
+    a.tiles_per_split = (a.ntiles + nsplit - 1) / nsplit;
+    a.part = workspace;
+    a.bpart = (db && KIND == 0) ? workspace + (size_t)nsplit * slab / sizeof(float) : nullptr;
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_pl_kernel<KIND>), hipFuncAttributeMaxDynamicSharedMemorySize, GeoX3<KIND>::LDS_F8);
+        if (e != hipSuccess) { wsu_set_error("hipFuncSetAttribute(wgrad_pl): %s", hipGetErrorString(e)); return WSU_ERR_HIP; }
+        attr = true;
+    }
+    hipLaunchKernelGGL(wgrad_pl_kernel<KIND>, dim3(nsplit * a.nmb * a.nnb), dim3(NT), GeoX3<KIND>::LDS_F8, s, a);
+    int rc = wsu_check_launch("wgrad_pl_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(wgrad_reduce_kernel<KIND>, dim3(512), dim3(256), 0, s, a.part, (const float*)a.bpart, dw, a.bpart ? db : (float*)nullptr, nsplit, a.nmb, a.nnb);
+    return wsu_check_launch("wgrad_reduce_kernel");
+}
+
 }  // namespace
 
 extern "C" {
+
+// K7p weight / bias gradients on PLANAR operands (layout and gradient encodings: wsu.h).  Conv: g (cout channels, gradient), x1 / x2 (the
+// layer's saved planar input(s)), dw (cout, c1 + c2, 3, 3), db (cout) or NULL.  Transposed conv: x (cin, at h x w), dy (cout, gradient, at
+// 2h x 2w), dw (cin, cout, 2, 2); its bias gradient is wsu_colsum_pl (train_pl.hip).  Channel counts multiples of 64.  Workspace:
+// wsu_wgrad_workspace_bytes.  Deterministic.
+int wsu_conv3x3_pl_bwd_weight(const void* g, const void* x1, const void* x2, float* dw, float* db, float* workspace, size_t workspace_bytes,
+                              int n, int h, int w, int c1, int c2, int cout, void* stream) {
+    WSU_REQUIRE(g && x1 && dw && workspace, "conv3x3_pl_bwd_weight: null pointer");
+    WSU_REQUIRE(n > 0 && h >= 2 && w >= 2, "conv3x3_pl_bwd_weight: bad shape");
+    WSU_REQUIRE(c1 > 0 && c1 % 64 == 0 && c2 >= 0 && c2 % 64 == 0 && (c2 == 0) == (x2 == nullptr), "conv3x3_pl_bwd_weight: c1=%d c2=%d must be multiples of 64", c1, c2);
+    WSU_REQUIRE(cout > 0 && cout % 64 == 0, "conv3x3_pl_bwd_weight: cout=%d must be a multiple of 64", cout);
+    WgPlArgs a{};
+    a.u = (const char*)g; a.v1 = (const char*)x1; a.v2 = (const char*)x2; a.n = n; a.hu = h; a.wu = w; a.cu = cout; a.cv1 = c1; a.cv2 = c2;
+    return run_wgrad_pl<0>(a, dw, db, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+}
+
+int wsu_convt2x2_pl_bwd_weight(const void* x, const void* dy, float* dw, float* workspace, size_t workspace_bytes,
+                               int n, int h, int w, int cin, int cout, void* stream) {
+    WSU_REQUIRE(x && dy && dw && workspace, "convt2x2_pl_bwd_weight: null pointer");
+    WSU_REQUIRE(n > 0 && h > 0 && w > 0, "convt2x2_pl_bwd_weight: bad shape");
+    WSU_REQUIRE(cin > 0 && cin % 64 == 0 && cout > 0 && cout % 64 == 0, "convt2x2_pl_bwd_weight: cin=%d cout=%d must be multiples of 64", cin, cout);
+    WgPlArgs a{};
+    a.u = (const char*)x; a.v1 = (const char*)dy; a.v2 = nullptr; a.n = n; a.hu = h; a.wu = w; a.cu = cin; a.cv1 = cout; a.cv2 = 0;
+    return run_wgrad_pl<1>(a, dw, nullptr, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+}
 
 size_t wsu_wgrad_workspace_bytes(int cm, int cn, int ntaps) {
     // room for up to 512 partial slabs' worth of workgroups: ceil(512 / blocks) splits, each (cm/64)(cn/64) slabs

@@ -370,6 +370,38 @@ def conv3x3_pl_bwd_data(g: torch.Tensor, w_packed_dgrad: torch.Tensor, w_packed_
     return dx1, dx2
 
 
+def conv3x3_pl_bwd_weight(g: torch.Tensor, x1: torch.Tensor, x2: Optional[torch.Tensor], want_bias: bool = True):
+    """Weight / bias gradient of the 3x3 conv on planar operands (wsu_conv3x3_pl_bwd_weight): g planar gradient, x1 / x2 planar inputs."""
+    lib = _lib.load()
+    _dev_check(g, x1, x2)
+    n, nco, _, h, w, _ = g.shape
+    cout, c1 = nco * 16, x1.shape[1] * 16
+    c2 = 0 if x2 is None else x2.shape[1] * 16
+    dw = torch.empty((cout, c1 + c2, 3, 3), dtype=torch.float32, device=g.device)
+    db = torch.empty(cout, dtype=torch.float32, device=g.device) if want_bias else None
+    ws = workspace(lib.wsu_wgrad_workspace_bytes(cout, c1 + c2, 9), g.device)
+    meta = {"flops": 2.0 * 9 * (c1 + c2) * cout * n * h * w, "bytes": float(n * h * w * 3 * (cout * ((c1 + c2) // 64) + (c1 + c2) * (cout // 64)))}
+    check(_launch("conv3x3_pl_bwd_weight", meta, lambda: lib.wsu_conv3x3_pl_bwd_weight(
+        g.data_ptr(), x1.data_ptr(), _ptr(x2), dw.data_ptr(), _ptr(db), ws.data_ptr(), ws.numel() * 4,
+        n, h, w, c1, c2, cout, _stream())), "wsu_conv3x3_pl_bwd_weight")
+    return dw, db
+
+
+def convt2x2_pl_bwd_weight(x: torch.Tensor, dy: torch.Tensor):
+    """Weight gradient of the transposed conv on planar operands: x planar input (N, Cin/16, 3, h, w, 4), dy planar gradient at (2h, 2w)."""
+    lib = _lib.load()
+    _dev_check(x, dy)
+    n, nci, _, h, w, _ = x.shape
+    cin, cout = nci * 16, dy.shape[1] * 16
+    assert dy.shape[3] == 2 * h and dy.shape[4] == 2 * w
+    dw = torch.empty((cin, cout, 2, 2), dtype=torch.float32, device=x.device)
+    ws = workspace(lib.wsu_wgrad_workspace_bytes(cin, cout, 4), x.device)
+    meta = {"flops": 2.0 * 4 * cin * cout * n * h * w}
+    check(_launch("convt2x2_pl_bwd_weight", meta, lambda: lib.wsu_convt2x2_pl_bwd_weight(
+        x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), ws.numel() * 4, n, h, w, cin, cout, _stream())), "wsu_convt2x2_pl_bwd_weight")
+    return dw
+
+
 def pack_conv3x3_wino(w: torch.Tensor) -> torch.Tensor:
     """OIHW fp32 -> Winograd F(2,3) packed weights of wsu_conv3x3_wino_fwd (mode bf16x3)."""
     lib = _lib.load()
