@@ -166,6 +166,29 @@ int wsu_conv3x3_pl_bwd_weight(const void* g, const void* x1, const void* x2, flo
 int wsu_convt2x2_pl_bwd_weight(const void* x, const void* dy, float* dw, float* workspace, size_t workspace_bytes,
                                int n, int h, int w, int cin, int cout, void* stream);
 
+/* ---- K7p: the other backward kernels of the planar training path (csrc/planar.hip, csrc/train_pl.hip; autograd of unet.py:137-189).
+ *      wsu_convt2x2_pl_bwd_data: dx[n,i,j,ci] = sum dy[n,2i+a,2j+b,co] w[ci,co,a,b] times the ReLU mask of the layer below (mask: the planar
+ *        ACTIVATION the transposed conv consumed, optional); dy (cout channels at 2h x 2w) and dx (cin at h x w) planar gradients; weights from
+ *        wsu_convt2x2_pl_pack_dgrad (cin * cout * 16 bytes); cin a multiple of 64, cout of 16.
+ *      wsu_maxpool2x2_pl_bwd: g = (skip_g + routing of dy_pool onto the first maximum of each 2x2 window) * (act > 0); act = the stored activation
+ *        the pool consumed (the argmax is recomputed from it); skip_g optional; g may alias skip_g.
+ *      wsu_conv1x1_sigmoid_pl_bwd: head backward (unet.py:186-188): x planar activation (c in {16..128}), w (cout <= 4, c), out / dout (N, cout, H, W)
+ *        fp32 -> g (planar gradient w.r.t. the pre-activation of the layer that produced x), dw (cout, c), db (cout).
+ *      wsu_colsum_pl: per-channel sums of a planar gradient (bias gradient of the transposed conv).
+ *      wsu_conv3x3_first_pl_bwd_weight: first layer, single input plane: dw (c, 1, 3, 3), db (c) from the planar gradient g and img (N, 1, H, W).
+ *      All reductions are two-stage with a fixed order (deterministic). */
+int wsu_convt2x2_pl_pack_dgrad(const float* w_iohw, void* w_packed, int cin, int cout, void* stream);
+int wsu_convt2x2_pl_bwd_data(const void* dy, const void* w_packed_dgrad, void* dx, const void* mask,
+                             int n, int h, int w, int cin, int cout, void* stream);
+int wsu_maxpool2x2_pl_bwd(const void* skip_g, const void* dy_pool, const void* act, void* g, int n, int h, int w, int c, void* stream);
+size_t wsu_head_pl_bwd_workspace_bytes(int c, int cout);
+int wsu_conv1x1_sigmoid_pl_bwd(const void* x, const float* w, const float* out, const float* dout, void* g, float* dw, float* db,
+                               float* workspace, size_t workspace_bytes, int n, int h, int wd, int c, int cout, void* stream);
+size_t wsu_chansum_pl_workspace_bytes(int c);
+int wsu_colsum_pl(const void* g, float* db, float* workspace, size_t workspace_bytes, int n, int h, int w, int c, void* stream);
+int wsu_conv3x3_first_pl_bwd_weight(const void* g, const float* img, float* dw, float* db, float* workspace, size_t workspace_bytes,
+                                    int n, int h, int w, int c, void* stream);
+
 /* ---- K3p / K0p: the other two kernels of the planar (F16F8P) inference path (csrc/planar.hip).
  *      wsu_convt2x2_pl_fwd: nn.ConvTranspose2d(k2, s2) + bias (unet.py:125,130,177,183), x: cin channels at (h, w) planar -> y: cout channels at
  *      (2h, 2w) planar; weights from wsu_convt2x2_pack(mode F16F8); cin a multiple of 32, cout of 64.

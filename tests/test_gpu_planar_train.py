@@ -9,7 +9,10 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from gpu_util import DEV, GRAD_LO, planar_decode, planar_encode
+import math
+
+from gpu_util import DEV, GRAD_LO, gpu_model, planar_decode, planar_encode
+from ws_unet_amd import formula, losses
 
 pytestmark = pytest.mark.gpu
 
@@ -106,3 +109,130 @@ def test_convt2x2_pl_bwd_weight(n, h, w, cin, cout):
     dw = ops.convt2x2_pl_bwd_weight(planar_encode(x), planar_encode(dy, GRAD_LO))
     torch.cuda.synchronize()
     assert rel_l2(dw.cpu(), wgt.grad) < REL_L2, rel_l2(dw.cpu(), wgt.grad)
+
+
+@pytest.mark.parametrize("n,h,w,cin,cout,masked", [(2, 8, 32, 64, 64, True), (1, 13, 40, 128, 64, True), (2, 5, 7, 64, 32, False), (1, 4, 64, 256, 128, True)])
+def test_convt2x2_pl_bwd_data(n, h, w, cin, cout, masked):
+    ops = _ops()
+    wgt = _rand((cin, cout, 2, 2), 9, (1.0 / cin) ** 0.5)
+    dy = _q(_rand((n, cout, 2 * h, 2 * w), 10), GRAD_LO)
+    act = torch.relu(_rand((n, cin, h, w), 11))
+    x = torch.zeros((n, cin, h, w), requires_grad=True)
+    F.conv_transpose2d(x, wgt, stride=2).backward(dy)
+    ref = x.grad * (act > 0) if masked else x.grad
+    wp = ops.pack_convt2x2_pl_dgrad(wgt.to(DEV))
+    dx = ops.convt2x2_pl_bwd_data(planar_encode(dy, GRAD_LO), wp, cin, planar_encode(act) if masked else None)
+    torch.cuda.synchronize()
+    got = planar_decode(dx, GRAD_LO)
+    assert rel_l2(got, ref) < REL_L2, rel_l2(got, ref)
+    assert float((got - ref).abs().max()) < 2e-3 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("with_skip", [True, False])
+def test_maxpool2x2_pl_bwd(with_skip):
+    ops = _ops()
+    n, c, h, w = 2, 32, 12, 20
+    act = _q(torch.relu(_rand((n, c, h, w), 12)), 4096.0)
+    act[0, :, 0:2, 0:2] = 0.0                                           # an all-zero window: nothing is routed
+    act[0, :, 2:4, 2:4] = 1.5                                           # a tie: the first position wins
+    skip = _q(_rand((n, c, h, w), 13), GRAD_LO)
+    dyp = _q(_rand((n, c, h // 2, w // 2), 14), GRAD_LO)
+    a = act.clone().requires_grad_(True)
+    F.max_pool2d(a, 2).backward(dyp)
+    ref = (a.grad + (skip if with_skip else 0)) * (act > 0)
+    g = ops.maxpool2x2_pl_bwd(planar_encode(skip, GRAD_LO) if with_skip else None, planar_encode(dyp, GRAD_LO), planar_encode(act))
+    torch.cuda.synchronize()
+    got = planar_decode(g, GRAD_LO)
+    assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-7     # one re-encoding of an fp32 sum
+    assert float(got[0, :, 0:2, 0:2].abs().max()) == 0.0
+
+
+def test_head_and_first_layer_pl_bwd():
+    ops = _ops()
+    n, c, h, w = 2, 64, 24, 40
+    x = _q(torch.relu(_rand((n, c, h, w), 15)), 4096.0)
+    wh = _rand((1, c, 1, 1), 16, 0.2).requires_grad_(True)
+    bh = torch.zeros(1, requires_grad=True)
+    xa = x.clone().requires_grad_(True)
+    out = torch.sigmoid(F.conv2d(xa, wh, bh))
+    dout = _rand((n, 1, h, w), 17, 3.0)
+    out.backward(dout)
+    g, dw, db = ops.conv1x1_sigmoid_pl_bwd(planar_encode(x), wh.detach().to(DEV), out.detach().to(DEV), dout.to(DEV))
+    torch.cuda.synchronize()
+    ref_g = xa.grad * (x > 0)
+    assert rel_l2(planar_decode(g, GRAD_LO), ref_g) < 3e-5
+    assert rel_l2(dw.cpu(), wh.grad) < 1e-5 and rel_l2(db.cpu(), bh.grad) < 1e-5
+    # per-channel sums and the first layer's weight gradient from the same planar gradient
+    gq = planar_decode(g, GRAD_LO)
+    assert rel_l2(ops.colsum_pl(g).cpu(), gq.sum(dim=(0, 2, 3))) < 2e-6
+    img = torch.rand((n, 1, h, w), generator=torch.Generator().manual_seed(18))
+    w1 = torch.zeros((c, 1, 3, 3), requires_grad=True)
+    b1 = torch.zeros(c, requires_grad=True)
+    F.conv2d(F.pad(img, (1, 1, 1, 1), mode="reflect"), w1, b1).backward(gq)
+    dw1, db1 = ops.conv3x3_first_pl_bwd_weight(g, img.to(DEV))
+    torch.cuda.synchronize()
+    assert rel_l2(dw1.cpu(), w1.grad) < 1e-5 and rel_l2(db1.cpu(), b1.grad) < 2e-6
+
+
+@pytest.fixture(scope="module")
+def grad_golden():
+    import os
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", "unet_grad.npz"))
+
+
+@pytest.mark.parametrize("ns", [0, 1, 2])
+def test_unet_gradients_golden_planar(grad_golden, ns):
+    """train_mode 'f16f8p' end to end against the reference's autograd golden (tests/golden/make_golden.py: L1WS on 2x1x64x64 pairs):
+    planar activations and gradients, the bands of test_gpu_backward.py::test_unet_gradients_golden for the split arithmetics."""
+    ops = _ops()
+    g = grad_golden
+    model = gpu_model(ns, "he", "f16f8p")
+    model.train_mode = "f16f8p"
+    cov_u8 = formula.synthetic_images(2, 64, 64, seed=11)
+    st_u8 = cov_u8.copy(); st_u8[0] = formula.lsbr_embed(cov_u8[0], 0.4, seed=5)
+    covers = torch.from_numpy(cov_u8.astype(np.float32) / np.float32(255.))[:, None].to(DEV)
+    inputs = torch.from_numpy(st_u8.astype(np.float32) / np.float32(255.))[:, None].to(DEV)
+    alphas = torch.tensor([0.4, 0.0], device=DEV)
+    timer = ops.KernelTimer()
+    ops.set_timer(timer)
+    try:
+        out = model(inputs)
+        loss = losses.L1WSLoss()(out, (covers, alphas), inputs)
+        loss.backward()
+        torch.cuda.synchronize()
+    finally:
+        ops.set_timer(None)
+    used = timer.summary()
+    assert "conv3x3_pl_bwd_data" in used and "conv3x3_pl_bwd_weight" in used and "conv3x3_bwd_data" not in used     # the planar path ran
+    assert math.isclose(loss.item(), float(g[f"grad{ns}_loss"][0]), rel_tol=1e-5)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), g[f"grad{ns}_out"], atol=1e-4, rtol=0)
+    for k, p in model.named_parameters():
+        got = p.grad.detach().cpu().numpy().reshape(-1)
+        ref = g[f"grad{ns}_{k}_sub"]
+        if not (ns == 0 or got.size <= 4096):
+            got = got[::97]
+        scale = float(np.abs(ref).max())
+        np.testing.assert_allclose(got, ref, rtol=0, atol=1.5e-2 * scale + 1e-12, err_msg=f"unet_{ns} {k}")
+        full = p.grad.detach().double().cpu().numpy()
+        assert math.isclose(float(np.sqrt((full ** 2).sum())), g[f"grad{ns}_{k}_sum"][2], rel_tol=8e-3), k
+    first = {k: p.grad.clone() for k, p in model.named_parameters()}
+    model.zero_grad()
+    losses.L1WSLoss()(model(inputs), (covers, alphas), inputs).backward()
+    for k, p in model.named_parameters():
+        assert torch.equal(p.grad, first[k]), k                        # deterministic
+
+
+def test_planar_vs_fp32_storage_gradients_smooth_loss():
+    """The two training paths of one model under a smooth (L2) loss at 2x1x128x128: same arithmetic class, different storage -- every parameter
+    gradient agrees to a relative L2 of 1e-3 (ReLU-mask flips on rounding noise are the floor; test_gpu_backward_large.py)."""
+    model = gpu_model(2, "he", "f16f8p")
+    x = torch.rand((2, 1, 128, 128), generator=torch.Generator().manual_seed(3)).to(DEV)
+    tgt = torch.rand((2, 1, 128, 128), generator=torch.Generator().manual_seed(4)).to(DEV)
+    res = {}
+    for tm in ("f32", "f16f8p"):
+        model.train_mode = tm
+        model.zero_grad()
+        ((model(x) - tgt) ** 2).mean().backward()
+        res[tm] = {k: p.grad.detach().double().cpu() for k, p in model.named_parameters()}
+    for k in res["f32"]:
+        assert rel_l2(res["f16f8p"][k], res["f32"][k]) < 2e-3, (k, rel_l2(res["f16f8p"][k], res["f32"][k]))

@@ -18,10 +18,10 @@ __device__ __forceinline__ void swap32(uint32_t& upper_of, uint32_t& lower_of) {
 
 // X, Y = 4 + 4 values of one pixel (channels c0 + 4 hh .. and c0 + 8 + 4 hh ..; hh = lane >> 5): encode, gather whole 16-byte granules into
 // single lanes (conv3x3_pl.hip) and store the chunk's three planes (f16 | f16 | residuals): every instruction writes contiguous runs of 32 lanes x 16 B.
-__device__ __forceinline__ void store_chunk_px(const f32x4& X, const f32x4& Y, char* dst, size_t plane_bytes, int hh, bool ok) {
+__device__ __forceinline__ void store_chunk_px(const f32x4& X, const f32x4& Y, char* dst, size_t plane_bytes, int hh, bool ok, float div_lo = WSU_F8_XLO_DIV) {
     uint32_t xh0, xh1, xlo, yh0, yh1, ylo;
-    wsu_split4_f16r8(X, WSU_F8_XLO_DIV, xh0, xh1, xlo);
-    wsu_split4_f16r8(Y, WSU_F8_XLO_DIV, yh0, yh1, ylo);
+    wsu_split4_f16r8(X, div_lo, xh0, xh1, xlo);
+    wsu_split4_f16r8(Y, div_lo, yh0, yh1, ylo);
     swap32(xh0, yh0); swap32(xh1, yh1);
     uint32_t xlp = xlo, ylp = ylo;
     swap32(xlo, xlp); swap32(ylo, ylp);                                  // lanes 0-31 collect all 16 residuals of the chunk
@@ -227,6 +227,195 @@ __global__ __launch_bounds__(ct::NT) void convt2x2_pl_kernel(const CtpArgs a) {
 }
 
 // =====================================================================================================================================
+// K7p.  Data gradient of the transposed conv (autograd of unet.py:177,183):  dx[n, i, j, ci] = sum_{a,b,co} dy[n, 2i+a, 2j+b, co] * w[ci, co, a, b],
+// times the ReLU mask of the layer below.  GEMM M = 64 ci, N = 4 x 32 input-resolution pixels, K = 4 sub-positions x Cout; persistent
+// workgroup per CU: 8 matrix waves (32 ci x one tile row each) + 8 loader waves (the kernel is DMA-issue / HBM bound: 40 pieces per chunk).
+// The dy tile (8 x 64 output pixels) arrives DE-INTERLEAVED -- each DMA lane fetches pixel (2 (y0 + r) + a, 2 (x0 + c) + b), so the LDS image is
+// [plane][sub-position][128 px][16 B] and every B-operand read is a contiguous 512 bytes.  Weights [sub][plane][64 ci][16 B] per chunk from
+// wsu_convt2x2_pl_pack_dgrad.  Gradient encodings in and out (wsu_device.h).
+// =====================================================================================================================================
+namespace ctb {
+constexpr int TW = 32, TH = 4, NPIX = TW * TH;
+constexpr int IN1 = 4 * 4 * NPIX * 16;                    // 32768: [plane 4][sub 4][128 px][16 B]
+constexpr int W1 = 4 * 4 * WSU_COB * 16;                  // 16384: [sub 4][plane 4][64 ci][16 B]
+constexpr int STAGE = IN1 + W1;                           // 49152
+constexpr int LDS_TOTAL = 2 * STAGE;
+constexpr int NWAVE = 8, NLOAD = 8, NT = (NWAVE + NLOAD) * 64;
+constexpr int IN_SLOTS = 3 * 4 * 2, W_SLOTS = W1 / 1024;  // 24 + 16 pieces per chunk
+constexpr int PER = (IN_SLOTS + W_SLOTS) / NLOAD;         // 5
+static_assert((IN_SLOTS + W_SLOTS) % NLOAD == 0, "DMA pieces divide over the loader waves");
+}
+
+struct CtbPlArgs {
+    const char* dy; const char* wp; char* dx; const char* mask;
+    int n, h, w, cin, cout;
+    int tiles_x, tiles_y, ncb, nch, ntiles;
+};
+
+__device__ __forceinline__ CtTile ctb_tile_of(const CtbPlArgs& a, int t) {
+    CtTile r;
+    r.cb = t % a.ncb; t /= a.ncb;
+    const int tx = t % a.tiles_x; t /= a.tiles_x;
+    const int ty = t % a.tiles_y;
+    r.n = t / a.tiles_y; r.y0 = ty * ctb::TH; r.x0 = tx * ctb::TW;
+    return r;
+}
+
+__device__ __forceinline__ void ctb_issue_dma(const CtbPlArgs& a, const CtTile& t, int c, char* st, int lw8, int lane) {
+    using namespace ctb;
+    const int oh = 2 * a.h, ow = 2 * a.w;
+    const size_t ohw = (size_t)oh * ow;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int slot = lw8 + NLOAD * k;
+        if (slot < IN_SLOTS) {
+            const int plane = slot >> 3, sub = (slot >> 1) & 3, seg = slot & 1;
+            const int pix = seg * 64 + lane;
+            const int oy = min(2 * (t.y0 + pix / TW) + (sub >> 1), oh - 1), ox = min(2 * (t.x0 + pix % TW) + (sub & 1), ow - 1);
+            const char* src = a.dy + ((((size_t)t.n * a.nch + c) * 3 + plane) * ohw + (size_t)oy * ow + ox) * 16;
+            __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(st + ((plane * 4 + sub) * NPIX + seg * 64) * 16), 16, 0, 0);
+        } else {
+            const int piece = slot - IN_SLOTS;
+            const char* src = a.wp + ((size_t)t.cb * a.nch + c) * W1 + piece * 1024 + lane * 16;
+            __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(st + IN1 + piece * 1024), 16, 0, 0);
+        }
+    }
+}
+
+__global__ __launch_bounds__(ctb::NT) void convt2x2_bwd_pl_kernel(const CtbPlArgs a) {
+    using namespace ctb;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+    const int G = gridDim.x;
+    const int lw = (int)wsu_xcd_remap(blockIdx.x, G);
+    const int K = a.ntiles > lw ? (a.ntiles - lw + G - 1) / G : 0;
+    const int J = K * a.nch;
+
+    if (wv >= NWAVE) {
+        const int lw8 = wv - NWAVE;
+        CtTile t = ctb_tile_of(a, lw);
+        if (J > 0) ctb_issue_dma(a, t, 0, smem, lw8, lane);
+        int c = 0, kt = 0;
+        for (int j = 0; j < J; ++j) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            {   // LDS plane 3 = e4m3(g * 4) of the f16 granules this wave fetched
+                char* st = smem + (j & 1) * STAGE;
+#pragma unroll
+                for (int k = 0; k < PER; ++k) {
+                    const int slot = lw8 + NLOAD * k;
+                    const int plane = slot >> 3, sub = (slot >> 1) & 3, seg = slot & 1;
+                    if (slot < IN_SLOTS && plane < 2) {
+                        const int pix = seg * 64 + lane;
+                        const u32x4 hgr = *reinterpret_cast<const u32x4*>(st + ((plane * 4 + sub) * NPIX + pix) * 16);
+                        *reinterpret_cast<u32x2*>(st + ((3 * 4 + sub) * NPIX + pix) * 16 + plane * 8) = wsu_f16x8_to_fp8_grad(hgr);
+                    }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (j + 1 < J) {
+                if (++c == a.nch) { c = 0; ++kt; t = ctb_tile_of(a, lw + kt * G); }
+                ctb_issue_dma(a, t, c, smem + ((j + 1) & 1) * STAGE, lw8, lane);
+            }
+        }
+        return;
+    }
+
+    const int row = wv & 3, mh = wv >> 2;
+    CtTile cur = ctb_tile_of(a, lw);
+    f32x16 acc;
+    const int sc_a = hh ? WSU_F8_SCALE_WLO : WSU_F8_SCALE_W, sc_b = hh ? WSU_F8_SCALE_G : WSU_F8_SCALE_GLO;
+    const size_t hw = (size_t)a.h * a.w;
+    const int nci = a.cin >> 4;
+    u32x2 mk[2][2];                                                      // [chunk-in-wave cp][plane]: this lane's 4 + 4 mask values
+    int c = 0, kt = 0;
+    for (int j = 0; j < J; ++j) {
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const char* st = smem + (j & 1) * STAGE;
+        if (c == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        }
+        const int irow = cur.y0 + row, icol = cur.x0 + l31;
+        if (c + 1 == a.nch && a.mask) {                                  // the tile's mask values travel during its last matrix section
+            const int yy = min(irow, a.h - 1), xx = min(icol, a.w - 1);
+#pragma unroll
+            for (int cp = 0; cp < 2; ++cp)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl)
+                    mk[cp][pl] = *reinterpret_cast<const u32x2*>(a.mask + ((((size_t)cur.n * nci + cur.cb * 4 + mh * 2 + cp) * 3 + pl) * hw + (size_t)yy * a.w + xx) * 16 + hh * 8);
+        }
+        const char* ldsA = st + IN1 + (mh * 32 + l31) * 16;            // + ((sub * 4 + plane) * 64) * 16
+        const char* ldsB = st + (row * TW + l31) * 16;                  // + ((plane * 4 + sub) * NPIX) * 16
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int s = 2 * t + hh;
+            const u32x4 a0 = *reinterpret_cast<const u32x4*>(ldsA + ((s * 4 + 2) * 64) * 16), a1 = *reinterpret_cast<const u32x4*>(ldsA + ((s * 4 + 3) * 64) * 16);
+            const u32x4 b0 = *reinterpret_cast<const u32x4*>(ldsB + ((2 * 4 + s) * NPIX) * 16), b1 = *reinterpret_cast<const u32x4*>(ldsB + ((3 * 4 + s) * NPIX) * 16);
+            wsu_mfma_f8x2(a0, a1, b0, b1, sc_a, sc_b, acc);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int s2 = 2 * t + u;
+                const u32x4 ah = *reinterpret_cast<const u32x4*>(ldsA + ((s2 * 4 + hh) * 64) * 16);
+                const u32x4 bh = *reinterpret_cast<const u32x4*>(ldsB + ((hh * 4 + s2) * NPIX) * 16);
+                wsu_mfma_f16(ah, bh, acc);
+            }
+        }
+        if (c + 1 == a.nch) {
+            const bool ok = irow < a.h && icol < a.w;
+#pragma unroll
+            for (int cp = 0; cp < 2; ++cp) {
+                const int oc = cur.cb * 4 + mh * 2 + cp;
+                f32x4 X, Y;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { X[e] = acc[8 * cp + e]; Y[e] = acc[8 * cp + 4 + e]; }
+                if (a.mask) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {                            // f16 > 0 <=> its bits > 0 as a signed 16-bit integer
+                        const uint32_t wx = e < 2 ? mk[cp][0].x : mk[cp][0].y, wy = e < 2 ? mk[cp][1].x : mk[cp][1].y;
+                        const short hx = (short)((e & 1) ? wx >> 16 : wx & 0xFFFF), hy = (short)((e & 1) ? wy >> 16 : wy & 0xFFFF);
+                        if (!(hx > 0)) X[e] = 0.f;
+                        if (!(hy > 0)) Y[e] = 0.f;
+                    }
+                }
+                char* dst = a.dx + ((((size_t)cur.n * nci + oc) * 3) * hw + (size_t)min(irow, a.h - 1) * a.w + min(icol, a.w - 1)) * 16;
+                store_chunk_px(X, Y, dst, hw * 16, hh, ok, WSU_F8_GLO_DIV);
+            }
+            ++kt; c = 0;
+            if (j + 1 < J) cur = ctb_tile_of(a, lw + kt * G);
+        } else {
+            ++c;
+        }
+    }
+}
+
+// [cb = ci / 64][chunk = co / 16][sub = 2a + b][plane][64 ci][16 B]: planes f16 co 0-7 | f16 co 8-15 | e4m3(w * 2^6) | e4m3((w - f16 w) * 2^18)
+__global__ void pack_convt_dgrad_pl_kernel(const float* __restrict__ w, char* __restrict__ dst, int cin, int cout) {
+    const int nch = cout / 16;
+    const long long total = (long long)(cin / WSU_COB) * nch * 4 * WSU_COB;
+    for (long long d = (long long)blockIdx.x * blockDim.x + threadIdx.x; d < total; d += (long long)gridDim.x * blockDim.x) {
+        long long t = d;
+        const int m = t % WSU_COB; t /= WSU_COB;
+        const int sub = t % 4; t /= 4;
+        const int c = t % nch; const int cb = (int)(t / nch);
+        f32x4 q[4];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) q[e >> 2][e & 3] = w[(((size_t)(cb * WSU_COB + m) * cout + c * 16 + e) * 2 + (sub >> 1)) * 2 + (sub & 1)];
+        uint32_t h[8], l[4], x[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) wsu_split4_f16f8(q[k], WSU_F8_WLO_DIV, WSU_F8_W_DIV, h[2 * k], h[2 * k + 1], l[k], x[k]);
+        char* base = dst + (((size_t)cb * nch + c) * 4 + sub) * (4 * WSU_COB * 16) + m * 16;
+        *reinterpret_cast<u32x4*>(base) = mk_u4(h[0], h[1], h[2], h[3]);
+        *reinterpret_cast<u32x4*>(base + WSU_COB * 16) = mk_u4(h[4], h[5], h[6], h[7]);
+        *reinterpret_cast<u32x4*>(base + 2 * WSU_COB * 16) = mk_u4(x[0], x[1], x[2], x[3]);
+        *reinterpret_cast<u32x4*>(base + 3 * WSU_COB * 16) = mk_u4(l[0], l[1], l[2], l[3]);
+    }
+}
+
+// =====================================================================================================================================
 // K0p.  First layer: y = relu(conv3x3_reflect(x) + b), x (N, cin <= 8, H, W) fp32 NCHW, y planar with cout = 16 k channels.  One thread per
 // pixel (consecutive lanes = consecutive pixels of a row: every store instruction writes 64 x 16 contiguous bytes), 16 output channels at a
 // time from tap-major weights in LDS; fp32 FMAs in the tap order of conv3x3_first_kernel (pointwise.hip), so the values before encoding are
@@ -330,6 +519,43 @@ int wsu_convt2x2_pl_fwd(const void* x, const void* w_packed, const float* bias, 
     const int grid = (int)(nt < ncu ? nt : ncu);
     hipLaunchKernelGGL(convt2x2_pl_kernel, dim3(grid), dim3(ct::NT), ct::LDS_TOTAL, static_cast<hipStream_t>(stream), a);
     return wsu_check_launch("convt2x2_pl_kernel");
+}
+
+// K7p: data gradient of the transposed conv on planar tensors.  dy: cout channels at (2h, 2w), planar gradient; dx: cin channels at (h, w),
+// planar gradient; mask (optional): the planar ACTIVATION the transposed conv consumed (its sign = ReLU mask of the layer below).  Weights from
+// wsu_convt2x2_pl_pack_dgrad (cin * cout * 16 bytes).  cin a multiple of 64, cout of 16.
+int wsu_convt2x2_pl_pack_dgrad(const float* w_iohw, void* w_packed, int cin, int cout, void* stream) {
+    WSU_REQUIRE(w_iohw && w_packed, "convt2x2_pl_pack_dgrad: null pointer");
+    WSU_REQUIRE(cin > 0 && cin % WSU_COB == 0 && cout > 0 && cout % 16 == 0, "convt2x2_pl_pack_dgrad: bad channels cin=%d cout=%d", cin, cout);
+    hipLaunchKernelGGL(pack_convt_dgrad_pl_kernel, dim3(256), dim3(256), 0, static_cast<hipStream_t>(stream), w_iohw, (char*)w_packed, cin, cout);
+    return wsu_check_launch("pack_convt_dgrad_pl_kernel");
+}
+
+int wsu_convt2x2_pl_bwd_data(const void* dy, const void* w_packed_dgrad, void* dx, const void* mask,
+                             int n, int h, int w, int cin, int cout, void* stream) {
+    WSU_REQUIRE(dy && w_packed_dgrad && dx, "convt2x2_pl_bwd_data: null pointer");
+    WSU_REQUIRE(n > 0 && h > 0 && w > 0 && cin > 0 && cin % WSU_COB == 0 && cout > 0 && cout % 16 == 0, "convt2x2_pl_bwd_data: bad shape (cin %% 64, cout %% 16)");
+    WSU_REQUIRE((long long)h * w * 64 < 0x7FFFFFFFLL, "convt2x2_pl_bwd_data: h*w too large");
+    CtbPlArgs a;
+    a.dy = (const char*)dy; a.wp = (const char*)w_packed_dgrad; a.dx = (char*)dx; a.mask = (const char*)mask;
+    a.n = n; a.h = h; a.w = w; a.cin = cin; a.cout = cout;
+    a.tiles_x = (w + ctb::TW - 1) / ctb::TW; a.tiles_y = (h + ctb::TH - 1) / ctb::TH; a.ncb = cin / WSU_COB; a.nch = cout / 16;
+    const long long nt = (long long)n * a.tiles_x * a.tiles_y * a.ncb;
+    WSU_REQUIRE(nt > 0 && nt < 0x3FFFFFFFLL, "convt2x2_pl_bwd_data: %lld tiles out of range", nt);
+    a.ntiles = (int)nt;
+    static int ncu = 0;
+    if (ncu == 0) {
+        int dev = 0; hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+            wsu_set_error("convt2x2_pl_bwd_data: cannot query the device"); return WSU_ERR_HIP;
+        }
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&convt2x2_bwd_pl_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, ctb::LDS_TOTAL);
+        if (e != hipSuccess) { wsu_set_error("hipFuncSetAttribute(convt2x2_bwd_pl): %s", hipGetErrorString(e)); return WSU_ERR_HIP; }
+        ncu = prop.multiProcessorCount;
+    }
+    const int grid = (int)(nt < ncu ? nt : ncu);
+    hipLaunchKernelGGL(convt2x2_bwd_pl_kernel, dim3(grid), dim3(ctb::NT), ctb::LDS_TOTAL, static_cast<hipStream_t>(stream), a);
+    return wsu_check_launch("convt2x2_bwd_pl_kernel");
 }
 
 // K0p: first layer into planar storage.  x_nchw: (N, cin, H, W) fp32, cin 1..8; w_oihw: (cout, cin, 3, 3); cout a multiple of 16 (<= 128).

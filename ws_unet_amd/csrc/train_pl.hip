@@ -132,6 +132,221 @@ __global__ __launch_bounds__(256) void ring_fold_pl_kernel(const char* __restric
     }
 }
 
+// 8 channels of one pixel: f16 granule + its 8 residual bytes -> fp32; and back
+__device__ __forceinline__ void pl_decode8(const u32x4& h, const u32x2& r, float lo_mul, float (&v)[8]) {
+    const f16x8 a = __builtin_bit_cast(f16x8, h);
+    const int r0 = (int)r.x, r1 = (int)r.y;
+    v[0] = (float)a[0] + __builtin_amdgcn_cvt_f32_fp8(r0, 0) * lo_mul; v[1] = (float)a[1] + __builtin_amdgcn_cvt_f32_fp8(r0, 1) * lo_mul;
+    v[2] = (float)a[2] + __builtin_amdgcn_cvt_f32_fp8(r0, 2) * lo_mul; v[3] = (float)a[3] + __builtin_amdgcn_cvt_f32_fp8(r0, 3) * lo_mul;
+    v[4] = (float)a[4] + __builtin_amdgcn_cvt_f32_fp8(r1, 0) * lo_mul; v[5] = (float)a[5] + __builtin_amdgcn_cvt_f32_fp8(r1, 1) * lo_mul;
+    v[6] = (float)a[6] + __builtin_amdgcn_cvt_f32_fp8(r1, 2) * lo_mul; v[7] = (float)a[7] + __builtin_amdgcn_cvt_f32_fp8(r1, 3) * lo_mul;
+}
+__device__ __forceinline__ void pl_encode8(const float (&v)[8], float div_lo, u32x4& h, u32x2& r) {
+    uint32_t h0, h1, h2, h3, l0, l1;
+    wsu_split4_f16r8(mk_f4(v[0], v[1], v[2], v[3]), div_lo, h0, h1, l0);
+    wsu_split4_f16r8(mk_f4(v[4], v[5], v[6], v[7]), div_lo, h2, h3, l1);
+    h = mk_u4(h0, h1, h2, h3); r = mk_u2(l0, l1);
+}
+// addresses of the f16 granule / residual half of 8-channel group cg (of c channels) at pixel pix of image n
+__device__ __forceinline__ const char* pl_h(const char* t, int n, int c, int cg, size_t hw, size_t pix) { return t + pl_off(n, c >> 4, cg >> 1, cg & 1, hw, pix); }
+__device__ __forceinline__ const char* pl_r(const char* t, int n, int c, int cg, size_t hw, size_t pix) { return t + pl_off(n, c >> 4, cg >> 1, 2, hw, pix) + (cg & 1) * 8; }
+
+// ---- 2x2 max-pool backward + skip add + ReLU mask (autograd of unet.py:143-149 with the skip connection of :178,184) -------------------------
+// g[n, c, y, x] = (skip_g[n, c, y, x] + [ (y, x) is the first maximum of its window ] * dyp[n, c, y/2, x/2]) * (a[n, c, y, x] > 0), a = the
+// stored activation the pool consumed.  One thread per (pooled pixel, 8-channel group); the argmax is recomputed from the stored values in the
+// window order (0,0) (0,1) (1,0) (1,1) of nn.MaxPool2d.
+__global__ __launch_bounds__(256) void pool_bwd_pl_kernel(const char* __restrict__ skip_g, const char* __restrict__ dyp, const char* __restrict__ act,
+                                                          char* __restrict__ g, int n, int h, int w, int c) {
+    const int hp = h >> 1, wp = w >> 1, ncg = c >> 3;
+    const size_t hw = (size_t)h * w, hwp = (size_t)hp * wp;
+    const long long total = (long long)n * ncg * hwp;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        long long t = i;
+        const int xp = (int)(t % wp); t /= wp;
+        const int yp = (int)(t % hp); t /= hp;
+        const int cg = (int)(t % ncg); const int img = (int)(t / ncg);
+        float d[8];
+        pl_decode8(*reinterpret_cast<const u32x4*>(pl_h(dyp, img, c, cg, hwp, (size_t)yp * wp + xp)),
+                   *reinterpret_cast<const u32x2*>(pl_r(dyp, img, c, cg, hwp, (size_t)yp * wp + xp)), WSU_F8_GLO_DIV, d);
+        float av[4][8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const size_t pix = (size_t)(2 * yp + (k >> 1)) * w + 2 * xp + (k & 1);
+            pl_decode8(*reinterpret_cast<const u32x4*>(pl_h(act, img, c, cg, hw, pix)), *reinterpret_cast<const u32x2*>(pl_r(act, img, c, cg, hw, pix)), WSU_F8_XLO_DIV, av[k]);
+        }
+        int best[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            int bi = 0; float bv = av[0][e];
+#pragma unroll
+            for (int k = 1; k < 4; ++k) if (av[k][e] > bv) { bv = av[k][e]; bi = k; }
+            best[e] = bi;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const size_t pix = (size_t)(2 * yp + (k >> 1)) * w + 2 * xp + (k & 1);
+            float v[8];
+            if (skip_g) pl_decode8(*reinterpret_cast<const u32x4*>(pl_h(skip_g, img, c, cg, hw, pix)), *reinterpret_cast<const u32x2*>(pl_r(skip_g, img, c, cg, hw, pix)), WSU_F8_GLO_DIV, v);
+            else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if (best[e] == k) v[e] += d[e];
+                if (!(av[k][e] > 0.f)) v[e] = 0.f;
+            }
+            u32x4 hq; u32x2 rq;
+            pl_encode8(v, WSU_F8_GLO_DIV, hq, rq);
+            *reinterpret_cast<u32x4*>(const_cast<char*>(pl_h(g, img, c, cg, hw, pix))) = hq;
+            *reinterpret_cast<u32x2*>(const_cast<char*>(pl_r(g, img, c, cg, hw, pix))) = rq;
+        }
+    }
+}
+
+// ---- 1x1 head + sigmoid backward (autograd of unet.py:186-188): dz = dout * out * (1 - out);  g[c] = (sum_o w[o][c] dz[o]) * (x[c] > 0);
+// dW[o][c] = sum_px dz[o] x[c];  db[o] = sum_px dz[o].  Thread = (pixel lane, 8-channel group); per-block partials, fixed-order reduction. --------
+constexpr int HEADP_MAXCO = 4;
+__global__ __launch_bounds__(256) void head_bwd_pl_kernel(const char* __restrict__ x, const float* __restrict__ wgt, const float* __restrict__ out,
+                                                          const float* __restrict__ dout, char* __restrict__ g, float* __restrict__ part,
+                                                          int n, int hw_, int c, int cout) {
+    const int ncg = c >> 3;                                   // 8 for the reference's 64 channels
+    const int ppb = 256 / ncg;                                // pixels per block pass
+    const int cg = threadIdx.x / ppb, pl = threadIdx.x % ppb;
+    const size_t hw = (size_t)hw_;
+    const long long npix = (long long)n * hw;
+    float wv[HEADP_MAXCO][8], aw[HEADP_MAXCO][8], ab[HEADP_MAXCO];
+#pragma unroll
+    for (int o = 0; o < HEADP_MAXCO; ++o) {
+        ab[o] = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { wv[o][e] = o < cout ? wgt[(size_t)o * c + cg * 8 + e] : 0.f; aw[o][e] = 0.f; }
+    }
+    for (long long p = (long long)blockIdx.x * ppb + pl; p < npix; p += (long long)gridDim.x * ppb) {
+        const int img = (int)(p / hw); const size_t pix = (size_t)(p % hw);
+        float xv[8], gv[8];
+        pl_decode8(*reinterpret_cast<const u32x4*>(pl_h(x, img, c, cg, hw, pix)), *reinterpret_cast<const u32x2*>(pl_r(x, img, c, cg, hw, pix)), WSU_F8_XLO_DIV, xv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) gv[e] = 0.f;
+#pragma unroll
+        for (int o = 0; o < HEADP_MAXCO; ++o)
+            if (o < cout) {
+                const size_t oi = ((size_t)img * cout + o) * hw + pix;
+                const float ov = out[oi];
+                const float dz = dout[oi] * ov * (1.f - ov);
+                ab[o] += dz;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { gv[e] = fmaf(wv[o][e], dz, gv[e]); aw[o][e] = fmaf(xv[e], dz, aw[o][e]); }
+            }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) if (!(xv[e] > 0.f)) gv[e] = 0.f;
+        u32x4 hq; u32x2 rq;
+        pl_encode8(gv, WSU_F8_GLO_DIV, hq, rq);
+        *reinterpret_cast<u32x4*>(const_cast<char*>(pl_h(g, img, c, cg, hw, pix))) = hq;
+        *reinterpret_cast<u32x2*>(const_cast<char*>(pl_r(g, img, c, cg, hw, pix))) = rq;
+    }
+    // block partial: part[block][o][c + 1]
+    __shared__ float red[256 * 9];
+    for (int o = 0; o < cout; ++o) {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[threadIdx.x * 9 + e] = aw[o][e];
+        red[threadIdx.x * 9 + 8] = ab[o];
+        __syncthreads();
+        if (pl == 0) {
+            float sacc[9];
+#pragma unroll
+            for (int e = 0; e < 9; ++e) sacc[e] = 0.f;
+            for (int k = 0; k < ppb; ++k)
+#pragma unroll
+                for (int e = 0; e < 9; ++e) sacc[e] += red[(cg * ppb + k) * 9 + e];
+            float* dst = part + ((size_t)blockIdx.x * cout + o) * (c + 1);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dst[cg * 8 + e] = sacc[e];
+            if (cg == 0) dst[c] = sacc[8];
+        }
+    }
+}
+__global__ void head_bwd_pl_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ db, int nblocks, int c, int cout) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cout * (c + 1)) return;
+    float s = 0.f;
+    for (int b = 0; b < nblocks; ++b) s += part[(size_t)b * cout * (c + 1) + i];
+    const int o = i / (c + 1), k = i % (c + 1);
+    if (k < c) dw[(size_t)o * c + k] = s; else db[o] = s;
+}
+
+// ---- per-channel sums of a planar gradient (bias gradient of the transposed conv) and the first layer's weight gradient (single input plane:
+// dW[co][tap] = sum_px g[co][px] * img[reflect(px + tap)], db[co] = sum_px g[co][px]; unet.py:82,141).  Thread = (pixel lane, 8-channel group);
+// block partials [block][c][NV], reduced in block order. ----------------------------------------------------------------------------------------
+template <bool FIRST>
+__global__ __launch_bounds__(256) void chansum_pl_kernel(const char* __restrict__ g, const float* __restrict__ img, float* __restrict__ part,
+                                                         int n, int h, int w, int c) {
+    constexpr int NV = FIRST ? 10 : 1;                        // 9 taps + bias | the plain sum
+    const int ncg = c >> 3, ppb = 256 / ncg;
+    const int cg = threadIdx.x / ppb, pl = threadIdx.x % ppb;
+    const size_t hw = (size_t)h * w;
+    const long long npix = (long long)n * hw;
+    float acc[NV][8];
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[k][e] = 0.f;
+    for (long long p = (long long)blockIdx.x * ppb + pl; p < npix; p += (long long)gridDim.x * ppb) {
+        const int im = (int)(p / hw); const size_t pix = (size_t)(p % hw);
+        float gv[8];
+        pl_decode8(*reinterpret_cast<const u32x4*>(pl_h(g, im, c, cg, hw, pix)), *reinterpret_cast<const u32x2*>(pl_r(g, im, c, cg, hw, pix)), WSU_F8_GLO_DIV, gv);
+        if constexpr (FIRST) {
+            const int y = (int)(pix / w), x = (int)(pix % w);
+            const float* src = img + (size_t)im * hw;
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) {
+                const float iv = src[(size_t)wsu_reflect(y + tp / 3 - 1, h) * w + wsu_reflect(x + tp % 3 - 1, w)];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[tp][e] = fmaf(gv[e], iv, acc[tp][e]);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[9][e] += gv[e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[0][e] += gv[e];
+        }
+    }
+    __shared__ float red[256 * 8];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[threadIdx.x * 8 + e] = acc[k][e];
+        __syncthreads();
+        if (pl == 0) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float sacc = 0.f;
+                for (int j = 0; j < ppb; ++j) sacc += red[(cg * ppb + j) * 8 + e];
+                part[((size_t)blockIdx.x * c + cg * 8 + e) * NV + k] = sacc;
+            }
+        }
+    }
+}
+// out[i] = sum over blocks of part[b][i], i < count (fixed order)
+__global__ void block_sum_kernel(const float* __restrict__ part, float* __restrict__ out, int nblocks, int count) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    float sacc = 0.f;
+    for (int b = 0; b < nblocks; ++b) sacc += part[(size_t)b * count + i];
+    out[i] = sacc;
+}
+// first layer: [c][10] sums -> dw (c, 1, 3, 3), db (c)
+__global__ void first_split_kernel(const float* __restrict__ sums, float* __restrict__ dw, float* __restrict__ db, int c) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= c * 10) return;
+    const int co = i / 10, k = i % 10;
+    if (k < 9) dw[co * 9 + k] = sums[i]; else if (db) db[co] = sums[i];
+}
+
+constexpr int SUM_BLOCKS = 1024;
+
 inline unsigned grid_for(long long total) { return (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192); }
 
 }  // namespace
@@ -150,3 +365,78 @@ extern "C" int wsu_ring_fold_pl(const void* strips_out, void* dx1, void* dx2, co
                        (const char*)mask1, (const char*)mask2, n, h, w, cin / 16, csplit / 16, L);
     return wsu_check_launch("ring_fold_pl_kernel");
 }
+
+extern "C" {
+
+// K7p: g = (skip_g + max-pool routing of dy_pool) * (act > 0) on planar tensors (layout: wsu.h): skip_g (optional), g at (h, w); dy_pool at (h/2, w/2);
+// act = the stored activation the pool consumed (c channels, multiple of 16; h, w even).  g may alias skip_g.
+int wsu_maxpool2x2_pl_bwd(const void* skip_g, const void* dy_pool, const void* act, void* g, int n, int h, int w, int c, void* stream) {
+    WSU_REQUIRE(dy_pool && act && g, "maxpool2x2_pl_bwd: null pointer");
+    WSU_REQUIRE(n > 0 && h > 0 && w > 0 && h % 2 == 0 && w % 2 == 0 && c > 0 && c % 16 == 0, "maxpool2x2_pl_bwd: bad shape");
+    const long long total = (long long)n * (c / 8) * (h / 2) * (w / 2);
+    hipLaunchKernelGGL(pool_bwd_pl_kernel, dim3(grid_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       (const char*)skip_g, (const char*)dy_pool, (const char*)act, (char*)g, n, h, w, c);
+    return wsu_check_launch("pool_bwd_pl_kernel");
+}
+
+size_t wsu_head_pl_bwd_workspace_bytes(int c, int cout) { return (size_t)SUM_BLOCKS * cout * (c + 1) * sizeof(float); }
+
+// K7p: backward of the 1x1 head + sigmoid: x (planar activation, c channels = the head's input, c in {16, 32, 64, 128}), w (cout, c), out / dout
+// (N, cout, H, W) fp32 (dout pre-scaled like every planar gradient), cout <= 4 -> g (planar gradient w.r.t. the PRE-activation of the layer that produced x:
+// its ReLU mask is applied), dw (cout, c), db (cout).
+int wsu_conv1x1_sigmoid_pl_bwd(const void* x, const float* w, const float* out, const float* dout, void* g, float* dw, float* db,
+                               float* workspace, size_t workspace_bytes, int n, int h, int wd, int c, int cout, void* stream) {
+    WSU_REQUIRE(x && w && out && dout && g && dw && db && workspace, "conv1x1_sigmoid_pl_bwd: null pointer");
+    WSU_REQUIRE(n > 0 && h > 0 && wd > 0 && c >= 16 && c <= 128 && (c & (c - 1)) == 0 && cout >= 1 && cout <= HEADP_MAXCO, "conv1x1_sigmoid_pl_bwd: bad shape c=%d cout=%d", c, cout);
+    WSU_REQUIRE(workspace_bytes >= wsu_head_pl_bwd_workspace_bytes(c, cout), "conv1x1_sigmoid_pl_bwd: workspace too small");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const long long npix = (long long)n * h * wd;
+    const int ppb = 256 / (c / 8);
+    const int nblk = (int)((npix + ppb - 1) / ppb < SUM_BLOCKS ? (npix + ppb - 1) / ppb : SUM_BLOCKS);
+    hipLaunchKernelGGL(head_bwd_pl_kernel, dim3(nblk), dim3(256), 0, s, (const char*)x, w, out, dout, (char*)g, workspace, n, h * wd, c, cout);
+    int rc = wsu_check_launch("head_bwd_pl_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(head_bwd_pl_reduce_kernel, dim3((cout * (c + 1) + 63) / 64), dim3(64), 0, s, workspace, dw, db, nblk, c, cout);
+    return wsu_check_launch("head_bwd_pl_reduce_kernel");
+}
+
+size_t wsu_chansum_pl_workspace_bytes(int c) { return (size_t)(SUM_BLOCKS + 1) * c * 10 * sizeof(float); }
+
+// K7p: db[c] = per-channel sum of a planar gradient (bias gradient of the transposed conv), c in {16, 32, 64, ..., 2048}
+int wsu_colsum_pl(const void* g, float* db, float* workspace, size_t workspace_bytes, int n, int h, int w, int c, void* stream) {
+    WSU_REQUIRE(g && db && workspace, "colsum_pl: null pointer");
+    WSU_REQUIRE(n > 0 && h > 0 && w > 0 && c >= 16 && c <= 2048 && c % 16 == 0 && 256 % (c / 8) == 0, "colsum_pl: bad shape (c=%d must be 16..2048 with 256 %% (c / 8) == 0)", c);
+    WSU_REQUIRE(workspace_bytes >= wsu_chansum_pl_workspace_bytes(c), "colsum_pl: workspace too small");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const long long npix = (long long)n * h * w;
+    const int ppb = 256 / (c / 8);
+    const int nblk = (int)((npix + ppb - 1) / ppb < SUM_BLOCKS ? (npix + ppb - 1) / ppb : SUM_BLOCKS);
+    hipLaunchKernelGGL(chansum_pl_kernel<false>, dim3(nblk), dim3(256), 0, s, (const char*)g, (const float*)nullptr, workspace, n, h, w, c);
+    int rc = wsu_check_launch("chansum_pl_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(block_sum_kernel, dim3((c + 63) / 64), dim3(64), 0, s, workspace, db, nblk, c);
+    return wsu_check_launch("block_sum_kernel");
+}
+
+// K7p: weight / bias gradient of the first layer for a single input plane: g (planar gradient, c channels), img (N, 1, H, W) fp32 -> dw (c, 1, 3, 3), db (c) or NULL
+int wsu_conv3x3_first_pl_bwd_weight(const void* g, const float* img, float* dw, float* db, float* workspace, size_t workspace_bytes,
+                                    int n, int h, int w, int c, void* stream) {
+    WSU_REQUIRE(g && img && dw && workspace, "conv3x3_first_pl_bwd_weight: null pointer");
+    WSU_REQUIRE(n > 0 && h >= 2 && w >= 2 && c >= 16 && c <= 256 && c % 16 == 0 && 256 % (c / 8) == 0, "conv3x3_first_pl_bwd_weight: bad shape c=%d", c);
+    WSU_REQUIRE(workspace_bytes >= wsu_chansum_pl_workspace_bytes(c), "conv3x3_first_pl_bwd_weight: workspace too small");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const long long npix = (long long)n * h * w;
+    const int ppb = 256 / (c / 8);
+    const int nblk = (int)((npix + ppb - 1) / ppb < SUM_BLOCKS ? (npix + ppb - 1) / ppb : SUM_BLOCKS);
+    float* sums = workspace + (size_t)SUM_BLOCKS * c * 10;
+    hipLaunchKernelGGL(chansum_pl_kernel<true>, dim3(nblk), dim3(256), 0, s, (const char*)g, img, workspace, n, h, w, c);
+    int rc = wsu_check_launch("chansum_pl_kernel<first>");
+    if (rc) return rc;
+    hipLaunchKernelGGL(block_sum_kernel, dim3((c * 10 + 63) / 64), dim3(64), 0, s, workspace, sums, nblk, c * 10);
+    rc = wsu_check_launch("block_sum_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(first_split_kernel, dim3((c * 10 + 63) / 64), dim3(64), 0, s, (const float*)sums, dw, db, c);
+    return wsu_check_launch("first_split_kernel");
+}
+
+}  // extern "C"

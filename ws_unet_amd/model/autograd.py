@@ -60,10 +60,100 @@ def _forward_train(model, x: torch.Tensor, m0: int) -> Dict[str, torch.Tensor]:
     return t
 
 
+def _forward_train_pl(model, x: torch.Tensor) -> Dict[str, torch.Tensor]:
+    """train_mode 'f16f8p': the inference path's planar kernels (UNet._forward_planar) with every activation the backward needs kept --
+    in the planar layout, 3 bytes per element; the last conv stores its output AND the fused head's."""
+    W = ops.MODE_F16F8
+    t: Dict[str, torch.Tensor] = {}
+    e11 = model.e11
+    head = dict(head_w=model.outconv.weight.detach(), head_b=model.outconv.bias.detach())
+    cur = t["xe11"] = ops.conv3x3_first_pl(x, e11.weight, e11.bias.detach())
+    for lvl in range(model.nsteps + 1):
+        a, b = ENC[lvl]
+        if lvl >= 1:
+            la = getattr(model, a)
+            cur = t["x" + a] = ops.conv3x3_pl(cur, None, model._packed(a, W, "conv"), la.bias.detach(), la.out_channels)
+        lb = getattr(model, b)
+        if lvl < model.nsteps:
+            t["x" + b], cur = ops.conv3x3_pl(cur, None, model._packed(b, W, "conv"), lb.bias.detach(), lb.out_channels, pool=True)
+            t[f"xp{lvl + 1}"] = cur
+        elif model.nsteps == 0:
+            t["out"], cur = ops.conv3x3_pl(cur, None, model._packed(b, W, "conv"), lb.bias.detach(), lb.out_channels, **head)
+            t["x" + b] = cur
+        else:
+            cur = t["x" + b] = ops.conv3x3_pl(cur, None, model._packed(b, W, "conv"), lb.bias.detach(), lb.out_channels)
+    for depth in range(model.nsteps, 0, -1):
+        up, c1, c2 = dec_names(depth)
+        lu, l1, l2 = getattr(model, up), getattr(model, c1), getattr(model, c2)
+        xu = t["xu" + up[-1]] = ops.convt2x2_pl(cur, model._packed(up, W, "convt"), lu.bias.detach(), lu.out_channels)
+        cur = t["x" + c1] = ops.conv3x3_pl(xu, t["x" + ENC[depth - 1][1]], model._packed(c1, W, "conv"), l1.bias.detach(), l1.out_channels)
+        if depth == 1:
+            t["out"], cur = ops.conv3x3_pl(cur, None, model._packed(c2, W, "conv"), l2.bias.detach(), l2.out_channels, **head)
+            t["x" + c2] = cur
+        else:
+            cur = t["x" + c2] = ops.conv3x3_pl(cur, None, model._packed(c2, W, "conv"), l2.bias.detach(), l2.out_channels)
+    t["last"] = cur
+    return t
+
+
+def _backward_pl(model, t: Dict[str, torch.Tensor], x: torch.Tensor, dout: torch.Tensor) -> Dict[str, torch.Tensor]:
+    """Backward of train_mode 'f16f8p': every gradient tensor planar (f16 + e4m3 residual, pre-scaled by a power of two), data gradients through
+    the persistent LDS-DMA conv kernel, weight gradients from planar operands; the same layer walk as the fp32-storage path below."""
+    W = ops.MODE_F16F8
+    grads: Dict[str, torch.Tensor] = {}
+    scale = ops.pow2_grad_scale(dout)
+    dout = ops.scale_by(dout, scale[0:1])
+
+    def conv_bwd(name, g, x1, x2, mask1, need_dx=True):
+        layer = getattr(model, name)
+        grads[name + ".weight"], grads[name + ".bias"] = ops.conv3x3_pl_bwd_weight(g, x1, x2)
+        if not need_dx:
+            return None, None
+        return ops.conv3x3_pl_bwd_data(g, model._packed(name, W, "dgrad"), model._packed(name, W, "ring"), layer.in_channels,
+                                       x1.shape[1] * 16, mask1, None)
+
+    g, grads["outconv.weight"], grads["outconv.bias"] = ops.conv1x1_sigmoid_pl_bwd(t["last"], model.outconv.weight, t["out"], dout)
+    skip_g: Dict[int, torch.Tensor] = {}
+    for depth in range(1, model.nsteps + 1):
+        up, c1, c2 = dec_names(depth)
+        xc1, xu, skip = t["x" + c1], t["xu" + up[-1]], t["x" + ENC[depth - 1][1]]
+        g, _ = conv_bwd(c2, g, xc1, None, xc1)
+        dxu, skip_g[depth] = conv_bwd(c1, g, xu, skip, None)              # neither half is masked here: the upconv output has no ReLU, the skip's
+        below = t["x" + (dec_names(depth + 1)[2] if depth < model.nsteps else ENC[model.nsteps][1])]    # mask meets the pool routing below
+        lu = getattr(model, up)
+        grads[up + ".weight"] = ops.convt2x2_pl_bwd_weight(below, dxu)
+        grads[up + ".bias"] = ops.colsum_pl(dxu)
+        g = ops.convt2x2_pl_bwd_data(dxu, model._packed(up, W, "convt_dgrad_pl"), lu.in_channels, below)
+    for lvl in range(model.nsteps, -1, -1):
+        a, b = ENC[lvl]
+        if lvl < model.nsteps:
+            g = ops.maxpool2x2_pl_bwd(skip_g[lvl + 1], g, t["x" + b])
+        xa = t["x" + a]
+        g, _ = conv_bwd(b, g, xa, None, xa)
+        if lvl == 0:
+            grads[a + ".weight"], grads[a + ".bias"] = ops.conv3x3_first_pl_bwd_weight(g, x)
+        else:
+            g, _ = conv_bwd(a, g, t[f"xp{lvl}"], None, None)
+    ops.scale_many_(list(grads.values()), scale[1:2])
+    return grads
+
+
+def planar_train_ok(model, x: torch.Tensor) -> bool:
+    """The planar training path covers what the planar inference path covers, for single-plane inputs and without an input gradient."""
+    return model._planar_ok() and model.e11.in_channels == 1 and model.outconv.in_channels == 64 and not x.requires_grad
+
+
 class _UNetFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, x, *params):
-        m = ops.mode_id(getattr(model, "train_mode", "f32"))
+        tm = getattr(model, "train_mode", "f32")
+        if tm == "f16f8p":
+            if planar_train_ok(model, x):
+                t = _forward_train_pl(model, x)
+                ctx.model, ctx.t, ctx.x, ctx.m = model, t, x, ops.MODE_F16F8P
+                return t["out"]
+            tm = "bf16x3"                               # input gradients (saliency) and odd shapes: the fp32-storage path
+        m = ops.mode_id(tm)
         if m == ops.MODE_BF16:
             raise ValueError("train_mode must be 'f32' or 'bf16x3' (activations are kept in fp32 for the backward pass)")
         t = _forward_train(model, x, m)
@@ -76,6 +166,10 @@ class _UNetFn(torch.autograd.Function):
         grads: Dict[str, torch.Tensor] = {}
         dx = None
         dout = dout.contiguous().float()
+        if m == ops.MODE_F16F8P:
+            grads = _backward_pl(model, t, x, dout)
+            ctx.t = None
+            return (None, None) + tuple(grads[name] if p.requires_grad else None for name, p in model.named_parameters())
         # data- and weight-gradient GEMMs of a split-bf16 run: f16f8 arithmetic on the fp32 tensors (model.train_bwd_mode).  Gradients of
         # a mean-reduced loss sit far below f16's normal range, so the whole backward chain runs on gradients scaled by a power of two
         # chosen from |dL/dout| (every kernel on the way is linear in the gradient; ReLU masks and pool routing ignore the scale) and all

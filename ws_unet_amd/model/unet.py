@@ -148,6 +148,10 @@ class UNet(nn.Module):
             packed = ops.pack_conv3x3(p, mode)
         elif kind == "dgrad":
             packed = ops.pack_conv3x3(p, mode, dgrad=True)
+        elif kind == "ring":
+            packed = ops.pack_conv3x3_ring(p)
+        elif kind == "convt_dgrad_pl":
+            packed = ops.pack_convt2x2_pl_dgrad(p)
         elif kind == "convt_dgrad":
             packed = ops.pack_convt2x2_dgrad(p, mode)
         else:

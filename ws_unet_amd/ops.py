@@ -402,6 +402,90 @@ def convt2x2_pl_bwd_weight(x: torch.Tensor, dy: torch.Tensor):
     return dw
 
 
+def pack_convt2x2_pl_dgrad(w: torch.Tensor) -> torch.Tensor:
+    """w: (Cin, Cout, 2, 2) -> data-gradient weights of the planar transposed conv (wsu_convt2x2_pl_pack_dgrad)."""
+    lib = _lib.load()
+    w = w.detach()
+    _dev_check(w)
+    cin, cout = w.shape[:2]
+    out = torch.empty(cin * cout * 16, dtype=torch.uint8, device=w.device)
+    check(lib.wsu_convt2x2_pl_pack_dgrad(w.data_ptr(), out.data_ptr(), cin, cout, _stream()), "wsu_convt2x2_pl_pack_dgrad")
+    return out
+
+
+def convt2x2_pl_bwd_data(dy: torch.Tensor, w_packed_dgrad: torch.Tensor, cin: int, mask: Optional[torch.Tensor]) -> torch.Tensor:
+    """dy: planar gradient (N, Cout/16, 3, 2h, 2w, 4) -> dx planar gradient with cin channels at (h, w), masked by (mask > 0)."""
+    lib = _lib.load()
+    _dev_check(dy, w_packed_dgrad, mask)
+    n, nco, _, oh, ow, _ = dy.shape
+    h, w, cout = oh // 2, ow // 2, nco * 16
+    dx = torch.empty(planar_shape(n, cin, h, w), dtype=torch.float32, device=dy.device)
+    meta = {"flops": 2.0 * 4 * cin * cout * n * h * w, "bytes": float(n * h * w * (cout * 12 + cin * 5))}
+    check(_launch("convt2x2_pl_bwd_data", meta, lambda: lib.wsu_convt2x2_pl_bwd_data(
+        dy.data_ptr(), w_packed_dgrad.data_ptr(), dx.data_ptr(), _ptr(mask), n, h, w, cin, cout, _stream())), "wsu_convt2x2_pl_bwd_data")
+    return dx
+
+
+def maxpool2x2_pl_bwd(skip_g: Optional[torch.Tensor], dy_pool: torch.Tensor, act: torch.Tensor) -> torch.Tensor:
+    """(skip_g + routed dy_pool) * (act > 0) on planar tensors; writes into skip_g when given."""
+    lib = _lib.load()
+    _dev_check(skip_g, dy_pool, act)
+    n, nch, _, h, w, _ = act.shape
+    g = skip_g if skip_g is not None else torch.empty_like(act)
+    meta = {"bytes": float(n * nch * 16 * h * w * (9 if skip_g is not None else 6.75))}
+    check(_launch("maxpool2x2_pl_bwd", meta, lambda: lib.wsu_maxpool2x2_pl_bwd(
+        _ptr(skip_g), dy_pool.data_ptr(), act.data_ptr(), g.data_ptr(), n, h, w, nch * 16, _stream())), "wsu_maxpool2x2_pl_bwd")
+    return g
+
+
+def conv1x1_sigmoid_pl_bwd(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, dout: torch.Tensor):
+    """Head backward on a planar input: returns g (planar gradient), dw (cout, C, 1, 1), db (cout)."""
+    lib = _lib.load()
+    w2 = w.detach().reshape(w.shape[0], -1).contiguous()
+    _dev_check(x, w2, out, dout)
+    n, nch, _, h, wd, _ = x.shape
+    c, cout = nch * 16, w2.shape[0]
+    g = torch.empty_like(x)
+    dw = torch.empty((cout, c, 1, 1), dtype=torch.float32, device=x.device)
+    db = torch.empty(cout, dtype=torch.float32, device=x.device)
+    ws = workspace(lib.wsu_head_pl_bwd_workspace_bytes(c, cout), x.device)
+    meta = {"bytes": float(n * h * wd * (c * 6 + cout * 8))}
+    check(_launch("conv1x1_sigmoid_pl_bwd", meta, lambda: lib.wsu_conv1x1_sigmoid_pl_bwd(
+        x.data_ptr(), w2.data_ptr(), out.data_ptr(), dout.data_ptr(), g.data_ptr(), dw.data_ptr(), db.data_ptr(),
+        ws.data_ptr(), ws.numel() * 4, n, h, wd, c, cout, _stream())), "wsu_conv1x1_sigmoid_pl_bwd")
+    return g, dw, db
+
+
+def colsum_pl(g: torch.Tensor) -> torch.Tensor:
+    """Per-channel sums of a planar gradient."""
+    lib = _lib.load()
+    _dev_check(g)
+    n, nch, _, h, w, _ = g.shape
+    c = nch * 16
+    db = torch.empty(c, dtype=torch.float32, device=g.device)
+    ws = workspace(lib.wsu_chansum_pl_workspace_bytes(c), g.device)
+    check(_launch("colsum_pl", {"bytes": float(n * c * h * w * 3)}, lambda: lib.wsu_colsum_pl(
+        g.data_ptr(), db.data_ptr(), ws.data_ptr(), ws.numel() * 4, n, h, w, c, _stream())), "wsu_colsum_pl")
+    return db
+
+
+def conv3x3_first_pl_bwd_weight(g: torch.Tensor, x_nchw: torch.Tensor, want_bias: bool = True):
+    """First-layer weight / bias gradient from a planar gradient; single input plane."""
+    lib = _lib.load()
+    _dev_check(g, x_nchw)
+    n, nch, _, h, w, _ = g.shape
+    c = nch * 16
+    if x_nchw.shape[1] != 1:
+        raise ValueError("the planar training path handles single-plane inputs (in_channels = 1); use train_mode 'f32' / 'bf16x3' otherwise")
+    dw = torch.empty((c, 1, 3, 3), dtype=torch.float32, device=g.device)
+    db = torch.empty(c, dtype=torch.float32, device=g.device) if want_bias else None
+    ws = workspace(lib.wsu_chansum_pl_workspace_bytes(c), g.device)
+    check(_launch("conv3x3_first_pl_bwd_weight", {"bytes": float(n * h * w * (c * 3 + 4))}, lambda: lib.wsu_conv3x3_first_pl_bwd_weight(
+        g.data_ptr(), x_nchw.data_ptr(), dw.data_ptr(), _ptr(db), ws.data_ptr(), ws.numel() * 4, n, h, w, c, _stream())),
+        "wsu_conv3x3_first_pl_bwd_weight")
+    return dw, db
+
+
 def pack_conv3x3_wino(w: torch.Tensor) -> torch.Tensor:
     """OIHW fp32 -> Winograd F(2,3) packed weights of wsu_conv3x3_wino_fwd (mode bf16x3)."""
     lib = _lib.load()
