@@ -241,14 +241,16 @@ def per_layer_roofline(timer, mode):
                     "outputs once + weights in the mode's storage format"}
 
 
-def train_step_leg(dev, batch, size, steps=5, warmup=3):
+def train_step_leg(dev, batch, size, steps=5, warmup=3, train_mode=None):
     """BASELINE.json configs[2]: unet_2 fwd + L1WS + bwd + AdamW on synthetic cover/stego pairs resident in HBM."""
     import numpy as np
     import torch
     from ws_unet_amd import formula, ops
     from ws_unet_amd.model import get_model
     from ws_unet_amd.trainer import Trainer
-    m = get_model("unet_2", in_channels=1, out_channels=1, channel=[0], drop_rate=None, mode="bf16x3")
+    m = get_model("unet_2", in_channels=1, out_channels=1, channel=[0], drop_rate=None, mode="f16f8p")
+    if train_mode:
+        m.train_mode = train_mode
     m.load_state_dict({k: torch.from_numpy(v) for k, v in formula.formula_state_dict(2, "default").items()})
     m = m.to(dev)
     cov = formula.synthetic_images(batch, size, size, seed=5)
@@ -272,7 +274,8 @@ def train_step_leg(dev, batch, size, steps=5, warmup=3):
     top = sorted(ks.items(), key=lambda kv: -kv[1]["total_ms"])[:3]
     flop = TRAIN_FLOP_PER_IMAGE_512 * (size / 512.0) ** 2 * batch
     res = {"workload": f"unet_2 fwd + L1WS + bwd + AdamW, batch={batch} synthetic {size}x{size} cover/stego pairs (BASELINE.json configs[2])",
-           "arithmetic": f"train_mode={m.train_mode} fwd={m.train_fwd_mode} bwd={m.train_bwd_mode} (fp32 storage and accumulation)",
+           "arithmetic": (f"train_mode={m.train_mode}: f16f8 arithmetic on planar activations and gradients (3 bytes per element), fp32 accumulation" if m.train_mode == "f16f8p"
+                          else f"train_mode={m.train_mode} fwd={m.train_fwd_mode} bwd={m.train_bwd_mode} (fp32 storage and accumulation)"),
            "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3, "images_per_s": batch * steps / dt,
            "tflops_algorithmic": flop * steps / dt / 1e12, "frac_of_mfma_peak": flop * steps / dt / PEAK["bf16x3"],
            "loss": float(loss.item()), "peak_mem_GB": torch.cuda.max_memory_allocated() / 2 ** 30,

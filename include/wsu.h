@@ -160,10 +160,10 @@ int wsu_conv3x3_pl_bwd_data(const void* g, const void* w_packed_dgrad, const voi
  *      wsu_conv3x3_bwd_weight with planar staging -- one stored f16 granule + half a residual granule per (pixel, 8 channels), no split arithmetic).
  *      conv: g (cout channels, planar gradient), x1 / x2 (the layer's saved planar inputs, c1 / c2 channels), dw (cout, c1 + c2, 3, 3), db (cout) or
  *      NULL (sum of the decoded gradient values, fixed order).  Transposed conv: x (cin channels at h x w), dy (cout channels, planar gradient at
- *      2h x 2w), dw (cin, cout, 2, 2).  All channel counts multiples of 64; workspace >= wsu_wgrad_workspace_bytes.  Deterministic. */
+ *      2h x 2w), dw (cin, cout, 2, 2), db (cout) or NULL.  All channel counts multiples of 64; workspace >= wsu_wgrad_workspace_bytes.  Deterministic. */
 int wsu_conv3x3_pl_bwd_weight(const void* g, const void* x1, const void* x2, float* dw, float* db, float* workspace, size_t workspace_bytes,
                               int n, int h, int w, int c1, int c2, int cout, void* stream);
-int wsu_convt2x2_pl_bwd_weight(const void* x, const void* dy, float* dw, float* workspace, size_t workspace_bytes,
+int wsu_convt2x2_pl_bwd_weight(const void* x, const void* dy, float* dw, float* db, float* workspace, size_t workspace_bytes,
                                int n, int h, int w, int cin, int cout, void* stream);
 
 /* ---- K7p: the other backward kernels of the planar training path (csrc/planar.hip, csrc/train_pl.hip; autograd of unet.py:137-189).

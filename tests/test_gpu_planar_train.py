@@ -105,10 +105,12 @@ def test_convt2x2_pl_bwd_weight(n, h, w, cin, cout):
     x = _q(torch.relu(_rand((n, cin, h, w), 7)), 4096.0)
     dy = _q(_rand((n, cout, 2 * h, 2 * w), 8), GRAD_LO)
     wgt = torch.zeros((cin, cout, 2, 2), requires_grad=True)
-    F.conv_transpose2d(x, wgt, stride=2).backward(dy)
-    dw = ops.convt2x2_pl_bwd_weight(planar_encode(x), planar_encode(dy, GRAD_LO))
+    b = torch.zeros(cout, requires_grad=True)
+    F.conv_transpose2d(x, wgt, b, stride=2).backward(dy)
+    dw, db = ops.convt2x2_pl_bwd_weight(planar_encode(x), planar_encode(dy, GRAD_LO))
     torch.cuda.synchronize()
     assert rel_l2(dw.cpu(), wgt.grad) < REL_L2, rel_l2(dw.cpu(), wgt.grad)
+    assert rel_l2(db.cpu(), b.grad) < 2e-6, rel_l2(db.cpu(), b.grad)       # partial tiles: clamped copies of edge pixels are not summed
 
 
 @pytest.mark.parametrize("n,h,w,cin,cout,masked", [(2, 8, 32, 64, 64, True), (1, 13, 40, 128, 64, True), (2, 5, 7, 64, 32, False), (1, 4, 64, 256, 128, True)])

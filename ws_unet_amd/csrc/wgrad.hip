@@ -422,7 +422,8 @@ __global__ __launch_bounds__(NT, 2) void wgrad_x3_kernel(const WgArgs a) {
         if (tid < 64) {
             float sum = 0.f;
             for (int j = 0; j < NT / 8; ++j) sum += red[j * 64 + tid];
-            a.bpart[(size_t)split * (a.nmb * 64) + mb * 64 + tid] = sum;
+            if (KIND == 0) a.bpart[(size_t)split * (a.nmb * 64) + mb * 64 + tid] = sum;
+            else           a.bpart[(size_t)split * (a.nnb * 64) + nb * 64 + tid] = sum;
         }
     }
 }
@@ -484,7 +485,8 @@ __global__ __launch_bounds__(NT, 2) void wgrad_pl_kernel(const WgPlArgs a) {
     constexpr int V_IT = (G::V_PIX + 31) / 32;                         // 5 (KIND 0), 4 (KIND 1)
     static_assert(NT == 256 && G::U_PIX % 32 == 0, "8 channel groups x 32 pixel lanes");
     const int scg = tid >> 5, spx = tid & 31;
-    const bool bias_on = KIND == 0 && a.bpart != nullptr && nb == 0;
+    // bias gradient = per-channel sum of the gradient operand: U for the conv (workgroups with nb == 0), V for the transposed conv (mb == 0)
+    const bool bias_on = a.bpart != nullptr && (KIND == 0 ? nb == 0 : mb == 0);
     float bs[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) bs[e] = 0.f;
@@ -522,6 +524,9 @@ __global__ __launch_bounds__(NT, 2) void wgrad_pl_kernel(const WgPlArgs a) {
         it.r = *reinterpret_cast<const u32x2*>(base + 2 * hwv * 16 + (cg & 1) * 8);
         return it;
     };
+    auto v_valid = [&](int y0, int x0, int p) __attribute__((always_inline)) {    // KIND 1: the window pixel lies inside the image (clamped copies do not count)
+        return 2 * y0 + p / VW < hv && 2 * x0 + p % VW < wv;
+    };
     auto put = [&](char* hi, char* c8, char* l8, int p, int cg, const Item& it, bool grad) __attribute__((always_inline)) {
         *reinterpret_cast<u32x4*>(hi + p * X3_ROW + cg * 16) = it.h;
         *reinterpret_cast<u32x2*>(c8 + p * F8_ROW + cg * 8) = grad ? wsu_f16x8_to_fp8_grad(it.h) : wsu_f16x8_to_fp8(it.h);
@@ -550,19 +555,23 @@ __global__ __launch_bounds__(NT, 2) void wgrad_pl_kernel(const WgPlArgs a) {
             for (int k = 0; k < U_IT; ++k) {
                 const int p = spx + 32 * k;
                 const Item it = u_load(n, y0, x0, p);
-                if (bias_on) bias_add(bs, it);
+                if (KIND == 0 && bias_on) bias_add(bs, it);
                 put(u_hi, u_lo, u_l8, p, scg, it, UGRAD);
             }
 #pragma unroll
             for (int k = 0; k < V_IT; ++k) {
                 const int p = spx + 32 * k;
-                if (p < G::V_PIX) put(v_hi, v_lo, v_l8, p, scg, v_load(n, y0, x0, p, scg), !UGRAD);
+                if (p < G::V_PIX) {
+                    const Item it = v_load(n, y0, x0, p, scg);
+                    if (KIND == 1 && bias_on && v_valid(y0, x0, p)) bias_add(bs, it);
+                    put(v_hi, v_lo, v_l8, p, scg, it, !UGRAD);
+                }
             }
         } else {
             if (ROLL) rot = (rot + TH) & (VH - 1);
 #pragma unroll
             for (int k = 0; k < U_IT; ++k) {
-                if (bias_on) bias_add(bs, pu[k]);
+                if (KIND == 0 && bias_on) bias_add(bs, pu[k]);
                 put(u_hi, u_lo, u_l8, spx + 32 * k, scg, pu[k], UGRAD);
             }
 #pragma unroll
@@ -571,6 +580,7 @@ __global__ __launch_bounds__(NT, 2) void wgrad_pl_kernel(const WgPlArgs a) {
                 if (pn < VN_PIX) {
                     const int rn = pn / VW, c = pn % VW;
                     const int slot = (VN_ROW0 + rn + rot) & (VH - 1);
+                    if (KIND == 1 && bias_on && v_valid(y0, x0, pn)) bias_add(bs, pv[k]);
                     put(v_hi, v_lo, v_l8, slot * VW + c, scg, pv[k], !UGRAD);
                 }
             }
@@ -631,7 +641,8 @@ __global__ __launch_bounds__(NT, 2) void wgrad_pl_kernel(const WgPlArgs a) {
             const int cg = tid >> 3, e = tid & 7;
             float sum = 0.f;
             for (int j = 0; j < 32; ++j) sum += red[(cg * 32 + j) * 8 + e];
-            a.bpart[(size_t)split * (a.nmb * 64) + mb * 64 + tid] = sum;
+            if (KIND == 0) a.bpart[(size_t)split * (a.nmb * 64) + mb * 64 + tid] = sum;
+            else           a.bpart[(size_t)split * (a.nnb * 64) + nb * 64 + tid] = sum;
         }
     }
 }
@@ -640,7 +651,7 @@ __global__ __launch_bounds__(NT, 2) void wgrad_pl_kernel(const WgPlArgs a) {
 template <int KIND>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bpart,
                                                            float* __restrict__ dw, float* __restrict__ db,
-                                                           int nsplit, int nmb, int nnb) {
+                                                           int nsplit, int nmb, int nnb, int nbias) {
     constexpr int NTAPS = Geo<KIND>::NTAPS;
     const int mtot = nmb * 64, ntot = nnb * 64;
     const long long total = (long long)mtot * ntot * NTAPS;
@@ -657,10 +668,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         const int m = mb * 64 + ml, n = nb * 64 + nl;
         dw[((size_t)m * ntot + n) * NTAPS + tap] = s;
     }
-    if (db && bpart) {
-        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < mtot; i += gridDim.x * blockDim.x) {
+    if (db && bpart) {                                                 // nbias = channels of the gradient operand (M for the conv, N for the transposed conv)
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nbias; i += gridDim.x * blockDim.x) {
             float s = 0.f;
-            for (int sp = 0; sp < nsplit; ++sp) s += bpart[(size_t)sp * mtot + i];
+            for (int sp = 0; sp < nsplit; ++sp) s += bpart[(size_t)sp * nbias + i];
             db[i] = s;
         }
     }
@@ -738,7 +749,7 @@ int run_wgrad(WgArgs a, float* dw, float* db, float* workspace, size_t workspace
         hipLaunchKernelGGL(wgrad_x3_kernel<KIND>, dim3(nsplit * a.nmb * a.nnb), dim3(NT), GeoX3<KIND>::LDS, s, a);
         int rc = wsu_check_launch("wgrad_x3_kernel");
         if (rc) return rc;
-        hipLaunchKernelGGL(wgrad_reduce_kernel<KIND>, dim3(512), dim3(256), 0, s, a.part, (const float*)a.bpart, dw, a.bpart ? db : (float*)nullptr, nsplit, a.nmb, a.nnb);
+        hipLaunchKernelGGL(wgrad_reduce_kernel<KIND>, dim3(512), dim3(256), 0, s, a.part, (const float*)a.bpart, dw, a.bpart ? db : (float*)nullptr, nsplit, a.nmb, a.nnb, a.nmb * 64);
         return wsu_check_launch("wgrad_reduce_kernel");
     }
     static bool attr_done = false;
@@ -750,7 +761,7 @@ int run_wgrad(WgArgs a, float* dw, float* db, float* workspace, size_t workspace
     hipLaunchKernelGGL(wgrad_kernel<KIND>, dim3(nsplit * a.nmb * a.nnb), dim3(NT), G::LDS, s, a);
     int rc = wsu_check_launch("wgrad_kernel");
     if (rc) return rc;
-    hipLaunchKernelGGL(wgrad_reduce_kernel<KIND>, dim3(512), dim3(256), 0, s, a.part, a.bpart, dw, db, nsplit, a.nmb, a.nnb);
+    hipLaunchKernelGGL(wgrad_reduce_kernel<KIND>, dim3(512), dim3(256), 0, s, a.part, a.bpart, dw, db, nsplit, a.nmb, a.nnb, a.nmb * 64);
     return wsu_check_launch("wgrad_reduce_kernel");
 }
 
@@ -763,7 +774,8 @@ int run_wgrad_pl(WgPlArgs a, float* dw, float* db, float* workspace, size_t work
     int nsplit = (512 + a.nmb * a.nnb - 1) / (a.nmb * a.nnb);
     nsplit = max(1, min(nsplit, a.ntiles));
     const size_t slab = (size_t)a.nmb * a.nnb * G::NTAPS * 4096 * sizeof(float);
-    const size_t bslab = (size_t)a.nmb * 64 * sizeof(float);
+    const int nbias = (KIND == 0 ? a.nmb : a.nnb) * 64;                // channels of the gradient operand
+    const size_t bslab = (size_t)nbias * sizeof(float);
     while (nsplit > 1 && nsplit * (slab + bslab) > workspace_bytes) --nsplit;
     if (nsplit * (slab + bslab) > workspace_bytes) {
         wsu_set_error("wgrad_pl: workspace of %zu bytes too small (need >= %zu)", workspace_bytes, slab + bslab);
@@ -772,7 +784,7 @@ int run_wgrad_pl(WgPlArgs a, float* dw, float* db, float* workspace, size_t work
     a.nsplit = nsplit;
     a.tiles_per_split = (a.ntiles + nsplit - 1) / nsplit;
     a.part = workspace;
-    a.bpart = (db && KIND == 0) ? workspace + (size_t)nsplit * slab / sizeof(float) : nullptr;
+    a.bpart = db ? workspace + (size_t)nsplit * slab / sizeof(float) : nullptr;
     static bool attr = false;
     if (!attr) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_pl_kernel<KIND>), hipFuncAttributeMaxDynamicSharedMemorySize, GeoX3<KIND>::LDS_F8);
@@ -782,7 +794,7 @@ int run_wgrad_pl(WgPlArgs a, float* dw, float* db, float* workspace, size_t work
     hipLaunchKernelGGL(wgrad_pl_kernel<KIND>, dim3(nsplit * a.nmb * a.nnb), dim3(NT), GeoX3<KIND>::LDS_F8, s, a);
     int rc = wsu_check_launch("wgrad_pl_kernel");
     if (rc) return rc;
-    hipLaunchKernelGGL(wgrad_reduce_kernel<KIND>, dim3(512), dim3(256), 0, s, a.part, (const float*)a.bpart, dw, a.bpart ? db : (float*)nullptr, nsplit, a.nmb, a.nnb);
+    hipLaunchKernelGGL(wgrad_reduce_kernel<KIND>, dim3(512), dim3(256), 0, s, a.part, (const float*)a.bpart, dw, a.bpart ? db : (float*)nullptr, nsplit, a.nmb, a.nnb, nbias);
     return wsu_check_launch("wgrad_reduce_kernel");
 }
 
@@ -792,7 +804,7 @@ extern "C" {
 
 // K7p weight / bias gradients on PLANAR operands (layout and gradient encodings: wsu.h).  Conv: g (cout channels, gradient), x1 / x2 (the
 // layer's saved planar input(s)), dw (cout, c1 + c2, 3, 3), db (cout) or NULL.  Transposed conv: x (cin, at h x w), dy (cout, gradient, at
-// 2h x 2w), dw (cin, cout, 2, 2); its bias gradient is wsu_colsum_pl (train_pl.hip).  Channel counts multiples of 64.  Workspace:
+// 2h x 2w), dw (cin, cout, 2, 2), db (cout) or NULL (sum of dy, taken while staging).  Channel counts multiples of 64.  Workspace:
 // wsu_wgrad_workspace_bytes.  Deterministic.
 int wsu_conv3x3_pl_bwd_weight(const void* g, const void* x1, const void* x2, float* dw, float* db, float* workspace, size_t workspace_bytes,
                               int n, int h, int w, int c1, int c2, int cout, void* stream) {
@@ -805,14 +817,14 @@ int wsu_conv3x3_pl_bwd_weight(const void* g, const void* x1, const void* x2, flo
     return run_wgrad_pl<0>(a, dw, db, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
 }
 
-int wsu_convt2x2_pl_bwd_weight(const void* x, const void* dy, float* dw, float* workspace, size_t workspace_bytes,
+int wsu_convt2x2_pl_bwd_weight(const void* x, const void* dy, float* dw, float* db, float* workspace, size_t workspace_bytes,
                                int n, int h, int w, int cin, int cout, void* stream) {
     WSU_REQUIRE(x && dy && dw && workspace, "convt2x2_pl_bwd_weight: null pointer");
     WSU_REQUIRE(n > 0 && h > 0 && w > 0, "convt2x2_pl_bwd_weight: bad shape");
     WSU_REQUIRE(cin > 0 && cin % 64 == 0 && cout > 0 && cout % 64 == 0, "convt2x2_pl_bwd_weight: cin=%d cout=%d must be multiples of 64", cin, cout);
     WgPlArgs a{};
     a.u = (const char*)x; a.v1 = (const char*)dy; a.v2 = nullptr; a.n = n; a.hu = h; a.wu = w; a.cu = cin; a.cv1 = cout; a.cv2 = 0;
-    return run_wgrad_pl<1>(a, dw, nullptr, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+    return run_wgrad_pl<1>(a, dw, db, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
 }
 
 size_t wsu_wgrad_workspace_bytes(int cm, int cn, int ntaps) {
@@ -820,7 +832,7 @@ size_t wsu_wgrad_workspace_bytes(int cm, int cn, int ntaps) {
     if (cm <= 0 || cn <= 0 || ntaps <= 0) return 0;
     const size_t nmb = cm / 64, nnb = cn / 64;
     size_t nsplit = (512 + nmb * nnb - 1) / (nmb * nnb);
-    return nsplit * (nmb * nnb * ntaps * 4096 + nmb * 64) * sizeof(float);
+    return nsplit * (nmb * nnb * ntaps * 4096 + (nmb > nnb ? nmb : nnb) * 64) * sizeof(float);   // slabs + bias partials of either operand
 }
 
 static int colsum_channels(const float* x, float* out, float* workspace, size_t workspace_bytes, long long npix, int c, hipStream_t s) {

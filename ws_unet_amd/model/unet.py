@@ -101,9 +101,11 @@ class UNet(nn.Module):
         # planar path: e11 computed by the loader waves of e12's kernel (wsu_conv3x3_pl_fused_first_fwd).  Off by default: xe11 never
         # reaches HBM (-2.1 GB at batch 32) but the loaders' VALU work makes them the critical path -- e11 + e12 1.82 -> 1.60 ms, +0.8 % images/s
         self.fuse_first_planar = os.environ.get("WSU_FUSE_FIRST_PL", "0") != "0"
-        # arithmetic of the autograd path: exact fp32 MFMA for an 'f32' model, split-bf16 (fp32 storage and accumulation,
-        # ~2^-16 relative per product -- finer than the TF32 convs PyTorch trains with by default on the reference's GPUs) otherwise
-        self.train_mode = os.environ.get("WSU_TRAIN_MODE") or ("f32" if self.mode == "f32" else "bf16x3")
+        # arithmetic of the autograd path: exact fp32 MFMA for an 'f32' model; 'f16f8p' for a planar model -- the f16f8 arithmetic on planar
+        # activations AND gradients (3 bytes per element, model/autograd.py; single-plane inputs, falls back to 'bf16x3' otherwise and when the
+        # input gradient is asked for); else split-bf16 on fp32 tensors (~2^-16 relative per product -- finer than the TF32 convs PyTorch
+        # trains with by default on the reference's GPUs)
+        self.train_mode = os.environ.get("WSU_TRAIN_MODE") or ("f32" if self.mode == "f32" else "f16f8p" if self.mode in ("f16f8p", "f16f8q") else "bf16x3")
         # matrix layers of the training FORWARD when train_mode is 'bf16x3': 'f16f8x' (default) or 'bf16x3'
         self.train_fwd_mode = os.environ.get("WSU_TRAIN_FWD_MODE") or "f16f8x"
         self.train_bwd_mode = os.environ.get("WSU_TRAIN_BWD_MODE") or "f16f8x"     # data-gradient 3x3 convs: 'f16f8x' or 'bf16x3'

@@ -387,19 +387,20 @@ def conv3x3_pl_bwd_weight(g: torch.Tensor, x1: torch.Tensor, x2: Optional[torch.
     return dw, db
 
 
-def convt2x2_pl_bwd_weight(x: torch.Tensor, dy: torch.Tensor):
-    """Weight gradient of the transposed conv on planar operands: x planar input (N, Cin/16, 3, h, w, 4), dy planar gradient at (2h, 2w)."""
+def convt2x2_pl_bwd_weight(x: torch.Tensor, dy: torch.Tensor, want_bias: bool = True):
+    """Weight / bias gradient of the transposed conv on planar operands: x planar input (N, Cin/16, 3, h, w, 4), dy planar gradient at (2h, 2w)."""
     lib = _lib.load()
     _dev_check(x, dy)
     n, nci, _, h, w, _ = x.shape
     cin, cout = nci * 16, dy.shape[1] * 16
     assert dy.shape[3] == 2 * h and dy.shape[4] == 2 * w
     dw = torch.empty((cin, cout, 2, 2), dtype=torch.float32, device=x.device)
+    db = torch.empty(cout, dtype=torch.float32, device=x.device) if want_bias else None
     ws = workspace(lib.wsu_wgrad_workspace_bytes(cin, cout, 4), x.device)
-    meta = {"flops": 2.0 * 4 * cin * cout * n * h * w}
+    meta = {"flops": 2.0 * 4 * cin * cout * n * h * w, "bytes": float(n * h * w * 3 * (cin * (cout // 64) + 4 * cout * (cin // 64)))}
     check(_launch("convt2x2_pl_bwd_weight", meta, lambda: lib.wsu_convt2x2_pl_bwd_weight(
-        x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), ws.numel() * 4, n, h, w, cin, cout, _stream())), "wsu_convt2x2_pl_bwd_weight")
-    return dw
+        x.data_ptr(), dy.data_ptr(), dw.data_ptr(), _ptr(db), ws.data_ptr(), ws.numel() * 4, n, h, w, cin, cout, _stream())), "wsu_convt2x2_pl_bwd_weight")
+    return dw, db
 
 
 def pack_convt2x2_pl_dgrad(w: torch.Tensor) -> torch.Tensor:
