@@ -15,6 +15,7 @@
 // slab; wgrad_reduce sums the slabs in a fixed order into the OIHW / IOHW gradient (bitwise reproducible --
 // no float atomics).
 #include "wsu_device.h"
+#include <cstdlib>
 
 namespace {
 
@@ -439,6 +440,7 @@ struct WgPlArgs {
     float* part; float* bpart;
     int n, hu, wu, cu, cv1, cv2;
     int tiles_x, tiles_y, ntiles, nsplit, nmb, nnb, tiles_per_split;
+    int ablate;                     // timing-only experiments (WSU_WGRAD_ABLATE; results wrong when != 0): 1 = no matrix section, 2 = staging of the first tile only
 };
 
 template <int KIND>
@@ -549,6 +551,9 @@ __global__ __launch_bounds__(NT, 2) void wgrad_pl_kernel(const WgPlArgs a) {
         int n, y0, x0;
         decode(tile, n, y0, x0);
         __syncthreads();
+        if ((a.ablate & 2) && tile > t0) {
+            // timing experiment: no staging after the first tile
+        } else
         if (!have_pref) {
             rot = 0;
 #pragma unroll
@@ -587,7 +592,7 @@ __global__ __launch_bounds__(NT, 2) void wgrad_pl_kernel(const WgPlArgs a) {
         }
         __syncthreads();
         {
-            have_pref = tile + 1 < t1 && (!ROLL || (tile + 1) % a.tiles_y != 0);
+            have_pref = tile + 1 < t1 && (!ROLL || (tile + 1) % a.tiles_y != 0) && !(a.ablate & 2);
             if (have_pref) {
                 int n2, y2, x2;
                 decode(tile + 1, n2, y2, x2);
@@ -600,7 +605,7 @@ __global__ __launch_bounds__(NT, 2) void wgrad_pl_kernel(const WgPlArgs a) {
                 }
             }
         }
-        {
+        if (!(a.ablate & 1)) {
             const int colA8 = wm * 32 + ((lane >> 4) & 1) * 16, colB8 = wn * 32 + ((lane >> 4) & 1) * 16;
             constexpr int SU8 = UGRAD ? WSU_F8_SCALE_G : WSU_F8_SCALE_X, SUL = UGRAD ? WSU_F8_SCALE_GLO : WSU_F8_SCALE_XLO;
             constexpr int SV8 = UGRAD ? WSU_F8_SCALE_X : WSU_F8_SCALE_G, SVL = UGRAD ? WSU_F8_SCALE_XLO : WSU_F8_SCALE_GLO;
@@ -785,6 +790,9 @@ int run_wgrad_pl(WgPlArgs a, float* dw, float* db, float* workspace, size_t work
     a.tiles_per_split = (a.ntiles + nsplit - 1) / nsplit;
     a.part = workspace;
     a.bpart = db ? workspace + (size_t)nsplit * slab / sizeof(float) : nullptr;
+    static int ablate = -1;
+    if (ablate < 0) { const char* e = getenv("WSU_WGRAD_ABLATE"); ablate = e ? atoi(e) : 0; }
+    a.ablate = ablate;
     static bool attr = false;
     if (!attr) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_pl_kernel<KIND>), hipFuncAttributeMaxDynamicSharedMemorySize, GeoX3<KIND>::LDS_F8);
