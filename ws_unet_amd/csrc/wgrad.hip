@@ -652,6 +652,305 @@ __global__ __launch_bounds__(NT, 2) void wgrad_pl_kernel(const WgPlArgs a) {
     }
 }
 
+// ---- conv 3x3 weight gradient with loader waves and LDS-DMA (the production kernel of train_mode 'f16f8p') ------------------------------------
+// Ablation of wgrad_pl_kernel<0> (tools/time_wgrad.py): its time = matrix section + 70 % of the staging's HBM time -- one tile
+// of register prefetch (1.35 us) is shorter than the loaded HBM latency, and a second register set does not fit beside 144 accumulators.
+//   * workgroup = one (split, 64 co, 64 ci) slab like wgrad_pl_kernel, but 1024 threads, one per CU: twelve MATRIX waves = (32 co x 32 ci block,
+//     tap row ky) with 3 accumulator tiles (kx) -- 48 instead of 144 registers, so 16 waves of 128 registers fit -- and four LOADER waves;
+//   * steps walk DOWN an image column: a step brings one U tile (2 x 32 px) and the TWO new rows of the 4-row V window by LDS-DMA (32 pieces of
+//     64 lanes x 16 B, 8 per loader wave: a loader waits with `s_waitcnt vmcnt(8)` -- the next step's pieces stay in flight) into the padded
+//     [pixel][144 B] f16 / [pixel][96 B] residual images of wgrad_pl_kernel (lanes that would hit a pad unit idle, out-of-image U pixels fetch
+//     zeros); U tiles live in three slots, V row pairs in four, so the DMA of step k+2 is issued behind barrier k; a column (or the workgroup's
+//     range) starts with a prologue step that only contributes V rows;
+//   * the e4m3-copy images are derived by the loader lane that fetched the f16 unit (its own 16 bytes: no cross-wave dependency); bias sums are
+//     taken from the U images one step later (everything landed), 8 fixed channels per lane, reduced in lane order at the end;
+//   * one raw s_barrier per step.
+// (Two versions on the way, both slower than the register-staged kernel: converting the copies from the f16 fragments in the matrix waves --
+// 18 conversions per V element, VALU-bound; producer waves staging through two register sets -- spills at the 128-register cap put vmcnt(0) waits
+// behind every load group.)
+namespace wgr {
+constexpr int NMAT = 12, NLOAD = 4, NTD = (NMAT + NLOAD) * 64;
+constexpr int U_PIX = 64, VW = 34, V_PIX = 2 * VW;                  // a V slot = one pair of window rows
+// LDS images are split by channel half (the 32 channels of one matrix-wave block): [half][pixel][64 B] f16, [half][pixel][32 B] e4m3.  A
+// half-wave's transposing read then covers 4 (8) consecutive rows x 64 (32) B = 256 contiguous bytes: every bank once, no padding -- the
+// 144-byte pitch of wgrad_pl_kernel puts rows r and r+2 on 8 common banks (2 passes per ds_read_b64_tr_b16).
+constexpr int HROW = 64, BROW = 32;
+constexpr int U_HH = U_PIX * HROW, U_BH = U_PIX * BROW;              // 4096, 2048 per half
+constexpr int V_HH = V_PIX * HROW, V_BH = V_PIX * BROW;              // 4352, 2176
+constexpr int U_HI = 0, U_C8 = 2 * U_HH, U_L8 = U_C8 + 2 * U_BH, U_SLOT = U_L8 + 2 * U_BH;     // 16384
+constexpr int V_HI = 0, V_C8 = 2 * V_HH, V_L8 = V_C8 + 2 * V_BH, V_SLOT = V_L8 + 2 * V_BH;     // 17408
+constexpr int DEPTH = 3;                                             // the DMA of step k + DEPTH is issued behind barrier k
+constexpr int NU = DEPTH + 1, NV = DEPTH + 2;
+constexpr int V_BASE = NU * U_SLOT;
+constexpr int LDS_TOTAL = V_BASE + NV * V_SLOT;                      // 152576
+// DMA pieces of a step (64 lanes x 16 B): per half-image ceil(units / 64)
+constexpr int PH_UH = U_HH / 1024, PH_UL = U_BH / 1024;              // 4, 2 per half
+constexpr int PH_VH = (V_HH + 1023) / 1024, PH_VL = (V_BH + 1023) / 1024;   // 5, 3
+constexpr int P_UH = 2 * PH_UH, P_UL = 2 * PH_UL, P_VH = 2 * PH_VH, P_VL = 2 * PH_VL;          // 8, 4, 10, 6
+constexpr int NPIECE = P_UH + P_UL + P_VH + P_VL;                    // 28
+constexpr int PER = NPIECE / NLOAD;                                  // 7
+static_assert(NPIECE % NLOAD == 0 && U_HH % 1024 == 0 && U_BH % 1024 == 0, "piece bookkeeping");
+static_assert(LDS_TOTAL <= 160 * 1024, "LDS budget");
+}
+
+__device__ __attribute__((aligned(16))) unsigned g_wg_zero16[4];     // zeros for out-of-image U pixels
+
+typedef __attribute__((address_space(3))) void lds_void_w;
+typedef __attribute__((address_space(1))) const void glb_void_w;
+
+struct WgrWalk { int t; bool pro; int ty, tx, n; };
+__device__ __forceinline__ WgrWalk wgr_walk_at(const WgPlArgs& a, int tile) {
+    WgrWalk w; w.t = tile; w.pro = true;
+    int tt = tile;
+    w.ty = tt % a.tiles_y; tt /= a.tiles_y;
+    w.tx = tt % a.tiles_x; w.n = tt / a.tiles_x;
+    return w;
+}
+__device__ __forceinline__ void wgr_advance(const WgPlArgs& a, int t1, WgrWalk& w) {
+    if (w.pro) { w.pro = false; return; }
+    ++w.t;
+    if (++w.ty == a.tiles_y) { w.ty = 0; if (++w.tx == a.tiles_x) { w.tx = 0; ++w.n; } }
+    w.pro = w.t < t1 && w.ty == 0;
+}
+
+// piece p (0..27) of a step: image kind (0: U f16, 1: U residual, 2: V f16, 3: V residual), channel half, piece inside the half-image
+__host__ __device__ constexpr int wgr_kind(int p) { return p < wgr::P_UH ? 0 : p < wgr::P_UH + wgr::P_UL ? 1 : p < wgr::P_UH + wgr::P_UL + wgr::P_VH ? 2 : 3; }
+__host__ __device__ constexpr int wgr_pidx(int p) { return p < wgr::P_UH ? p : p < wgr::P_UH + wgr::P_UL ? p - wgr::P_UH : p < wgr::P_UH + wgr::P_UL + wgr::P_VH ? p - wgr::P_UH - wgr::P_UL : p - wgr::P_UH - wgr::P_UL - wgr::P_VH; }
+__host__ __device__ constexpr int wgr_pph(int kd) { return kd == 0 ? wgr::PH_UH : kd == 1 ? wgr::PH_UL : kd == 2 ? wgr::PH_VH : wgr::PH_VL; }       // pieces per half-image
+__host__ __device__ constexpr int wgr_half_bytes(int kd) { return kd == 0 ? wgr::U_HH : kd == 1 ? wgr::U_BH : kd == 2 ? wgr::V_HH : wgr::V_BH; }
+__host__ __device__ constexpr int wgr_img_off(int kd) { return kd == 0 ? wgr::U_HI : kd == 1 ? wgr::U_L8 : kd == 2 ? wgr::V_HI : wgr::V_L8; }  // inside its slot
+// LDS byte offset (inside the slot) of piece p
+__host__ __device__ constexpr int wgr_piece_off(int p) {
+    return wgr_img_off(wgr_kind(p)) + (wgr_pidx(p) / wgr_pph(wgr_kind(p))) * wgr_half_bytes(wgr_kind(p)) + (wgr_pidx(p) % wgr_pph(wgr_kind(p))) * 1024;
+}
+
+// fragment reads on the half-images: 8 (16) k-values = pixels row0.. of the 32 channels of half-image `img`
+__device__ __forceinline__ u32x4 wgr_frag16(const char* img, int row0) {
+    const int lane = threadIdx.x & 63, li = lane & 15, q = li >> 2, pp = li & 3;
+    const char* a0 = img + (row0 + q) * wgr::HROW + ((lane >> 4) & 1) * 32 + pp * 8;
+    const s16x4 r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a0);
+    const s16x4 r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 4 * wgr::HROW));
+    const u32x2 lo = __builtin_bit_cast(u32x2, r0), hi = __builtin_bit_cast(u32x2, r1);
+    return mk_u4(lo.x, lo.y, hi.x, hi.y);
+}
+__device__ __forceinline__ u32x4 wgr_frag8(const char* img, int row0) {
+    const int lane = threadIdx.x & 63, li = lane & 15, q = li >> 1, pp = li & 1;
+    const char* a0 = img + (row0 + q) * wgr::BROW + ((lane >> 4) & 1) * 16 + pp * 8;
+    const i32x2_t r0 = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds_i32x2*)a0);
+    const i32x2_t r1 = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds_i32x2*)(a0 + 8 * wgr::BROW));
+    return mk_u4((uint32_t)r0[0], (uint32_t)r0[1], (uint32_t)r1[0], (uint32_t)r1[1]);
+}
+
+template <int LW>
+__device__ __forceinline__ void wgr_loader(const WgPlArgs& a, char* smem, int lane, int split, int mb, int nb, int t0, int t1) {
+    using namespace wgr;
+    const int L = LW * 64 + lane;
+    const char* vsrc; int cv, vch0;
+    if (nb * 64 < a.cv1) { vsrc = a.v1; cv = a.cv1; vch0 = nb * 64; }
+    else                 { vsrc = a.v2; cv = a.cv2; vch0 = nb * 64 - a.cv1; }
+    const size_t hw = (size_t)a.hu * a.wu;
+    const bool bias_on = a.bpart != nullptr && nb == 0;
+    if (t0 >= t1) {                                                     // empty split: no barriers on either side; the partials it owns are zeros
+        if (bias_on && L < 64) a.bpart[(size_t)split * (a.nmb * 64) + mb * 64 + L] = 0.f;
+        return;
+    }
+    // per piece k (p = LW + 4 k): the lane's unit -- alive or beyond the image's pixels --, the tile-independent part of its source address
+    // 16 * ((chunk * 3 + plane) * H * W [+ r * W + c for U]), its (row, column) inside the tile / row pair, and where its e4m3 copy goes
+    int coff[PER], rc[PER], c8off[PER];
+    unsigned alive = 0;
+    WSU_STATIC_FOR(PER, k, {
+        constexpr int p = LW + NLOAD * k, kd = wgr_kind(p), upr = (kd & 1) ? 2 : 4, npx = kd < 2 ? U_PIX : V_PIX, roww = kd < 2 ? TW : VW;
+        constexpr int half = wgr_pidx(p) / wgr_pph(kd), pih = wgr_pidx(p) % wgr_pph(kd);
+        const int sidx = pih * 64 + lane;
+        const int pxl = sidx / upr, u = sidx - pxl * upr;              // pixel, 16-byte unit inside the half-row
+        if (pxl < npx) alive |= 1u << k;
+        const int g = half * upr + u;                                   // unit of the whole 64-channel row
+        const int chunk = (kd & 1) ? g : g >> 1, plane = (kd & 1) ? 2 : (g & 1);        // f16: unit = 2 chunk + plane; residual: unit = chunk
+        const int r = pxl / roww, c = pxl - r * roww;
+        rc[k] = r * 256 + c;
+        coff[k] = (int)((chunk * 3 + plane) * hw) * 16 + (kd < 2 ? (r * a.wu + c) * 16 : 0);
+        c8off[k] = half * (kd < 2 ? U_BH : V_BH) + pxl * BROW + u * 8; // the 8 copies of an f16 unit inside the copy image
+    });
+    auto issue = [&](const WgrWalk& w, int k_step) __attribute__((always_inline)) {
+        const int y0 = w.ty * 2, x0 = w.tx * TW;
+        const char* ubase = a.u + ((size_t)w.n * (a.cu >> 4) + mb * 4) * 3 * hw * 16 + ((size_t)y0 * a.wu + x0) * 16;     // wave-uniform
+        const char* vbase = vsrc + ((size_t)w.n * (cv >> 4) + (vch0 >> 4)) * 3 * hw * 16;
+        const int vy = w.pro ? y0 - 1 : y0 + 1;                         // first of the two padded rows this step brings
+        const int vrow0 = wsu_reflect(vy, a.hu) * a.wu * 16, vrow1 = wsu_reflect(vy + 1, a.hu) * a.wu * 16;
+        const int ulim = min(a.hu - y0, 2) * 256 + min(a.wu - x0, TW);  // U pixel (r, c) is inside the image iff r < ulim_y && c < ulim_x
+        char* us = smem + (k_step % NU) * U_SLOT;
+        char* vs = smem + V_BASE + (k_step % NV) * V_SLOT;
+        WSU_STATIC_FOR(PER, k, {
+            constexpr int p = LW + NLOAD * k, kd = wgr_kind(p);
+            if (alive & (1u << k)) {
+                const char* src;
+                if constexpr (kd < 2) {                                 // (a prologue step fetches its tile's U too -- unused, it keeps the piece count constant)
+                    const bool inside = (rc[k] >> 8) < (ulim >> 8) && (rc[k] & 255) < (ulim & 255);
+                    src = inside ? ubase + coff[k] : reinterpret_cast<const char*>(g_wg_zero16);
+                } else {
+                    const int xx = wsu_reflect(x0 - 1 + (rc[k] & 255), a.wu);
+                    src = vbase + (coff[k] + ((rc[k] >> 8) ? vrow1 : vrow0) + xx * 16);
+                }
+                char* dst = (kd < 2 ? us : vs) + wgr_piece_off(p);
+                __builtin_amdgcn_global_load_lds((glb_void_w*)src, (lds_void_w*)dst, 16, 0, 0);
+            }           // every piece has live lanes (static layout): a wave issues exactly PER DMA instructions per step -- the vmcnt arithmetic below
+        });
+    };
+    // e4m3 copies of the f16 units this lane fetched for step k_step (its own 16 bytes, landed: vmcnt)
+    auto derive = [&](int k_step) __attribute__((always_inline)) {
+        char* us = smem + (k_step % NU) * U_SLOT;
+        char* vs = smem + V_BASE + (k_step % NV) * V_SLOT;
+        WSU_STATIC_FOR(PER, k, {
+            constexpr int p = LW + NLOAD * k, kd = wgr_kind(p);
+            if constexpr (kd == 0 || kd == 2) {
+                if (alive & (1u << k)) {
+                    char* img = kd == 0 ? us : vs;
+                    const u32x4 hgr = *reinterpret_cast<const u32x4*>(img + wgr_piece_off(p) + lane * 16);
+                    *reinterpret_cast<u32x2*>(img + (kd == 0 ? U_C8 : V_C8) + c8off[k]) = kd == 0 ? wsu_f16x8_to_fp8_grad(hgr) : wsu_f16x8_to_fp8(hgr);
+                }
+            }
+        });
+    };
+    float bs[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bs[e] = 0.f;
+    auto bias = [&](int k_step) __attribute__((always_inline)) {        // lane = (8-channel group L >> 5, pixels (L & 31) + 32 k) of the landed U tile
+        const char* us = smem + (k_step % NU) * U_SLOT;
+        const int cg = L >> 5;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int p = (L & 31) + 32 * k;
+            const f16x8 hv8 = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(us + U_HI + (cg >> 2) * U_HH + p * HROW + (cg & 3) * 16));
+            const u32x2 rr = *reinterpret_cast<const u32x2*>(us + U_L8 + (cg >> 2) * U_BH + p * BROW + (cg & 3) * 8);
+            const int r0 = (int)rr.x, r1 = (int)rr.y;
+            bs[0] += (float)hv8[0] + __builtin_amdgcn_cvt_f32_fp8(r0, 0) * WSU_F8_GLO_DIV; bs[1] += (float)hv8[1] + __builtin_amdgcn_cvt_f32_fp8(r0, 1) * WSU_F8_GLO_DIV;
+            bs[2] += (float)hv8[2] + __builtin_amdgcn_cvt_f32_fp8(r0, 2) * WSU_F8_GLO_DIV; bs[3] += (float)hv8[3] + __builtin_amdgcn_cvt_f32_fp8(r0, 3) * WSU_F8_GLO_DIV;
+            bs[4] += (float)hv8[4] + __builtin_amdgcn_cvt_f32_fp8(r1, 0) * WSU_F8_GLO_DIV; bs[5] += (float)hv8[5] + __builtin_amdgcn_cvt_f32_fp8(r1, 1) * WSU_F8_GLO_DIV;
+            bs[6] += (float)hv8[6] + __builtin_amdgcn_cvt_f32_fp8(r1, 2) * WSU_F8_GLO_DIV; bs[7] += (float)hv8[7] + __builtin_amdgcn_cvt_f32_fp8(r1, 3) * WSU_F8_GLO_DIV;
+        }
+    };
+    // Every existing step k gets exactly one barrier k on both sides, plus two closing barriers: S + 2 barriers per wave (S >= 2).
+    // DMA of step k + DEPTH goes out behind barrier k; `ahead` = steps issued beyond the one being waited for (PER pieces each stay in flight).
+    auto wait_all_but = [&](int ahead) __attribute__((always_inline)) {
+        if (ahead >= 2)      asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+        else                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    static_assert(PER == 7 && DEPTH == 3, "the vmcnt immediates above");
+    WgrWalk wi = wgr_walk_at(a, t0);                                    // the walk position of the next DMA issue
+    WgrWalk wb = wi;                                                    // the step whose barrier comes next (for the bias pass)
+    int issued = 0;                                                     // steps issued so far
+    for (; issued < DEPTH && wi.t < t1; ++issued) { issue(wi, issued); wgr_advance(a, t1, wi); }        // steps 0 .. DEPTH-1
+    wait_all_but(issued - 1);                                           // step 0 landed (this wave's pieces)
+    derive(0);
+    for (int k = 0; ; ++k) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // this wave's derived copies of step k are written
+        __builtin_amdgcn_s_barrier();                                   // barrier k: the matrix waves start step k; all of step k is visible
+        asm volatile("" ::: "memory");
+        if (wi.t < t1) { if (!(a.ablate & 2)) issue(wi, issued); wgr_advance(a, t1, wi); ++issued; }     // step k + DEPTH: its slots held steps k-1 (U) / k-2 (V)
+        if (bias_on && !wb.pro) bias(k);
+        wgr_advance(a, t1, wb);
+        if (!(wb.t < t1)) break;                                        // no step k+1
+        wait_all_but((a.ablate & 2) ? 0 : issued - (k + 2));             // step k+1 landed
+        if (!(a.ablate & 4)) derive(k + 1);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                       // closing barrier 1: the matrix waves have left the last step
+    asm volatile("" ::: "memory");
+    if (bias_on) {                                                      // per-lane partials -> LDS (the stages are free now)
+        float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[L * 8 + e] = bs[e];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                       // closing barrier 2 (all 16 waves): the partials are visible
+    asm volatile("" ::: "memory");
+    if (bias_on && L < 64) {                                            // one sum per channel over the 32 lanes of its group, in lane order
+        const float* red = reinterpret_cast<const float*>(smem);
+        const int cg = L >> 3, e = L & 7;
+        float sum = 0.f;
+        for (int j = 0; j < 32; ++j) sum += red[(cg * 32 + j) * 8 + e];
+        a.bpart[(size_t)split * (a.nmb * 64) + mb * 64 + L] = sum;
+    }
+}
+
+
+__global__ __launch_bounds__(wgr::NTD) void wgrad_ring_kernel(const WgPlArgs a) {
+    using namespace wgr;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+    // the (mb, nb) workgroups of one split read the same U / V tiles at the same pace: consecutive logical ids share an XCD (one L2)
+    int b = (int)wsu_xcd_remap(blockIdx.x, gridDim.x);
+    const int nb = b % a.nnb; b /= a.nnb;
+    const int mb = b % a.nmb;
+    const int split = b / a.nmb;
+    const int t0 = split * a.tiles_per_split;
+    const int t1 = min(t0 + a.tiles_per_split, a.ntiles);
+    // step sequence (the same state machine on both sides, WgrWalk): tile t0's prologue, t0, t0+1, ..., a prologue before every tile that starts a
+    // column; tiles are numbered down the image columns (ty fastest, then tx, then the image)
+    if (wv >= NMAT) {
+        // ================= loader waves (wgr_loader<LW>: the piece kinds of a wave are compile-time) =======================================
+        switch (wv - NMAT) {
+            case 0: wgr_loader<0>(a, smem, lane, split, mb, nb, t0, t1); break;
+            case 1: wgr_loader<1>(a, smem, lane, split, mb, nb, t0, t1); break;
+            case 2: wgr_loader<2>(a, smem, lane, split, mb, nb, t0, t1); break;
+            default: wgr_loader<3>(a, smem, lane, split, mb, nb, t0, t1); break;
+        }
+        return;
+    }
+
+    // ================= matrix waves ========================================================================================================
+    const int blk = wv & 3, ky = wv >> 2, wm = blk >> 1, wn = blk & 1;
+    const int sc_a = hh ? WSU_F8_SCALE_GLO : WSU_F8_SCALE_G, sc_b = hh ? WSU_F8_SCALE_X : WSU_F8_SCALE_XLO;
+    f32x16 acc[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const bool empty = t0 >= t1;
+    WgrWalk w = wgr_walk_at(a, t0);
+    for (int k = 0; w.t < t1; ++k) {
+        __builtin_amdgcn_s_barrier();                                   // step k is in LDS
+        asm volatile("" ::: "memory");
+        if (!w.pro && !(a.ablate & 1)) {
+            const char* us = smem + (k % NU) * U_SLOT;
+            const char* u_hi = us + U_HI + wm * U_HH; const char* u_c8 = us + U_C8 + wm * U_BH; const char* u_l8 = us + U_L8 + wm * U_BH;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const u32x4 ah0 = wgr_frag16(u_hi, r * TW + 8 * hh), ah1 = wgr_frag16(u_hi, r * TW + 16 + 8 * hh);
+                const u32x4 a8 = wgr_frag8(u_c8, r * TW + 16 * hh), al8 = wgr_frag8(u_l8, r * TW + 16 * hh);
+                const int i = r + ky;                                   // window row 0..3: rows 0, 1 came with step k-1, rows 2, 3 with step k
+                const char* vs = smem + V_BASE + ((i < 2 ? k + NV - 1 : k) % NV) * V_SLOT;
+                const char* v_hi = vs + V_HI + wn * V_HH; const char* v_c8 = vs + V_C8 + wn * V_BH; const char* v_l8 = vs + V_L8 + wn * V_BH;
+                const int vrow0 = (i & 1) * VW;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int vrow = vrow0 + kx;
+                    const u32x4 bl8 = wgr_frag8(v_l8, vrow + 16 * hh), b8 = wgr_frag8(v_c8, vrow + 16 * hh);
+                    wsu_mfma_f8x2(a8, al8, bl8, b8, sc_a, sc_b, acc[kx]);
+                    const u32x4 bh0 = wgr_frag16(v_hi, vrow + 8 * hh), bh1 = wgr_frag16(v_hi, vrow + 16 + 8 * hh);
+                    wsu_mfma_f16(ah0, bh0, acc[kx]);
+                    wsu_mfma_f16(ah1, bh1, acc[kx]);
+                }
+            }
+        }
+        wgr_advance(a, t1, w);
+    }
+    if (!empty) {
+        __builtin_amdgcn_s_barrier();                                   // the two closing barriers (the loaders publish their bias partials between them)
+        __builtin_amdgcn_s_barrier();
+    }
+    float* dst = a.part + ((size_t)((split * a.nmb + mb) * a.nnb + nb) * 9) * 4096;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            dst[(size_t)(ky * 3 + kx) * 4096 + m * 64 + wn * 32 + l31] = acc[kx][r];
+        }
+}
+
 // dW (conv: OIHW [M = co][Ntot = ci][3][3]; convT: IOHW [M = ci][Ntot = co][2][2]) = sum over splits, fixed order
 template <int KIND>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bpart,
@@ -793,6 +1092,29 @@ int run_wgrad_pl(WgPlArgs a, float* dw, float* db, float* workspace, size_t work
     static int ablate = -1;
     if (ablate < 0) { const char* e = getenv("WSU_WGRAD_ABLATE"); ablate = e ? atoi(e) : 0; }
     a.ablate = ablate;
+    static int impl = -1;                                              // WSU_WGRAD_IMPL=reg: the register-staged kernel (A/B runs)
+    if (impl < 0) { const char* e = getenv("WSU_WGRAD_IMPL"); impl = (e && e[0] == 'r') ? 0 : 1; }
+    if (KIND == 0 && impl == 1) {
+        // one persistent-style workgroup per CU: the splits cover the tiles, fewer and longer than the register-staged kernel's
+        static int ncu = 0;
+        if (ncu == 0) {
+            int dev = 0; hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { wsu_set_error("wgrad_ring: cannot query the device"); return WSU_ERR_HIP; }
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_ring_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, wgr::LDS_TOTAL);
+            if (e != hipSuccess) { wsu_set_error("hipFuncSetAttribute(wgrad_ring): %s", hipGetErrorString(e)); return WSU_ERR_HIP; }
+            ncu = prop.multiProcessorCount;
+        }
+        int ns = (ncu + a.nmb * a.nnb - 1) / (a.nmb * a.nnb);
+        ns = max(1, min(ns, min(nsplit, a.ntiles)));
+        a.nsplit = ns;
+        a.tiles_per_split = (a.ntiles + ns - 1) / ns;
+        a.bpart = db ? workspace + (size_t)ns * slab / sizeof(float) : nullptr;
+        hipLaunchKernelGGL(wgrad_ring_kernel, dim3(ns * a.nmb * a.nnb), dim3(wgr::NTD), wgr::LDS_TOTAL, s, a);
+        int rc = wsu_check_launch("wgrad_ring_kernel");
+        if (rc) return rc;
+        hipLaunchKernelGGL(wgrad_reduce_kernel<KIND>, dim3(512), dim3(256), 0, s, a.part, (const float*)a.bpart, dw, a.bpart ? db : (float*)nullptr, ns, a.nmb, a.nnb, nbias);
+        return wsu_check_launch("wgrad_reduce_kernel");
+    }
     static bool attr = false;
     if (!attr) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_pl_kernel<KIND>), hipFuncAttributeMaxDynamicSharedMemorySize, GeoX3<KIND>::LDS_F8);
