@@ -1,6 +1,6 @@
 """Train-step timing (BASELINE.json configs[2]): unet_2 fwd + L1WS loss + bwd + AdamW on a synthetic batch of
 512x512 cover/stego pairs.  Prints one JSON line with images/s (whole job) and the per-kernel time split of rank 0.
-Usage: python tools/bench_train.py [--batch 16] [--steps 5] [--size 512] [--train-mode bf16x3|f32]
+Usage: python tools/bench_train.py [--batch 16] [--steps 5] [--size 512] [--train-mode f16f8p|bf16x3|f32]
 Data parallel (BASELINE configs[4], e.g. 8 x batch 8 @ 1024): one process per GPU, `--batch` is per rank, the flat gradient
 bucket is all-reduced over RCCL every step:
   python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 tools/bench_train.py --batch 8 --size 1024"""
@@ -17,11 +17,11 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=16)
 ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--size", type=int, default=512)
-ap.add_argument("--train-mode", default="bf16x3")
+ap.add_argument("--train-mode", default="f16f8p")
 a = ap.parse_args()
 rank, world = parallel.init_from_env()
 dev = torch.device("cuda", torch.cuda.current_device())
-m = get_model("unet_2", in_channels=1, out_channels=1, channel=[0], drop_rate=None, mode="f32")
+m = get_model("unet_2", in_channels=1, out_channels=1, channel=[0], drop_rate=None, mode="f32" if a.train_mode == "f32" else "f16f8p")
 m.load_state_dict({k: torch.from_numpy(v) for k, v in formula.formula_state_dict(2, "default").items()})
 m = m.to(dev); m.train_mode = a.train_mode
 cov = formula.synthetic_images(a.batch, a.size, a.size, seed=5 + rank)      # every rank its own shard of the global batch
