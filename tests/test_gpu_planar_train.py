@@ -80,6 +80,11 @@ def test_conv3x3_pl_bwd_data(n, h, w, cin, csplit, cout, masked, pad_zero):
     (1, 37, 70, 64, 0, 128),            # partial tiles, several tiles per image column (rolling row window)
     (2, 24, 40, 64, 64, 64),            # fused concat
     (3, 10, 33, 128, 0, 64),
+    # shapes where a workgroup of the ring kernel walks several steps (256 CUs): across column ends, with empty splits, the LDS ring wrapping
+    (4, 100, 96, 64, 0, 64),            # 600 tiles over 256 workgroups: 3 tiles each, columns of 50 tiles, 56 empty splits
+    (2, 320, 128, 64, 0, 64),           # 1280 tiles: 5 tiles + prologue per workgroup (ring of 4 U / 5 V slots wraps)
+    (1, 200, 96, 128, 0, 128),          # 4 (mb, nb) workgroups per split: 64 splits of 5 tiles, columns of 100
+    (1, 96, 160, 64, 64, 64),           # fused concat, 240 tiles over 128 splits
 ])
 def test_conv3x3_pl_bwd_weight(n, h, w, c1, c2, cout):
     ops = _ops()
@@ -224,12 +229,14 @@ def test_unet_gradients_golden_planar(grad_golden, ns):
         assert torch.equal(p.grad, first[k]), k                        # deterministic
 
 
-def test_planar_vs_fp32_storage_gradients_smooth_loss():
-    """The two training paths of one model under a smooth (L2) loss at 2x1x128x128: same arithmetic class, different storage -- every parameter
-    gradient agrees to a relative L2 of 1e-3 (ReLU-mask flips on rounding noise are the floor; test_gpu_backward_large.py)."""
+@pytest.mark.parametrize("n,size", [(2, 128), (1, 512)])
+def test_planar_vs_fp32_storage_gradients_smooth_loss(n, size):
+    """The two training paths of one model under a smooth (L2) loss: same arithmetic class, different storage -- every parameter gradient agrees
+    to a relative L2 of 2e-3 (ReLU-mask flips on rounding noise are the floor; test_gpu_backward_large.py).  At 512x512 every persistent
+    workgroup of the data-gradient kernel walks several tiles and the weight-gradient ring several steps."""
     model = gpu_model(2, "he", "f16f8p")
-    x = torch.rand((2, 1, 128, 128), generator=torch.Generator().manual_seed(3)).to(DEV)
-    tgt = torch.rand((2, 1, 128, 128), generator=torch.Generator().manual_seed(4)).to(DEV)
+    x = torch.rand((n, 1, size, size), generator=torch.Generator().manual_seed(3)).to(DEV)
+    tgt = torch.rand((n, 1, size, size), generator=torch.Generator().manual_seed(4)).to(DEV)
     res = {}
     for tm in ("f32", "f16f8p"):
         model.train_mode = tm
