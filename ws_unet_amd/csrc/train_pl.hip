@@ -299,9 +299,11 @@ __global__ __launch_bounds__(256) void chansum_pl_kernel(const char* __restrict_
         if constexpr (FIRST) {
             const int y = (int)(pix / w), x = (int)(pix % w);
             const float* src = img + (size_t)im * hw;
+            const int ro[3] = {wsu_reflect(y - 1, h) * w, y * w, wsu_reflect(y + 1, h) * w};
+            const int co[3] = {wsu_reflect(x - 1, w), x, wsu_reflect(x + 1, w)};
 #pragma unroll
             for (int tp = 0; tp < 9; ++tp) {
-                const float iv = src[(size_t)wsu_reflect(y + tp / 3 - 1, h) * w + wsu_reflect(x + tp % 3 - 1, w)];
+                const float iv = src[ro[tp / 3] + co[tp % 3]];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) acc[tp][e] = fmaf(gv[e], iv, acc[tp][e]);
             }
@@ -329,13 +331,15 @@ __global__ __launch_bounds__(256) void chansum_pl_kernel(const char* __restrict_
         }
     }
 }
-// out[i] = sum over blocks of part[b][i], i < count (fixed order)
-__global__ void block_sum_kernel(const float* __restrict__ part, float* __restrict__ out, int nblocks, int count) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= count) return;
+// out[i] = sum over blocks of part[b][i], i < count: one wave per output, lane-strided partial sums + a butterfly (a fixed order: deterministic)
+__global__ __launch_bounds__(256) void block_sum_kernel(const float* __restrict__ part, float* __restrict__ out, int nblocks, int count) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= count) return;                                   // wave-uniform
     float sacc = 0.f;
-    for (int b = 0; b < nblocks; ++b) sacc += part[(size_t)b * count + i];
-    out[i] = sacc;
+    for (int b = lane; b < nblocks; b += 64) sacc += part[(size_t)b * count + i];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) sacc += __shfl_xor(sacc, m);
+    if (lane == 0) out[i] = sacc;
 }
 // first layer: [c][10] sums -> dw (c, 1, 3, 3), db (c)
 __global__ void first_split_kernel(const float* __restrict__ sums, float* __restrict__ dw, float* __restrict__ db, int c) {
@@ -414,7 +418,7 @@ int wsu_colsum_pl(const void* g, float* db, float* workspace, size_t workspace_b
     hipLaunchKernelGGL(chansum_pl_kernel<false>, dim3(nblk), dim3(256), 0, s, (const char*)g, (const float*)nullptr, workspace, n, h, w, c);
     int rc = wsu_check_launch("chansum_pl_kernel");
     if (rc) return rc;
-    hipLaunchKernelGGL(block_sum_kernel, dim3((c + 63) / 64), dim3(64), 0, s, workspace, db, nblk, c);
+    hipLaunchKernelGGL(block_sum_kernel, dim3((c + 3) / 4), dim3(256), 0, s, workspace, db, nblk, c);
     return wsu_check_launch("block_sum_kernel");
 }
 
@@ -432,7 +436,7 @@ int wsu_conv3x3_first_pl_bwd_weight(const void* g, const float* img, float* dw, 
     hipLaunchKernelGGL(chansum_pl_kernel<true>, dim3(nblk), dim3(256), 0, s, (const char*)g, img, workspace, n, h, w, c);
     int rc = wsu_check_launch("chansum_pl_kernel<first>");
     if (rc) return rc;
-    hipLaunchKernelGGL(block_sum_kernel, dim3((c * 10 + 63) / 64), dim3(64), 0, s, workspace, sums, nblk, c * 10);
+    hipLaunchKernelGGL(block_sum_kernel, dim3((c * 10 + 3) / 4), dim3(256), 0, s, workspace, sums, nblk, c * 10);
     rc = wsu_check_launch("block_sum_kernel");
     if (rc) return rc;
     hipLaunchKernelGGL(first_split_kernel, dim3((c * 10 + 63) / 64), dim3(64), 0, s, (const float*)sums, dw, db, c);

@@ -457,7 +457,7 @@ __global__ __launch_bounds__(NT, 2) void wgrad_pl_kernel(const WgPlArgs a) {
     constexpr bool UGRAD = KIND == 0;                      // which operand is the gradient
 
     const int tid = threadIdx.x;
-    int b = blockIdx.x;
+    int b = (int)wsu_xcd_remap(blockIdx.x, gridDim.x);      // the (mb, nb) workgroups of a split share their U / V tiles: same XCD, one L2
     const int nb = b % a.nnb; b /= a.nnb;
     const int mb = b % a.nmb;
     const int split = b / a.nmb;
