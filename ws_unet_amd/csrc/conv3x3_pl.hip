@@ -208,7 +208,14 @@ __global__ __launch_bounds__(NT) void conv3x3_pl_kernel(const PlArgs a) {
         if (tid < 64) s_b1[tid] = a.b1 ? a.b1[tid] : 0.f;
     }
     // (these plain loads have retired -- their values went into the LDS stores -- before the first vmcnt wait below; the barrier of
-    // step 0 publishes them)
+    // step 0 publishes them.  The fused first layer reads w1 / b1 BEFORE that barrier -- the loaders compute step 0's planes from them --
+    // so that variant takes one barrier of its own here: without it the first tile of a workgroup was intermittently computed from
+    // table entries another wave had not written yet.)
+    if constexpr (F1) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
     unsigned long long t_wait = 0, t_bar = 0, t_dma = 0, t_mma = 0, t_epi = 0, t0 = 0, rt0 = 0;
     unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0;
     STAMP(t0);
