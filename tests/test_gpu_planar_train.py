@@ -104,6 +104,25 @@ def test_conv3x3_pl_bwd_weight(n, h, w, c1, c2, cout):
     assert torch.equal(dw, dw2)                                        # fixed-order reduction
 
 
+def test_planar_backward_kernels_race_screen():
+    """Repeat launches of the pipelined backward kernels (weight-gradient ring: LDS-DMA three steps deep; data gradient: persistent kernel + ring
+    launches) must be bitwise identical: a missing wait or barrier shows up as a launch-to-launch difference."""
+    ops = _ops()
+    n, h, w, c = 2, 320, 128, 64
+    x = planar_encode(torch.relu(_rand((n, c, h, w), 21)))
+    g = planar_encode(_rand((n, c, h, w), 22), GRAD_LO)
+    wd = _rand((c, c, 3, 3), 23, 0.05).to(DEV)
+    wp, wr = ops.pack_conv3x3(wd, ops.MODE_F16F8, dgrad=True), ops.pack_conv3x3_ring(wd)
+    dw0, db0 = ops.conv3x3_pl_bwd_weight(g, x, None)
+    dx0, _ = ops.conv3x3_pl_bwd_data(g, wp, wr, c, c, x, None)
+    dw0, db0, dx0 = dw0.clone(), db0.clone(), dx0.clone()
+    for _ in range(15):
+        dw, db = ops.conv3x3_pl_bwd_weight(g, x, None)
+        dx, _ = ops.conv3x3_pl_bwd_data(g, wp, wr, c, c, x, None)
+        assert torch.equal(dw, dw0) and torch.equal(db, db0)
+        assert torch.equal(dx.view(torch.int32), dx0.view(torch.int32))
+
+
 @pytest.mark.parametrize("n,h,w,cin,cout", [(2, 8, 32, 64, 64), (1, 13, 40, 128, 64), (2, 5, 7, 64, 128)])
 def test_convt2x2_pl_bwd_weight(n, h, w, cin, cout):
     ops = _ops()
