@@ -283,3 +283,28 @@ def test_planar_training_deep_nets(ns):
     for k in res["f32"]:
         dp, dx = rel_l2(res["f16f8p"][k], res["f32"][k]), rel_l2(res["bf16x3"][k], res["f32"][k])
         assert dp < 1.5 * dx + 5e-4 and dp < 1e-2, (k, dp, dx)
+
+
+def test_planar_training_fallback_for_input_gradients():
+    """A planar model asked for dL/dx (saliency, src/saliency.py:159-174) takes the fp32-storage training path for that call -- the planar path
+    has no input-gradient kernel -- and a plain training call afterwards is planar again."""
+    ops = _ops()
+    model = gpu_model(1, "he", "f16f8p")
+    assert model.train_mode == "f16f8p"
+    x = torch.rand((1, 1, 64, 64), generator=torch.Generator().manual_seed(9)).to(DEV)
+    used = []
+    for rg in (True, False):
+        xi = x.clone().requires_grad_(rg)
+        timer = ops.KernelTimer()
+        ops.set_timer(timer)
+        try:
+            model.zero_grad()
+            model(xi).sum().backward()
+            torch.cuda.synchronize()
+        finally:
+            ops.set_timer(None)
+        used.append(set(timer.summary()))
+        if rg:
+            assert xi.grad is not None and torch.isfinite(xi.grad).all() and float(xi.grad.abs().max()) > 0
+    assert "conv3x3_bwd_data" in used[0] and "conv3x3_pl_bwd_data" not in used[0]
+    assert "conv3x3_pl_bwd_data" in used[1] and "conv3x3_bwd_data" not in used[1]
