@@ -3,7 +3,7 @@
 // src/detector/train.py:55-95; oracle: oracle/unet_ref.py under torch.autograd):
 //   * reflect-padding adjoint of the 3x3 data gradient: gather of the gradient's border rows / columns into strips, and the fold of the
 //     strips' 1x3 convolutions (computed by conv3x3_pl_kernel<GRAD> with the ring weight sets) back onto rows 1, H-2 / columns 1, W-2
-//   * (further down) max-pool backward, head backward, first-layer weight gradient, bias sums
+//   * max-pool backward (+ skip add + ReLU mask), head backward, per-channel sums, first-layer weight gradient
 // Planar layout (include/wsu.h): [n][C/16][3 planes][H][W][16 B], planes = f16 ch 0-7 | f16 ch 8-15 | e4m3 residuals ch 0-15; activations
 // scale the residual by 2^12, gradients by 2^14 (wsu_device.h).  Everything is deterministic (fixed-order reductions, no float atomics).
 #include "wsu_device.h"

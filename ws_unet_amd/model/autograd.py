@@ -1,12 +1,16 @@
 """Training path of the UNet: one torch.autograd.Function whose forward and backward are libwsu kernels.
 
 The reference has no hand-written backward -- it relies on autograd through
-src/unet/model/unet.py:137-189.  Here the whole network is ONE autograd node: forward saves the NHWC
-activations (and 2-bit pool argmax), backward walks the layers in reverse calling the K7 kernels
-(include/wsu.h).  All activations stay fp32; `model.train_mode` picks the arithmetic of the forward /
-data-gradient / weight-gradient GEMMs ('f32' exact, or 'bf16x3': split-bf16 weight gradients, and -- `train_fwd_mode` / `train_bwd_mode`,
-default 'f16f8x' -- the f16f8 arithmetic for the forward and data-gradient 3x3 convs); bias gradients are exact fp32 sums.
-The gradient w.r.t. the network input (saliency, src/saliency.py:159-174) is produced when `x.requires_grad`.
+src/unet/model/unet.py:137-189.  Here the whole network is ONE autograd node: forward saves the
+activations, backward walks the layers in reverse calling the K7 kernels (include/wsu.h).  `model.train_mode` picks the path:
+  'f16f8p'  (default for planar models) activations AND gradients in the planar three-plane layout (3 bytes per element), the f16f8
+            arithmetic in forward, data gradient and weight gradient (_forward_train_pl / _backward_pl); single-plane inputs, no input
+            gradient -- other calls fall back to 'bf16x3';
+  'bf16x3'  fp32 NHWC tensors; the matrix kernels run the f16f8 arithmetic on them (`train_fwd_mode` / `train_bwd_mode` = 'f16f8x', default)
+            or split-bf16; 2-bit pool argmax saved by the forward;
+  'f32'     exact fp32 on the matrix cores.
+Bias gradients are fp32 sums in every mode.  The gradient w.r.t. the network input (saliency, src/saliency.py:159-174) is produced when
+`x.requires_grad`.
 
 Conventions inside backward: `g` is the PRE-activation gradient of the layer being processed; every kernel
 that produces the gradient w.r.t. a post-ReLU activation applies that activation's ReLU mask itself
