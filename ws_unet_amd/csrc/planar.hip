@@ -46,7 +46,9 @@ constexpr int IN1 = WSU_GRAN * PLANE;                     // 8192 per chunk
 constexpr int W1 = 4 * WSU_GRAN * WSU_COB * 16;           // 16384 per chunk (layout of wsu_convt2x2_pack, mode F16F8)
 constexpr int CHUNK = IN1 + W1;                           // 24576
 constexpr int STAGE = 2 * CHUNK;                          // 49152
-constexpr int LDS_EXTRA = 2 * STAGE;                      // bias [1024]
+constexpr int NSTAGE = 3;                                 // the DMA of step j+2 goes out behind barrier j (a step of this kernel is ~1.5 us of
+                                                          // matrix work: one step of distance left the DMA's latency exposed -- 4.3 k cycles per step)
+constexpr int LDS_EXTRA = NSTAGE * STAGE;                 // bias [1024]
 constexpr int LDS_TOTAL = LDS_EXTRA + 1024 * 4;
 constexpr int NWAVE = 8, NLOAD = 4, NT = (NWAVE + NLOAD) * 64;
 constexpr int HBM_PLANES = 3;                             // stored planes per chunk (LDS plane 3 is derived by the loaders)
@@ -108,15 +110,23 @@ __global__ __launch_bounds__(ct::NT) void convt2x2_pl_kernel(const CtpArgs a) {
     for (int i = tid; i < a.cout; i += NT) s_bias[i] = a.bias ? a.bias[i] : 0.f;
 
     if (wv >= NWAVE) {
-        // ---- loader waves ----------------------------------------------------------------------------------------------------------
+        // ---- loader waves: every wave issues IN_PER + W_PER = 11 pieces per step (all lanes live), so `vmcnt(11)` = "my pieces of step j have
+        //      landed, those of step j+1 are still in flight" ------------------------------------------------------------------------------
         const int lw8 = wv - NWAVE;
-        CtTile t = ct_tile_of(a, lw);
-        if (J > 0) ct_issue_dma(a, t, 0, smem, lw8, lane);
+        static_assert(IN_PER + W_PER == 11, "the vmcnt immediate below");
+        CtTile t = ct_tile_of(a, lw);                                   // tile / step of the NEXT issue
         int c = 0, kt = 0;
+        auto issue_next = [&](int j_issue) __attribute__((always_inline)) {
+            ct_issue_dma(a, t, c, smem + (j_issue % NSTAGE) * STAGE, lw8, lane);
+            if (++c == a.nst) { c = 0; ++kt; t = ct_tile_of(a, lw + kt * G); }
+        };
+        if (J > 0) issue_next(0);
+        if (J > 1) issue_next(1);
         for (int j = 0; j < J; ++j) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (j + 1 < J) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+            else           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             {   // LDS plane 3 = e4m3 copies of the f16 granules this wave fetched (same lanes: no cross-wave dependency)
-                char* st = smem + (j & 1) * STAGE;
+                char* st = smem + (j % NSTAGE) * STAGE;
 #pragma unroll
                 for (int k = 0; k < IN_PER; ++k) {
                     const int slot = lw8 + NLOAD * k;
@@ -131,10 +141,7 @@ __global__ __launch_bounds__(ct::NT) void convt2x2_pl_kernel(const CtpArgs a) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            if (j + 1 < J) {
-                if (++c == a.nst) { c = 0; ++kt; t = ct_tile_of(a, lw + kt * G); }
-                ct_issue_dma(a, t, c, smem + ((j + 1) & 1) * STAGE, lw8, lane);
-            }
+            if (j + 2 < J) issue_next(j + 2);                           // its stage held step j-1: every matrix wave is past it
         }
         return;
     }
@@ -148,7 +155,7 @@ __global__ __launch_bounds__(ct::NT) void convt2x2_pl_kernel(const CtpArgs a) {
     for (int j = 0; j < J; ++j) {
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        const char* st = smem + (j & 1) * STAGE;
+        const char* st = smem + (j % NSTAGE) * STAGE;
         if (c == 0) {
 #pragma unroll
             for (int b = 0; b < 2; ++b)
@@ -239,7 +246,8 @@ constexpr int TW = 32, TH = 4, NPIX = TW * TH;
 constexpr int IN1 = 4 * 4 * NPIX * 16;                    // 32768: [plane 4][sub 4][128 px][16 B]
 constexpr int W1 = 4 * 4 * WSU_COB * 16;                  // 16384: [sub 4][plane 4][64 ci][16 B]
 constexpr int STAGE = IN1 + W1;                           // 49152
-constexpr int LDS_TOTAL = 2 * STAGE;
+constexpr int NSTAGE = 3;                                 // DMA two steps ahead (see ct::NSTAGE)
+constexpr int LDS_TOTAL = NSTAGE * STAGE;
 constexpr int NWAVE = 8, NLOAD = 8, NT = (NWAVE + NLOAD) * 64;
 constexpr int IN_SLOTS = 3 * 4 * 2, W_SLOTS = W1 / 1024;  // 24 + 16 pieces per chunk
 constexpr int PER = (IN_SLOTS + W_SLOTS) / NLOAD;         // 5
@@ -294,13 +302,20 @@ __global__ __launch_bounds__(ctb::NT) void convt2x2_bwd_pl_kernel(const CtbPlArg
 
     if (wv >= NWAVE) {
         const int lw8 = wv - NWAVE;
-        CtTile t = ctb_tile_of(a, lw);
-        if (J > 0) ctb_issue_dma(a, t, 0, smem, lw8, lane);
+        static_assert(PER == 5, "the vmcnt immediate below");           // every piece has live lanes: PER DMA instructions per wave and step
+        CtTile t = ctb_tile_of(a, lw);                                  // tile / chunk of the NEXT issue
         int c = 0, kt = 0;
+        auto issue_next = [&](int j_issue) __attribute__((always_inline)) {
+            ctb_issue_dma(a, t, c, smem + (j_issue % NSTAGE) * STAGE, lw8, lane);
+            if (++c == a.nch) { c = 0; ++kt; t = ctb_tile_of(a, lw + kt * G); }
+        };
+        if (J > 0) issue_next(0);
+        if (J > 1) issue_next(1);
         for (int j = 0; j < J; ++j) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (j + 1 < J) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");   // my pieces of step j landed, step j+1's stay in flight
+            else           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             {   // LDS plane 3 = e4m3(g * 4) of the f16 granules this wave fetched
-                char* st = smem + (j & 1) * STAGE;
+                char* st = smem + (j % NSTAGE) * STAGE;
 #pragma unroll
                 for (int k = 0; k < PER; ++k) {
                     const int slot = lw8 + NLOAD * k;
@@ -315,10 +330,7 @@ __global__ __launch_bounds__(ctb::NT) void convt2x2_bwd_pl_kernel(const CtbPlArg
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            if (j + 1 < J) {
-                if (++c == a.nch) { c = 0; ++kt; t = ctb_tile_of(a, lw + kt * G); }
-                ctb_issue_dma(a, t, c, smem + ((j + 1) & 1) * STAGE, lw8, lane);
-            }
+            if (j + 2 < J) issue_next(j + 2);                           // its stage held step j-1: every matrix wave is past it
         }
         return;
     }
@@ -334,7 +346,7 @@ __global__ __launch_bounds__(ctb::NT) void convt2x2_bwd_pl_kernel(const CtbPlArg
     for (int j = 0; j < J; ++j) {
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        const char* st = smem + (j & 1) * STAGE;
+        const char* st = smem + (j % NSTAGE) * STAGE;
         if (c == 0) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
