@@ -308,3 +308,28 @@ def test_planar_training_fallback_for_input_gradients():
             assert xi.grad is not None and torch.isfinite(xi.grad).all() and float(xi.grad.abs().max()) > 0
     assert "conv3x3_bwd_data" in used[0] and "conv3x3_pl_bwd_data" not in used[0]
     assert "conv3x3_pl_bwd_data" in used[1] and "conv3x3_bwd_data" not in used[1]
+
+
+def test_planar_training_range_fallback(caplog):
+    """Activations beyond +-448 (here: e11 scaled up, e12 scaled down) make the FIRST planar training forward switch the model to fp32 storage,
+    loudly; the gradients of that call already come from the fp32-storage path."""
+    import logging
+    ops = _ops()
+    model = gpu_model(1, "he", "f16f8p")
+    with torch.no_grad():
+        model.e11.weight.mul_(3000.0); model.e11.bias.mul_(3000.0); model.e12.weight.div_(3000.0)
+    model.invalidate_packed()
+    x = torch.rand((1, 1, 32, 64), generator=torch.Generator().manual_seed(10)).to(DEV)
+    timer = ops.KernelTimer()
+    ops.set_timer(timer)
+    try:
+        with caplog.at_level(logging.WARNING):
+            model(x).sum().backward()
+        torch.cuda.synchronize()
+    finally:
+        ops.set_timer(None)
+    assert model.train_mode == "bf16x3"
+    assert any("train_mode 'f16f8p'" in r.getMessage() for r in caplog.records)
+    used = set(timer.summary())
+    assert "conv3x3_bwd_data" in used and "conv3x3_pl_bwd_data" not in used
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters())

@@ -70,32 +70,33 @@ def _forward_train_pl(model, x: torch.Tensor) -> Dict[str, torch.Tensor]:
     W = ops.MODE_F16F8
     t: Dict[str, torch.Tensor] = {}
     e11 = model.e11
+    rf = model._range_flag_tensor(x.device)         # OR-ed by every epilogue that stores an activation beyond +-448 (UNet.range_exceeded)
     head = dict(head_w=model.outconv.weight.detach(), head_b=model.outconv.bias.detach())
-    cur = t["xe11"] = ops.conv3x3_first_pl(x, e11.weight, e11.bias.detach())
+    cur = t["xe11"] = ops.conv3x3_first_pl(x, e11.weight, e11.bias.detach(), range_flag=rf)
     for lvl in range(model.nsteps + 1):
         a, b = ENC[lvl]
         if lvl >= 1:
             la = getattr(model, a)
-            cur = t["x" + a] = ops.conv3x3_pl(cur, None, model._packed(a, W, "conv"), la.bias.detach(), la.out_channels)
+            cur = t["x" + a] = ops.conv3x3_pl(cur, None, model._packed(a, W, "conv"), la.bias.detach(), la.out_channels, range_flag=rf)
         lb = getattr(model, b)
         if lvl < model.nsteps:
-            t["x" + b], cur = ops.conv3x3_pl(cur, None, model._packed(b, W, "conv"), lb.bias.detach(), lb.out_channels, pool=True)
+            t["x" + b], cur = ops.conv3x3_pl(cur, None, model._packed(b, W, "conv"), lb.bias.detach(), lb.out_channels, pool=True, range_flag=rf)
             t[f"xp{lvl + 1}"] = cur
         elif model.nsteps == 0:
-            t["out"], cur = ops.conv3x3_pl(cur, None, model._packed(b, W, "conv"), lb.bias.detach(), lb.out_channels, **head)
+            t["out"], cur = ops.conv3x3_pl(cur, None, model._packed(b, W, "conv"), lb.bias.detach(), lb.out_channels, range_flag=rf, **head)
             t["x" + b] = cur
         else:
-            cur = t["x" + b] = ops.conv3x3_pl(cur, None, model._packed(b, W, "conv"), lb.bias.detach(), lb.out_channels)
+            cur = t["x" + b] = ops.conv3x3_pl(cur, None, model._packed(b, W, "conv"), lb.bias.detach(), lb.out_channels, range_flag=rf)
     for depth in range(model.nsteps, 0, -1):
         up, c1, c2 = dec_names(depth)
         lu, l1, l2 = getattr(model, up), getattr(model, c1), getattr(model, c2)
-        xu = t["xu" + up[-1]] = ops.convt2x2_pl(cur, model._packed(up, W, "convt"), lu.bias.detach(), lu.out_channels)
-        cur = t["x" + c1] = ops.conv3x3_pl(xu, t["x" + ENC[depth - 1][1]], model._packed(c1, W, "conv"), l1.bias.detach(), l1.out_channels)
+        xu = t["xu" + up[-1]] = ops.convt2x2_pl(cur, model._packed(up, W, "convt"), lu.bias.detach(), lu.out_channels, range_flag=rf)
+        cur = t["x" + c1] = ops.conv3x3_pl(xu, t["x" + ENC[depth - 1][1]], model._packed(c1, W, "conv"), l1.bias.detach(), l1.out_channels, range_flag=rf)
         if depth == 1:
-            t["out"], cur = ops.conv3x3_pl(cur, None, model._packed(c2, W, "conv"), l2.bias.detach(), l2.out_channels, **head)
+            t["out"], cur = ops.conv3x3_pl(cur, None, model._packed(c2, W, "conv"), l2.bias.detach(), l2.out_channels, range_flag=rf, **head)
             t["x" + c2] = cur
         else:
-            cur = t["x" + c2] = ops.conv3x3_pl(cur, None, model._packed(c2, W, "conv"), l2.bias.detach(), l2.out_channels)
+            cur = t["x" + c2] = ops.conv3x3_pl(cur, None, model._packed(c2, W, "conv"), l2.bias.detach(), l2.out_channels, range_flag=rf)
     t["last"] = cur
     return t
 
@@ -146,6 +147,18 @@ def planar_train_ok(model, x: torch.Tensor) -> bool:
     return model._planar_ok() and model.e11.in_channels == 1 and model.outconv.in_channels == 64 and not x.requires_grad
 
 
+def planar_range_fallback(model) -> bool:
+    """True (after switching the model to train_mode 'bf16x3', loudly) if a planar forward stored activations beyond +-448 since the last look:
+    there the e4m3 residual saturates and the planar format keeps only f16 accuracy; fp32 storage has fp32's range."""
+    if not model.range_exceeded():
+        return False
+    import logging
+    logging.warning("ws_unet_amd.UNet: activations beyond +-448 while training in train_mode 'f16f8p' (the planar format's e4m3 residual "
+                    "saturates there); switching this model to train_mode 'bf16x3' (fp32 storage)")
+    model.train_mode = "bf16x3"
+    return True
+
+
 class _UNetFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, x, *params):
@@ -153,9 +166,17 @@ class _UNetFn(torch.autograd.Function):
         if tm == "f16f8p":
             if planar_train_ok(model, x):
                 t = _forward_train_pl(model, x)
-                ctx.model, ctx.t, ctx.x, ctx.m = model, t, x, ops.MODE_F16F8P
-                return t["out"]
-            tm = "bf16x3"                               # input gradients (saliency) and odd shapes: the fp32-storage path
+                ok = True
+                if not getattr(model, "_range_checked_train", False):
+                    # first planar training forward of this model: one synchronising look at the range flag, as the inference path does.  The
+                    # trainer looks again after every epoch (Trainer._run_epoch): weights move.
+                    model._range_checked_train = True
+                    ok = not planar_range_fallback(model)
+                if ok:
+                    ctx.model, ctx.t, ctx.x, ctx.m = model, t, x, ops.MODE_F16F8P
+                    return t["out"]
+                t = None
+            tm = model.train_mode if model.train_mode != "f16f8p" else "bf16x3"   # input gradients (saliency), odd shapes, range fallback: fp32 storage
         m = ops.mode_id(tm)
         if m == ops.MODE_BF16:
             raise ValueError("train_mode must be 'f32' or 'bf16x3' (activations are kept in fp32 for the backward pass)")

@@ -166,9 +166,20 @@ class Trainer:
             acc += m * torch.tensor([float(inputs.shape[0]), 1.0, 1.0], dtype=torch.float64, device=dev)
             nimg += inputs.shape[0]
             nbatch += 1
-        sums = torch.cat([acc, torch.tensor([float(nimg), float(nbatch)], dtype=torch.float64, device=dev)])
+        # the planar format's range flag (activations beyond +-448 stored during this epoch's planar forwards, UNet.range_exceeded) rides on the
+        # same reduction: every rank sees the same count and takes the same decision
+        rf = getattr(self.model, "_range_flag", None)
+        flag = rf.to(torch.float64).reshape(1) if (rf is not None and rf.device == dev) else torch.zeros(1, dtype=torch.float64, device=dev)
+        sums = torch.cat([acc, torch.tensor([float(nimg), float(nbatch)], dtype=torch.float64, device=dev), flag])
         tot = parallel.reduce_epoch_sums_(sums).cpu().numpy()            # global sums on every rank; the epoch's only device -> host copy
         nimg, nbatch = tot[3], tot[4]
+        if tot[5] > 0:
+            rf.zero_()
+            if getattr(self.model, "train_mode", None) == "f16f8p":
+                import logging
+                logging.warning("ws_unet_amd.Trainer: activations beyond +-448 during epoch %d in train_mode 'f16f8p' (the planar format's e4m3 "
+                                "residual saturates there); switching to train_mode 'bf16x3' (fp32 storage)", epoch)
+                self.model.train_mode = "bf16x3"
         avg = {"loss": tot[0] / max(nimg, 1), "mae": tot[1] / max(nbatch, 1), "ws": tot[2] / max(nbatch, 1)}
         prefix = "train/" if train else "val/"
         for name in ("loss", "mae", "ws"):
