@@ -20,5 +20,7 @@ echo "evaluate done"
 timeout -k 10 300 python tools/bench_ws_attack.py > $O/ws_attack.log 2>&1
 timeout -k 10 300 python tools/bench_ws_attack.py --correct-bias >> $O/ws_attack.log 2>&1
 echo "ws attack done"
+WSU_TIME_TRAIN_LAUNCHES=1 timeout -k 10 300 python tools/time_train.py f16f8p 64 512 > $O/train_step.json 2> $O/train_step_launches.log
+echo "train launches done"
 timeout -k 10 400 python bench.py > $O/bench_n1.log 2>&1
 tail -1 $O/bench_n1.log | cut -c1-150
