@@ -1,4 +1,4 @@
-"""One data-parallel rank of tests/test_gpu_dp.py (a fresh process per rank: `python dp_worker.py RANK WORLD PORT OUT.npz`).
+"""One data-parallel rank of tests/test_gpu_dp.py (a fresh process per rank: `python dp_worker.py RANK WORLD PORT OUT.npz [MODE]`).
 Two of these share the box's single GPU and talk over the gloo backend on CUDA tensors, which exercises the same
 Trainer / parallel code path that RCCL serves on a multi-GPU node."""
 import os
@@ -24,12 +24,13 @@ def batch(n=4, size=64, seed=71):
 
 def main():
     rank, world, port, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
+    mode = sys.argv[5] if len(sys.argv) > 5 else "f32"
     os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": port, "RANK": str(rank), "WORLD_SIZE": str(world)})
     from ws_unet_amd import parallel
     from ws_unet_amd.trainer import Trainer
     from gpu_util import gpu_model, DEV
     parallel.init_from_env("gloo")
-    model = gpu_model(1, "he", "f32")
+    model = gpu_model(1, "he", mode)
     if rank != 0:                                             # replicas start different: Trainer's ONE flat broadcast must repair it
         with torch.no_grad():
             for p in model.parameters():

@@ -62,3 +62,40 @@ def test_two_rank_step_equals_single_rank_step(tmp_path):
     assert r0["fit"][0] == 2 and abs(r0["fit"][1] - 1.0) < 1e-12
     np.testing.assert_allclose(r0["val"], [1.0, 1.1], atol=1e-12)
     np.testing.assert_array_equal(r0["val"], r1["val"])
+
+
+def test_two_rank_step_planar_training(tmp_path):
+    """The same two-rank step in the default planar training arithmetic (train_mode 'f16f8p'): replicas bitwise identical, the all-reduced
+    gradient equal on both ranks and equal to the single-process whole-batch gradient up to the arithmetic (each rank scales its gradients by
+    its own power of two and sums in its own order: relative L2 <= 2e-3), the epoch reduction with the range-flag slot stops both together."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    outs = [tmp_path / f"rank{r}.npz" for r in range(2)]
+    procs = [subprocess.Popen([sys.executable, str(HERE / "dp_worker.py"), str(r), "2", str(port), str(outs[r]), "f16f8p"],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    logs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=420)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            pytest.fail("data-parallel ranks dead-locked (timeout)")
+        logs.append(o)
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+    r0, r1 = np.load(outs[0]), np.load(outs[1])
+    sys.path.insert(0, str(HERE))
+    from dp_worker import batch
+    covers, inputs, alphas = batch()
+    model = gpu_model(1, "he", "f16f8p")
+    assert model.train_mode == "f16f8p"
+    tr = Trainer(model, loss="l1ws", lr=1e-3)
+    loss, _ = tr.train_step(inputs.to(DEV), covers.to(DEV), alphas.to(DEV))
+    assert abs(0.5 * (r0["loss"][0] + r1["loss"][0]) - loss.item()) <= 1e-5 * abs(loss.item())
+    g1 = tr.opt.flat_grad.double().cpu().numpy()
+    np.testing.assert_array_equal(r0["grad"], r1["grad"])
+    rel = np.linalg.norm(r0["grad"].astype(np.float64) - g1) / np.linalg.norm(g1)
+    assert rel <= 2e-3, rel
+    for k, _ in model.named_parameters():
+        np.testing.assert_array_equal(r0["p_" + k], r1["p_" + k], err_msg=f"replicas diverged: {k}")
+    np.testing.assert_array_equal(r0["fit"], r1["fit"])
+    assert r0["fit"][0] == 2
