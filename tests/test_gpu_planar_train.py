@@ -248,7 +248,7 @@ def test_unet_gradients_golden_planar(grad_golden, ns):
         assert torch.equal(p.grad, first[k]), k                        # deterministic
 
 
-@pytest.mark.parametrize("n,size", [(2, 128), (1, 512)])
+@pytest.mark.parametrize("n,size", [(2, 128), (1, 512), (1, 1024)])
 def test_planar_vs_fp32_storage_gradients_smooth_loss(n, size):
     """The two training paths of one model under a smooth (L2) loss: same arithmetic class, different storage -- every parameter gradient agrees
     to a relative L2 of 2e-3 (ReLU-mask flips on rounding noise are the floor; test_gpu_backward_large.py).  At 512x512 every persistent
