@@ -56,17 +56,33 @@ def parse_args(argv=None):
     ap.add_argument("--no-other-modes", action="store_true")
     ap.add_argument("--no-train-step", action="store_true")
     ap.add_argument("--train-batch", type=int, default=64)
+    ap.add_argument("--rehearse", action="store_true",
+                    help="launcher rehearsal without GPUs: the ranks form a gloo group, run the barrier / max-over-ranks timing code around an "
+                         "empty step and rank 0 prints a line marked rehearsal (tests/test_host_logic.py; never a measurement)")
     return ap.parse_args(argv)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
 # N > 1 launched as plain `python bench.py --gpus N`: spawn the ranks BEFORE anything in this process touches the GPU
 # ---------------------------------------------------------------------------------------------------------------------
+def visible_gpus():
+    """GPUs this process could use, counted WITHOUT touching the GPU runtime (no torch / HIP import in the launching parent): the render
+    nodes the kernel driver exposes, capped by a visibility list in the environment.  None = cannot tell (let the ranks find out)."""
+    import glob
+    n = len(glob.glob("/dev/dri/renderD*"))
+    if n == 0 and not os.path.isdir("/dev/dri"):
+        return 0 if not os.path.exists("/dev/kfd") else None
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([t for t in v.split(",") if t.strip() != ""]))
+    return n
+
+
 def self_launch(args) -> int:
     import socket
-    import torch                                                   # device_count() does not initialise the GPU on this image
-    have = torch.cuda.device_count()
-    if have < args.gpus:
+    have = None if args.rehearse else visible_gpus()
+    if have is not None and have < args.gpus:
         print(f"bench.py: --gpus {args.gpus} needs {args.gpus} GPUs, {have} visible", file=sys.stderr)
         return 2
     s = socket.socket()
@@ -287,6 +303,25 @@ def train_step_leg(dev, batch, size, steps=5, warmup=3, train_mode=None):
     return res
 
 
+def rehearse(args, rank, world):
+    """The launch / rendezvous / barrier / max-over-ranks / rank-0-prints plumbing of the real run on CPU tensors over gloo."""
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pass
+    dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0 + 1e-3 * rank], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"metric": "rehearsal (no GPU work, not a measurement)", "value": None, "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "max_rank_time_s": t.item(), "gloo_world_size": dist.get_world_size()}))
+    dist.destroy_process_group()
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
@@ -299,6 +334,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.rehearse:
+        return rehearse(args, rank, world)
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback for the product path)"
     if torch.cuda.device_count() <= local_rank:
         raise SystemExit(f"bench.py: rank {rank} needs GPU {local_rank}, {torch.cuda.device_count()} visible")

@@ -53,8 +53,10 @@ def test_two_rank_step_equals_single_rank_step(tmp_path):
         np.testing.assert_array_equal(r0["p_" + k], r1["p_" + k], err_msg=f"replicas diverged: {k}")     # bitwise identical replicas
         # the first AdamW step moves every weight by lr * g / (|g| + eps): where |g| is near eps = 1e-8 the summation-order noise of the
         # gradient changes the step, so a handful of weights may differ by a fraction of lr; everything else agrees to fp32 rounding
+        # (the gradient and bitwise-replica checks above carry this test; here only: almost every weight agrees to fp32 rounding, and no
+        # weight moved by more than one AdamW step, 2 * lr)
         d = np.abs(r0["p_" + k] - ref)
-        assert d.max() <= 2.1e-3, k
+        assert d.max() <= 2.0e-3 * 1.05, k
         nbad += int((d > 2e-6).sum()); ntot += d.size
     assert nbad <= 1e-4 * ntot, (nbad, ntot)
     # both ranks stop after the same number of epochs, on the GLOBAL validation average (1.0, then 1.1 -> patience 1 exhausted)
@@ -99,3 +101,46 @@ def test_two_rank_step_planar_training(tmp_path):
         np.testing.assert_array_equal(r0["p_" + k], r1["p_" + k], err_msg=f"replicas diverged: {k}")
     np.testing.assert_array_equal(r0["fit"], r1["fit"])
     assert r0["fit"][0] == 2
+
+
+def test_two_rank_sharded_evaluate(tmp_path):
+    """BASELINE.json configs[3] on the one GPU of this box: two fresh processes run the real `predict_unet_sharded` over a 5-cover /
+    2-stego data set in the default mode (planar 'f16f8p') -- rows split 3 + 2 (covers) and 1 + 1 (stego), results all-gathered --
+    and BOTH return the single-rank table: same rows in fabrika's lexical order (src/fabrika.py:73), same columns
+    (src/unet/evaluate.py:135-139), same values (an image's prediction does not depend on its batch)."""
+    import pandas as pd
+    from test_gpu_evaluate import _make_dataset
+    from ws_unet_amd import evaluate
+    data = tmp_path / "data"
+    data.mkdir()
+    _make_dataset(data)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    outs = [str(tmp_path / f"rank{r}") for r in range(2)]
+    procs = [subprocess.Popen([sys.executable, str(HERE / "eval_worker.py"), str(r), "2", str(port), str(data), outs[r]],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    logs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=420)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            pytest.fail("sharded-evaluate ranks dead-locked (timeout)")
+        logs.append(o)
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+    model = gpu_model(2, "he", None, drop_rate=0.)
+    assert model.mode == "f16f8p"
+    ref_c = evaluate.predict_unet_cover(data, model=model, progress_on=False)              # the reference-shaped per-image loop
+    ref_s = evaluate.predict_unet_stego(data, model=model, stego_method="LSBR")
+    assert ref_c["name"].tolist() == ["images/1.png", "images/10.png", "images/22.png", "images/3.png", "images/7.png"]
+    for r in range(2):
+        got_c, got_s = pd.read_csv(outs[r] + ".cover.csv"), pd.read_csv(outs[r] + ".stego.csv")
+        assert list(got_c.columns) == ["name", "height", "width", "beta_hat", "l1"], list(got_c.columns)
+        assert got_c["name"].tolist() == ref_c["name"].tolist()
+        np.testing.assert_allclose(got_c["beta_hat"].to_numpy(float), ref_c["beta_hat"].to_numpy(float), atol=2e-5)
+        np.testing.assert_allclose(got_c["l1"].to_numpy(float), ref_c["l1"].to_numpy(float), atol=2e-5)
+        assert got_s["name"].tolist() == ref_s["name"].tolist() and set(ref_s.columns) <= set(got_s.columns)
+        np.testing.assert_allclose(got_s["beta_hat"].to_numpy(float), ref_s["beta_hat"].to_numpy(float), atol=2e-5)
+        np.testing.assert_allclose(got_s["l1"].to_numpy(float), ref_s["l1"].to_numpy(float), atol=2e-5)
+    a, b = pd.read_csv(outs[0] + ".cover.csv"), pd.read_csv(outs[1] + ".cover.csv")
+    np.testing.assert_array_equal(a["beta_hat"].to_numpy(), b["beta_hat"].to_numpy())      # every rank holds the same table

@@ -38,6 +38,31 @@ def _model_device(model) -> torch.device:
         return DEVICE
 
 
+def range_fallback(model, collective: bool = False) -> bool:
+    """One synchronising look at a planar model's range flag (UNet.range_exceeded: an activation beyond +-448 was stored since the last
+    look -- the format's e4m3 residual saturates there and that value keeps only f16 accuracy, MAE ~1e-4, AT the gate).  If set: warn,
+    switch the model to 'bf16x3s' (fp32-range storage) and return True -- the caller recomputes what it computed since the last look.
+    The evaluate drivers call this once per data-set pass (one sync per pass), the per-image functions once per image (they synchronise
+    on their result anyway).  `collective`: OR the flag over the ranks first (every rank of a sharded pass takes the same decision)."""
+    if getattr(model, "mode", None) not in ("f16f8p", "f16f8q") or not hasattr(model, "range_exceeded"):
+        return False
+    if collective:
+        from . import parallel
+        rf = getattr(model, "_range_flag", None)
+        if rf is None:
+            rf = model._range_flag_tensor(_model_device(model))
+        hit = parallel.any_rank_flag(rf)
+        if hit:
+            rf.zero_()
+    else:
+        hit = model.range_exceeded()
+    if hit:
+        logging.warning("ws_unet_amd.evaluate: activations beyond +-448 in mode '%s' (the planar format's e4m3 residual saturates there); "
+                        "switching this model to mode 'bf16x3s' and recomputing", model.mode)
+        model.mode = "bf16x3s"
+    return hit
+
+
 def infere_single(
     x: np.ndarray,
     model: typing.Callable,
@@ -50,6 +75,8 @@ def infere_single(
     x_ = transform(x / 255.)[None].to(_model_device(model))
     with torch.no_grad():
         y_ = model(x_)
+        if range_fallback(model):
+            y_ = model(x_)
     y = y_.detach().cpu().numpy()[0, 0, 1:-1, 1:-1] * 255.
     return y[..., None]
 
@@ -106,6 +133,8 @@ def predict_unet(
         if xi.dtype == np.uint8 or np.array_equal(xi, np.rint(xi)):
             x_u8 = torch.from_numpy(xi.astype(np.uint8))[None].to(_model_device(model))
             beta, l1 = predict_u8_batch(x_u8, model)
+            if range_fallback(model):
+                beta, l1 = predict_u8_batch(x_u8, model)
             return {**kw, "beta_hat": np.float32(beta[0].item()), "l1": np.float32(l1[0].item())}
     x_hat = infere_single(x, model=model, device=device)
     x = x[1:-1, 1:-1]
@@ -275,10 +304,23 @@ def _drop_model_kw(fn):
     return wrapped
 
 
-predict_unet_cover_batched = fabrika.precovers(iterator="batched", convert_to="pandas", ignore_missing=False)(
-    _drop_model_kw(predict_unet_batch))
-predict_unet_stego_batched = fabrika.stego_spatial(iterator="batched", convert_to="pandas", ignore_missing=False)(
-    _drop_model_kw(predict_unet_batch))
+def _range_guarded(iterate):
+    """A data-set pass of a batched driver, then ONE look at the model's range flag: if a planar forward of the pass left the format's
+    full-accuracy range, the whole pass is recomputed in 'bf16x3s' (loudly).  No per-chunk synchronisation."""
+    def run(dataset, *args, **kw):
+        res = iterate(dataset, *args, **kw)
+        model = kw.get("model")
+        if model is not None and range_fallback(model):
+            res = iterate(dataset, *args, **kw)
+        return res
+    run.__doc__ = iterate.__doc__
+    return run
+
+
+predict_unet_cover_batched = _range_guarded(fabrika.precovers(iterator="batched", convert_to="pandas", ignore_missing=False)(
+    _drop_model_kw(predict_unet_batch)))
+predict_unet_stego_batched = _range_guarded(fabrika.stego_spatial(iterator="batched", convert_to="pandas", ignore_missing=False)(
+    _drop_model_kw(predict_unet_batch)))
 
 
 def get_model_config(model_dir: pathlib.Path, stego_method: str, model_name: str) -> typing.Dict[str, typing.Any]:
@@ -340,7 +382,10 @@ def predict_unet_sharded(dataset, model: torch.nn.Module, *, stego_method: str =
         rows = list(pipelined_unet_rows(chunks, model))
         return torch.from_numpy(np.concatenate(rows)) if rows else torch.zeros((0, 2), dtype=torch.float32)
 
-    table = parallel.evaluate_sharded(files, predict_shard, None).cpu().numpy()
+    table = parallel.evaluate_sharded(files, predict_shard, None)
+    if range_fallback(model, collective=True):                # one look per pass, OR-ed over the ranks: everybody recomputes together
+        table = parallel.evaluate_sharded(files, predict_shard, None)
+    table = table.cpu().numpy()
     df["name"] = [str(pathlib.Path(f).relative_to(dataset)) for f in files]
     df["beta_hat"], df["l1"] = table[:, 0], table[:, 1]
     if stego_method is not None:

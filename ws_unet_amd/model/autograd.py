@@ -150,8 +150,12 @@ def planar_train_ok(model, x: torch.Tensor) -> bool:
 def planar_range_fallback(model) -> bool:
     """True (after switching the model to train_mode 'bf16x3', loudly) if a planar forward stored activations beyond +-448 since the last look:
     there the e4m3 residual saturates and the planar format keeps only f16 accuracy; fp32 storage has fp32's range."""
-    if not model.range_exceeded():
+    # collective: in a data-parallel job the ranks must not train in different arithmetics (one MAX all-reduce of one word, first forward only)
+    from .. import parallel
+    rf = getattr(model, "_range_flag", None)
+    if rf is None or not parallel.any_rank_flag(rf):
         return False
+    rf.zero_()
     import logging
     logging.warning("ws_unet_amd.UNet: activations beyond +-448 while training in train_mode 'f16f8p' (the planar format's e4m3 residual "
                     "saturates there); switching this model to train_mode 'bf16x3' (fp32 storage)")

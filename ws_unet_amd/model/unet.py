@@ -377,7 +377,17 @@ class UNet(nn.Module):
             self.e11.weight.grad[:, :, 1, 1] = 0.
         self.invalidate_packed()
 
-    def invalidate_packed(self):
+    def invalidate_packed(self, recheck_range: bool = True):
         """Drop cached packed weights.  Needed only after writing through ``param.data`` (which bypasses
-        the tensor version counter the cache keys on); optimizer steps and load_state_dict are detected."""
+        the tensor version counter the cache keys on); optimizer steps and load_state_dict are detected.
+        New weights also mean a new activation range: the planar modes' one-time look at the +-448 range flag is re-armed
+        (``recheck_range=False``: the optimiser's per-step call -- the trainer reads the flag once per epoch instead)."""
         self._pack_cache.clear()
+        if recheck_range:
+            self._range_checked = False
+            self._range_checked_train = False
+
+    def load_state_dict(self, *args, **kw):
+        res = super().load_state_dict(*args, **kw)
+        self.invalidate_packed()                                   # a foreign checkpoint: nobody knows its activation range
+        return res

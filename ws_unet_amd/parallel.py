@@ -101,6 +101,18 @@ def early_stop_update(val_loss: float, best_val_loss: float, patience: int, pati
     return best_val_loss, patience, patience <= 0
 
 
+def any_rank_flag(flag: torch.Tensor) -> bool:
+    """True on EVERY rank if `flag` (a one-element integer device tensor, e.g. the planar format's range flag) is non-zero on ANY rank:
+    decisions that change a rank's arithmetic are taken collectively.  One synchronising read; one tiny MAX all-reduce when world > 1."""
+    rank, world = world_info()
+    f = flag.detach().reshape(1).to(torch.int32).clone()
+    if world > 1:
+        if dist.get_backend() == "nccl" and not f.is_cuda:
+            f = f.to(_collective_device())
+        dist.all_reduce(f, op=dist.ReduceOp.MAX)
+    return bool(f.item())
+
+
 def allreduce_flat_(flat_grad: torch.Tensor) -> float:
     """Sum-all-reduce the flat gradient bucket in place; returns the scale (1/world) the optimiser must apply."""
     rank, world = world_info()
@@ -129,7 +141,8 @@ def gather_rows(local_indices: Sequence[int], local_values: torch.Tensor, total:
         if cnt:
             out[torch.as_tensor(list(local_indices), dtype=torch.long, device=out.device)] = local_values
         return out
-    dev = local_values.device if cnt else _collective_device()
+    # RCCL moves device tensors only: host-side rows (predict_unet_sharded hands over numpy tables) go up first; gloo takes either
+    dev = _collective_device() if dist.get_backend() == "nccl" else (local_values.device if cnt else torch.device("cpu"))
     big = 1 << 40
     kk = torch.tensor([k, -(k if cnt else big)], dtype=torch.int64, device=dev)    # MAX of (k, -k) = (largest, -smallest non-empty)
     dist.all_reduce(kk, op=dist.ReduceOp.MAX)                  # every non-empty shard must report the same k; empty shards adopt it

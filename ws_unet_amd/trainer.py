@@ -85,7 +85,16 @@ class FlatAdamW:
         self.step_count += 1
         self._table.step(self.step_count, self.lr, self.betas, self.eps, self.weight_decay, grad_scale, skip_flag)
         if hasattr(self.model, "invalidate_packed"):
-            self.model.invalidate_packed()                               # flat update bypasses tensor version counters
+            try:
+                self.model.invalidate_packed(recheck_range=False)        # flat update bypasses tensor version counters
+            except TypeError:
+                self.model.invalidate_packed()
+
+    def forget_skipped(self, n: int) -> None:
+        """`n` of the counted steps were suppressed on the device (skip_flag): the bias corrections follow the APPLIED updates, as
+        torch.optim.AdamW's would on the same sequence.  Called by the trainer where it reads the device-side counter (once per epoch),
+        so inside an epoch bc1 / bc2 run at most the epoch's skipped steps ahead."""
+        self.step_count = max(0, self.step_count - int(n))
 
     def state_dict(self):
         return {"step": self.step_count, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq,
@@ -113,6 +122,7 @@ class Trainer:
         self.epochs_run = 0
         self._nonfinite = torch.zeros(2, dtype=torch.int32, device=self.opt.flat_param.device)   # [this step, skipped steps so far]
         self._last_l1 = None
+        self._skipped_seen = 0
         if self.out_dir and self.rank == 0:
             (self.out_dir / "model").mkdir(parents=True, exist_ok=True)
             (self.out_dir / "log").mkdir(parents=True, exist_ok=True)
@@ -174,18 +184,33 @@ class Trainer:
         tot = parallel.reduce_epoch_sums_(sums).cpu().numpy()            # global sums on every rank; the epoch's only device -> host copy
         nimg, nbatch = tot[3], tot[4]
         if tot[5] > 0:
-            rf.zero_()
-            if getattr(self.model, "train_mode", None) == "f16f8p":
-                import logging
-                logging.warning("ws_unet_amd.Trainer: activations beyond +-448 during epoch %d in train_mode 'f16f8p' (the planar format's e4m3 "
-                                "residual saturates there); switching to train_mode 'bf16x3' (fp32 storage)", epoch)
+            import logging
+            if rf is not None:
+                rf.zero_()
+            # every rank sees the same reduced flag and takes the same decision; validation / inference forwards of this model leave the
+            # planar format too (model.mode), and the switch is always logged
+            was = (getattr(self.model, "train_mode", None), getattr(self.model, "mode", None))
+            if was[0] == "f16f8p":
                 self.model.train_mode = "bf16x3"
+            if was[1] in ("f16f8p", "f16f8q"):
+                self.model.mode = "bf16x3s"
+            logging.warning("ws_unet_amd.Trainer: activations beyond +-448 during %s epoch %d (the planar format's e4m3 residual saturates "
+                            "there): train_mode %s -> %s, mode %s -> %s", "training" if train else "validation", epoch, was[0],
+                            getattr(self.model, "train_mode", None), was[1], getattr(self.model, "mode", None))
         avg = {"loss": tot[0] / max(nimg, 1), "mae": tot[1] / max(nbatch, 1), "ws": tot[2] / max(nbatch, 1)}
         prefix = "train/" if train else "val/"
         for name in ("loss", "mae", "ws"):
             self.scalars.append((epoch, prefix + name, float(avg[name])))
         if train:
-            self.scalars.append((epoch, "train/skipped_steps", float(self.skipped_steps())))
+            skipped = self.skipped_steps()
+            new_skips = skipped - self._skipped_seen
+            if new_skips > 0:
+                import logging
+                logging.warning("ws_unet_amd.Trainer: %d optimiser step(s) skipped in epoch %d (inf / NaN in the gradient bucket; %d so far) -- "
+                                "a run that keeps skipping is stalled", new_skips, epoch, skipped)
+                self.opt.forget_skipped(new_skips)
+                self._skipped_seen = skipped
+            self.scalars.append((epoch, "train/skipped_steps", float(skipped)))
         return float(avg["loss"])
 
     def skipped_steps(self) -> int:
@@ -204,6 +229,7 @@ class Trainer:
             "patience": self.patience,
             "optimizer": self.opt.state_dict(),
             "scheduler": None,
+            "skipped_steps": self._skipped_seen,                        # extra key (the reference's readers use epoch / state_dict only)
         }, latest)
         if val_loss < self.best_val_loss:
             shutil.copyfile(latest, self.out_dir / "model" / "best_model.pt.tar")
