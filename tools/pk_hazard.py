@@ -3,8 +3,9 @@
   scan   <file.s> ...           list every site of the pattern in gfx950 assembly (also what tests/test_isa_lint.py runs)
   build                         build two diagnostic libraries next to libwsu.so from conv3x3_pl.hip compiled WITH the SLP vectorizer:
                                   libwsu_slp.so     as the compiler schedules it (the build that failed ~25 % of the launches)
-                                  libwsu_slpnop8.so the same assembly with `s_nop 0` inserted at the 8 sites separated only by an s_waitcnt
-                                  libwsu_slpnop.so  ... at every site (also the adjacent v_pk_add_f32 -> v_max_f32 pairs the compiler does not pad)
+                                  libwsu_slpnop_w.so the same assembly with `s_nop 0` inserted at the sites separated only by an s_waitcnt
+                                  libwsu_slpnop_a.so ... only at the ADJACENT pairs (v_pk_add_f32 op_sel_hi:[0,1] -> v_max_f32: hipcc does not pad these)
+                                  libwsu_slpnop.so   ... at every site
                                 (tools/stress_pl.py with WSU_LIB=... runs either; profiles/r03/pk_hazard.md has the result)
 
 The pattern: a VOP3P packed-f32 instruction (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 / v_pk_mov_b32) writes a VGPR pair and the next
@@ -82,11 +83,11 @@ def compiler_pads(producer: str) -> bool:
     return m is None or m.group(1) == "1"
 
 
-def patch(asm: str, only_waitcnt: bool = False):
-    """`s_nop 0` directly behind the producer of every site (only_waitcnt: only where an s_waitcnt is all that separates the pair -- the 8
-    sites of the fused-head variants); returns (patched text, number of sites patched)."""
+def patch(asm: str, which: str = "all"):
+    """`s_nop 0` directly behind the producer of every site; which = 'waitcnt': only where an s_waitcnt is all that separates the pair,
+    'adjacent': only the pairs with nothing in between, 'all'.  Returns (patched text, number of sites patched)."""
     lines = asm.split("\n")
-    sites = [s for s in find_sites(asm) if s[3] or not only_waitcnt]
+    sites = [s for s in find_sites(asm) if which == "all" or (which == "waitcnt") == bool(s[3])]
     for _, ln, *_ in sorted(sites, key=lambda s: -s[1]):
         lines.insert(ln, "\ts_nop 0")
     return "\n".join(lines), len(sites)
@@ -112,16 +113,19 @@ def hipcc_steps(src: Path, out_obj: Path, workdir: Path, flags):
     return steps
 
 
-def build_variants():
+def build_variants(root: Path = ROOT):
+    """`root`: the tree to build in (default: this one; `repro_r02/` = an export of the round-2 commit whose SLP build failed)."""
+    csrc = root / "ws_unet_amd" / "csrc"
     flags = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-function", "-Wno-unused-variable", "-Wno-unused-but-set-variable"]
-    objs = [str(CSRC / f"{n}.o") for n in ("wsu_common", "conv3x3", "planar", "convt2x2", "pointwise", "wgrad", "backward", "train", "train_pl", "ws_attack")]
+    srcs = re.search(r"^SRCS\s*=\s*(.*)$", (csrc / "Makefile").read_text(), re.M).group(1).split()
+    objs = [str(csrc / (n[:-4] + ".o")) for n in srcs if n != "conv3x3_pl.hip"]
     for o in objs:
-        assert Path(o).exists(), f"{o} missing: run make -C ws_unet_amd/csrc first"
-    for variant in ("slp", "slpnop8", "slpnop"):
-        work = Path("/tmp") / f"wsu_{variant}"
+        assert Path(o).exists(), f"{o} missing: run make -C {csrc} first"
+    for variant in ("slp", "slpnop_w", "slpnop_a", "slpnop"):
+        work = Path("/tmp") / f"wsu_{root.name}_{variant}"
         work.mkdir(exist_ok=True)
         obj = work / "conv3x3_pl.o"
-        steps = hipcc_steps(CSRC / "conv3x3_pl.hip", obj, work, flags)
+        steps = hipcc_steps(csrc / "conv3x3_pl.hip", obj, work, flags)
         dev_s = work / "conv3x3_pl-hip-amdgcn-amd-amdhsa-gfx950.s"
         for k, st in enumerate(steps):
             subprocess.run(st, cwd=work, check=True, stderr=subprocess.DEVNULL)
@@ -130,11 +134,12 @@ def build_variants():
                 n_before = len(find_sites(text))
                 n = 0
                 if variant != "slp":
-                    text, n = patch(text, only_waitcnt=variant == "slpnop8")
+                    text, n = patch(text, {"slpnop_w": "waitcnt", "slpnop_a": "adjacent", "slpnop": "all"}[variant])
                     dev_s.write_text(text)
-                    assert len([s_ for s_ in find_sites(text) if s_[3]]) == 0
-                print(f"[{variant}] {n_before} site(s) in the device assembly, {sum(1 for s_ in find_sites(text) if s_[3])} of them behind an s_waitcnt after patching {n} with s_nop 0")
-        lib = ROOT / "ws_unet_amd" / f"libwsu_{variant}.so"
+                left = find_sites(text)
+                print(f"[{variant}] {n_before} site(s) in the device assembly, {n} patched with s_nop 0; left: {sum(1 for s_ in left if s_[3])} behind an s_waitcnt, "
+                      f"{sum(1 for s_ in left if not s_[3])} adjacent")
+        lib = root / "ws_unet_amd" / f"libwsu_{variant}.so"
         subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", *objs, str(obj), "-o", str(lib)], check=True)
         print(f"[{variant}] {lib}")
 
@@ -142,8 +147,8 @@ def build_variants():
 if __name__ == "__main__":
     if len(sys.argv) >= 3 and sys.argv[1] == "scan":
         sys.exit(1 if scan_files(sys.argv[2:]) else 0)
-    elif len(sys.argv) == 2 and sys.argv[1] == "build":
-        build_variants()
+    elif len(sys.argv) in (2, 3) and sys.argv[1] == "build":
+        build_variants(Path(sys.argv[2]).resolve() if len(sys.argv) == 3 else ROOT)
     else:
         print(__doc__)
         sys.exit(2)

@@ -83,76 +83,80 @@ __device__ __forceinline__ Tile tile_of(const PlArgs& a, int t) {
     return r;
 }
 
+// ---- loader side: LDS-DMA through buffer descriptors ------------------------------------------------------------------------------
+// Round 3: the loaders' instruction stream.  Round 2's loader computed, per piece and step, its plane / segment from a run-time wave index
+// (divisions by 10), a 64-bit per-lane source address, a select between it and the zero block and a lane-alive test: ~540 vector and ~600
+// scalar instructions per step and wave for 17 DMA instructions (SGPRs spilled into VGPR lanes on the way), issued on the SIMD its two
+// matrix waves need for their MFMAs (profiles/r03/conv3x3_pl_loader.md).  Now:
+//   * the loader body is instantiated per loader wave (LW = 0..3): slot -> (plane, segment) is compile-time;
+//   * a piece = `buffer_load_dwordx4 ... offen lds` with a wave-uniform descriptor of the (image, chunk)'s 3 stored planes and a per-lane
+//     32-bit byte offset that is computed ONCE PER TILE (8 registers); out-of-image lanes of the GRAD variant carry an offset beyond the
+//     descriptor's size -- the hardware range check makes them read zeros (the zero padding), no select, no zero block;
+//   * weight pieces: one descriptor for the packed weights, offset = chunk base (scalar) + lane * 16.
+// Per step and wave that leaves ~3 instructions per piece, two of them scalar.
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void glb_void;
 
-// source offsets (in 16-byte units, inside one chunk's 4 planes of one image) of this lane's 5 input DMA slots; -1 = lane idle
-template <bool GRAD = false>
-__device__ __forceinline__ void plan_tile(const PlArgs& a, const Tile& t, int lw8, int lane, int (&goff)[IN_PER_WAVE]) {
-    const int hw = a.h * a.w;
-#pragma unroll
-    for (int k = 0; k < IN_PER_WAVE; ++k) {
-        const int slot = lw8 + NLOAD * k;
-        const int plane = slot / IN_SEG, seg = slot - plane * IN_SEG;
-        const int idx = seg * 64 + lane;
-        const int r = idx / IW, c = idx - r * IW;
-        if constexpr (GRAD) {                                  // zero padding: pixels outside the image come from a block of zeros (-2)
-            const int yy = t.y0 - 1 + r, xx = t.x0 - 1 + c;
-            const bool inside = yy >= 0 && yy < a.h && xx >= 0 && xx < a.w;
-            goff[k] = (slot < IN_SLOTS && idx < NPIX) ? (inside ? plane * hw + yy * a.w + xx : -2) : -1;
+template <int LW> struct LoaderGeo {
+    static constexpr int slot(int k) { return LW + NLOAD * k; }
+    static constexpr bool exists(int k) { return slot(k) < IN_SLOTS; }
+    static constexpr int plane(int k) { return slot(k) / IN_SEG; }
+    static constexpr int seg(int k) { return slot(k) % IN_SEG; }
+};
+constexpr unsigned OOB = 0xFFFFFFF0u;                              // beyond any descriptor (num_records = 48 * h * w < 2^32 - 16): reads as zeros
+
+// per-lane byte offsets (inside one (image, chunk)'s 3 planes) of this wave's input slots for tile t
+template <int LW, bool GRAD>
+__device__ __forceinline__ void plan_tile(const PlArgs& a, const Tile& t, int lane, unsigned (&voff)[IN_PER_WAVE]) {
+    const unsigned hw = (unsigned)(a.h * a.w);
+    WSU_STATIC_FOR(IN_PER_WAVE, k, {
+        if constexpr (LoaderGeo<LW>::exists(k)) {
+            constexpr int plane = LoaderGeo<LW>::plane(k), seg = LoaderGeo<LW>::seg(k);
+            const int idx = seg * 64 + lane;
+            const int r = idx / IW, c = idx - r * IW;
+            if constexpr (GRAD) {                                      // zero padding: pixels outside the image read zeros
+                const int yy = t.y0 - 1 + r, xx = t.x0 - 1 + c;
+                const bool inside = yy >= 0 && yy < a.h && xx >= 0 && xx < a.w;
+                voff[k] = inside ? (plane * hw + (unsigned)(yy * a.w + xx)) * 16u : OOB;
+            } else {
+                const int yy = wsu_reflect(t.y0 - 1 + r, a.h), xx = wsu_reflect(t.x0 - 1 + c, a.w);
+                voff[k] = (plane * hw + (unsigned)(yy * a.w + xx)) * 16u;
+            }
         } else {
-            const int yy = wsu_reflect(t.y0 - 1 + r, a.h), xx = wsu_reflect(t.x0 - 1 + c, a.w);
-            goff[k] = (slot < IN_SLOTS && idx < NPIX && (a.xres || plane != 2)) ? plane * hw + yy * a.w + xx : -1;
+            voff[k] = 0;
         }
-    }
+    });
 }
 
-// LDS-DMA of one chunk into a stage = 40 input pieces + 36 weight pieces of 1 KiB: slots 0..4 of a wave are its input pieces (plane and
-// segment follow from wave + 8 k), slots 5..9 its weight pieces.  The slots are issued ONE AT A TIME between the tap groups of the
-// matrix section (stamps of the first version, profiles/r02/conv3x3_pl_stamps.md: issuing all of a wave's pieces back to back right
-// after the barrier took 2-3 k cycles per step during which BOTH waves of every SIMD were in their issue phase and the matrix pipe idle).
-struct DmaPlan { const char* in_src; const char* w_src; char* st; };
-
-__device__ __forceinline__ DmaPlan dma_plan(const PlArgs& a, int tn, int tcb, int c, char* st, int lane) {
-    const size_t plane4 = (size_t)a.h * a.w * 16 * HBM_PLANES;         // bytes of one chunk of one image (3 stored planes)
-    DmaPlan p;
-    p.in_src = c < a.nch1 ? a.x1 + ((size_t)tn * a.nch1 + c) * plane4
-                          : a.x2 + ((size_t)tn * (a.nch - a.nch1) + (c - a.nch1)) * plane4;
-    p.w_src = a.wp + ((size_t)tcb * a.nch + c) * LDS_W + lane * 16;
-    if (a.imgs_per_wset > 0) p.w_src += (size_t)(tn / a.imgs_per_wset) * a.wset_bytes;
-    p.st = st;
-    return p;
-}
-
-template <int K>
-__device__ __forceinline__ void dma_slot(const DmaPlan& p, int lw8, const int (&goff)[IN_PER_WAVE]) {
-    if constexpr (K < IN_PER_WAVE) {
-        const int slot = lw8 + NLOAD * K;
-        const int plane = slot / IN_SEG, seg = slot - plane * IN_SEG;
-        if (goff[K] != -1) {
-            const char* src = goff[K] >= 0 ? p.in_src + (size_t)goff[K] * 16 : reinterpret_cast<const char*>(g_zero16);
-            __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(p.st + plane * PLANE + seg * 1024), 16, 0, 0);
+// the DMA of one chunk step into stage `st`: this wave's 7-8 input pieces and 9 weight pieces (weight and input pieces alternate, so that
+// the first pieces of both operands land early)
+typedef __attribute__((address_space(3))) char lds_char;
+template <int LW, bool XRES, bool WEIGHTS_ONLY>
+__device__ __forceinline__ void issue_dma(const PlArgs& a, int tn, int tcb, int c, lds_char* st, int lane, const unsigned (&voff)[IN_PER_WAVE]) {
+    const unsigned plane4 = (unsigned)(a.h * a.w) * 16u * HBM_PLANES;          // bytes of one chunk of one image (3 stored planes)
+    const char* in_src = c < a.nch1 ? a.x1 + ((size_t)tn * a.nch1 + c) * plane4
+                                    : a.x2 + ((size_t)tn * (a.nch - a.nch1) + (c - a.nch1)) * plane4;
+    const char* w_src = a.wp;
+    if (a.imgs_per_wset > 0) w_src += (size_t)(tn / a.imgs_per_wset) * a.wset_bytes;
+    const auto rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(in_src), 0, (int)plane4, 0x00020000);
+    const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(w_src), 0, 0x7FFFFFF0, 0x00020000);
+    const int w_base = (tcb * a.nch + c) * LDS_W;                                // scalar
+    const unsigned lane16 = (unsigned)lane * 16u;
+    WSU_STATIC_FOR(W_PER_WAVE, k, {
+        if constexpr (!WEIGHTS_ONLY && k < IN_PER_WAVE) {
+            if constexpr (LoaderGeo<LW>::exists(k) && (XRES || LoaderGeo<LW>::plane(k) != 2)) {
+                constexpr int plane = LoaderGeo<LW>::plane(k), seg = LoaderGeo<LW>::seg(k);
+                lds_void* dst = (lds_void*)(st + plane * PLANE + seg * 1024);
+                if constexpr (seg == IN_SEG - 1) {                      // the last segment of a plane is 36 lanes wide
+                    if (lane < NPIX - (IN_SEG - 1) * 64) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, dst, 16, voff[k], 0, 0, 0);
+                } else {
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, dst, 16, voff[k], 0, 0, 0);
+                }
+            }
         }
-    } else {
-        const int slot = lw8 + NLOAD * (K - IN_PER_WAVE);
-        if (slot < W_SLOTS)
-            __builtin_amdgcn_global_load_lds((glb_void*)(p.w_src + slot * 1024), (lds_void*)(p.st + LDS_IN + slot * 1024), 16, 0, 0);
-    }
-}
-
-template <bool WEIGHTS_ONLY = false>
-__device__ __forceinline__ void issue_dma(const PlArgs& a, int tn, int tcb, int c, char* st, int lw8, int lane, const int (&goff)[IN_PER_WAVE]) {
-    if constexpr (WEIGHTS_ONLY) {
-        DmaPlan p;
-        p.in_src = nullptr; p.st = st;
-        p.w_src = a.wp + ((size_t)tcb * a.nch + c) * LDS_W + lane * 16;
-        WSU_STATIC_FOR(W_PER_WAVE, k, { dma_slot<IN_PER_WAVE + k>(p, lw8, goff); });
-        return;
-    }
-    const DmaPlan p = dma_plan(a, tn, tcb, c, st, lane);
-    // weight and input pieces alternate, so that the first pieces of both operands land early
-    WSU_STATIC_FOR(IN_PER_WAVE, k, { dma_slot<k>(p, lw8, goff); dma_slot<IN_PER_WAVE + k>(p, lw8, goff); });
-    WSU_STATIC_FOR(W_PER_WAVE - IN_PER_WAVE, k, { dma_slot<2 * IN_PER_WAVE + k>(p, lw8, goff); });
+        constexpr int wslot = LW + NLOAD * k;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void*)(st + LDS_IN + wslot * 1024), 16, lane16, w_base + wslot * 1024, 0, 0);
+    });
 }
 
 // value of lane ^ 1 by a DPP quad permutation (a VALU modifier: no LDS crossbar round trip like ds_bpermute)
@@ -172,6 +176,180 @@ __device__ __forceinline__ void swap32(uint32_t& upper_of, uint32_t& lower_of) {
 #else
 #define STAMP(var) do {} while (0)
 #endif
+
+// ================= loader wave LW: the whole DMA of step j+1 right after the barrier that opens step j ====================================
+template <int LW, bool XRES, bool F1, bool GRAD>
+__device__ __forceinline__ void pl_loader(const PlArgs& a, char* smem, int lane, int lw, int G, int J) {
+    constexpr int lw8 = LW;
+    float* s_w1 = reinterpret_cast<float*>(smem + LDS_F1);
+    float* s_b1 = s_w1 + 9 * 64;
+    unsigned char* s_mask = reinterpret_cast<unsigned char*>(smem + LDS_EXTRA);   // GRAD: [4 output chunks][2 f16 planes][512 px] bytes of 8 mask bits (the bias slot)
+    unsigned long long t_wait = 0, t_bar = 0, t_dma = 0, s0 = 0, s1 = 0, s2 = 0, s3 = 0, t0 = 0, rt0 = 0;
+    STAMP(t0);
+#ifdef WSU_PL_STAMPS
+    rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    unsigned voff[IN_PER_WAVE];
+    Tile t = tile_of(a, lw);
+    // ---- fused first layer (F1): the loaders COMPUTE the input planes of a step instead of fetching them -- relu(b1 + w1 * 3x3 window of
+    // the image), fp32 FMAs in the tap order of first_pl_kernel, the same encodings, written where the DMA would have put them: the
+    // result is bitwise that of first_pl + this kernel, xe11 never exists in HBM.  Lane = 3 of the tile's 612 positions (fixed per
+    // tile, their 27 image values stay in registers over the 4 chunks); only the 36 weight pieces of a step still come by DMA.
+    constexpr int F1_PX = (NPIX + NLOAD * 64 - 1) / (NLOAD * 64);           // 3
+    float pimg[F1 ? F1_PX : 1][9];
+    float f1_max = 0.f;                                                     // range flag of the computed (never stored) xe11 values
+    auto f1_window = [&](const Tile& tt) __attribute__((always_inline)) {
+        if constexpr (F1) {
+            const float* img = a.img + (size_t)tt.n * a.h * a.w;
+#pragma unroll
+            for (int k = 0; k < F1_PX; ++k) {
+                const int idx = min(lw8 * 64 + lane + NLOAD * 64 * k, NPIX - 1);
+                const int r = idx / IW, cc = idx - r * IW;
+                const int yy = wsu_reflect(tt.y0 - 1 + r, a.h), xx = wsu_reflect(tt.x0 - 1 + cc, a.w);
+#pragma unroll
+                for (int tp = 0; tp < 9; ++tp)
+                    pimg[k][tp] = img[(size_t)wsu_reflect(yy + tp / 3 - 1, a.h) * a.w + wsu_reflect(xx + tp % 3 - 1, a.w)];
+            }
+        }
+    };
+    auto f1_chunk = [&](int c, char* st) __attribute__((always_inline)) {
+        if constexpr (F1) {
+#pragma unroll
+            for (int k = 0; k < F1_PX; ++k) {
+                const int idx = lw8 * 64 + lane + NLOAD * 64 * k;
+                f32x4 v[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) v[g] = *reinterpret_cast<const f32x4*>(s_b1 + c * 16 + 4 * g);
+#pragma unroll
+                for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 w4 = *reinterpret_cast<const f32x4*>(s_w1 + tp * 64 + c * 16 + 4 * g);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[g][e] = fmaf(pimg[k][tp], w4[e], v[g][e]);
+                    }
+                uint32_t h[8], lo[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[g][e] = fmaxf(v[g][e], 0.f); f1_max = fmaxf(f1_max, v[g][e]); }
+                    wsu_split4_f16r8(v[g], WSU_F8_XLO_DIV, h[2 * g], h[2 * g + 1], lo[g]);
+                }
+                // the e4m3 copies from the f16 values, exactly as derive_x8 makes them for fetched planes
+                const u32x2 xa = wsu_f16x8_to_fp8(mk_u4(h[0], h[1], h[2], h[3])), xb = wsu_f16x8_to_fp8(mk_u4(h[4], h[5], h[6], h[7]));
+                if (idx < NPIX) {
+                    char* d = st + idx * 16;
+                    *reinterpret_cast<u32x4*>(d) = mk_u4(h[0], h[1], h[2], h[3]);
+                    *reinterpret_cast<u32x4*>(d + PLANE) = mk_u4(h[4], h[5], h[6], h[7]);
+                    *reinterpret_cast<u32x4*>(d + 2 * PLANE) = mk_u4(lo[0], lo[1], lo[2], lo[3]);
+                    *reinterpret_cast<u32x4*>(d + 3 * PLANE) = mk_u4(xa.x, xa.y, xb.x, xb.y);
+                }
+            }
+        }
+    };
+    // LDS plane 3 (the e4m3 copies e4m3(x / 4) of the second cross term) is not stored in HBM: each loader derives it from the f16 granules
+    // IT fetched (same lane, after its own vmcnt wait -- no cross-wave dependency), 3 instructions per pair of values.
+    auto derive_x8 = [&](char* st) __attribute__((always_inline)) {
+        if constexpr (!F1) {
+            WSU_STATIC_FOR(IN_PER_WAVE, k, {
+                if constexpr (LoaderGeo<LW>::exists(k) && LoaderGeo<LW>::plane(k) < 2) {
+                    constexpr int plane = LoaderGeo<LW>::plane(k), seg = LoaderGeo<LW>::seg(k);
+                    const int idx = seg * 64 + lane;
+                    if (seg < IN_SEG - 1 || idx < NPIX) {
+                        const u32x4 hgr = *reinterpret_cast<const u32x4*>(st + plane * PLANE + idx * 16);
+                        *reinterpret_cast<u32x2*>(st + 3 * PLANE + idx * 16 + plane * 8) = GRAD ? wsu_f16x8_to_fp8_grad(hgr) : wsu_f16x8_to_fp8(hgr);
+                    }
+                }
+            });
+        }
+    };
+    // GRAD: the ReLU mask of the tile = sign test of the producing layer's f16 planes at the tile's 512 pixels x 64 output channels:
+    // 16 granules per loader lane, fetched during the tile's first step and committed as one byte each before its second barrier
+    // (the epilogue reads them after the last one; needs nch >= 2).
+    constexpr int MK = GRAD ? 16 : 1;
+    u32x4 mreg[MK];
+    bool mask_pending = false;
+    auto mask_issue = [&](const Tile& tt) __attribute__((always_inline)) {
+        if constexpr (GRAD) {
+            const bool d1 = tt.cb * 4 < a.nco1;
+            const char* mk = d1 ? a.mask : a.mask2;
+            if (mk == nullptr) return;
+            const int ncm = d1 ? a.nco1 : (a.cout >> 4) - a.nco1, oc0 = d1 ? tt.cb * 4 : tt.cb * 4 - a.nco1;
+            const size_t hw = (size_t)a.h * a.w;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int combo = k >> 1, pix = (k & 1) * 256 + lw8 * 64 + lane;          // combo = output chunk * 2 + plane
+                const int yy = min(tt.y0 + (pix >> 5), a.h - 1), xx = min(tt.x0 + (pix & 31), a.w - 1);
+                mreg[k] = *reinterpret_cast<const u32x4*>(mk + ((((size_t)tt.n * ncm + oc0 + (combo >> 1)) * HBM_PLANES + (combo & 1)) * hw + (size_t)yy * a.w + xx) * 16);
+            }
+            mask_pending = true;
+        }
+    };
+    auto mask_commit = [&]() __attribute__((always_inline)) {
+        if constexpr (GRAD) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                unsigned bits = 0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {                                             // f16 > 0 <=> its 16 bits > 0 as a signed integer
+                    const int wd = (int)mreg[k][e];
+                    bits |= ((short)(wd & 0xFFFF) > 0 ? 1u : 0u) << (2 * e);
+                    bits |= (wd >= 0x10000 ? 1u : 0u) << (2 * e + 1);
+                }
+                s_mask[(k >> 1) * 512 + (k & 1) * 256 + lw8 * 64 + lane] = (unsigned char)bits;
+            }
+        }
+    };
+    lds_char* smem3 = (lds_char*)smem;                                    // LDS address space from here on: no generic-pointer null checks per piece
+    if (J > 0) {
+        if constexpr (F1) f1_window(t); else plan_tile<LW, GRAD>(a, t, lane, voff);
+        issue_dma<LW, XRES, F1>(a, t.n, t.cb, 0, smem3, lane, voff);
+        f1_chunk(0, smem);
+    }
+    int c = 0, kt = 0;
+    for (int j = 0; j < J; ++j) {
+        STAMP(s0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // this wave's pieces of step j have landed
+        derive_x8(smem + (j & 1) * STAGE);
+        if (mask_pending) { mask_commit(); mask_pending = false; }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                // ... and its derived / computed planes are written
+        STAMP(s1);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        STAMP(s2);
+        const bool first_chunk = c == 0;
+        const Tile tj = t;
+        if (j + 1 < J && !(a.ablate & 1)) {
+            if (++c == a.nch) {
+                c = 0; ++kt;
+                t = tile_of(a, lw + kt * G);
+                if constexpr (F1) f1_window(t); else plan_tile<LW, GRAD>(a, t, lane, voff);
+            }
+            issue_dma<LW, XRES, F1>(a, t.n, t.cb, c, smem3 + ((j + 1) & 1) * STAGE, lane, voff);
+            f1_chunk(c, smem + ((j + 1) & 1) * STAGE);
+        }
+        if (GRAD && first_chunk) mask_issue(tj);
+        STAMP(s3);
+        t_wait += s1 - s0; t_bar += s2 - s1; t_dma += s3 - s2;
+    }
+    if constexpr (F1) {
+        if (a.range_flag && __builtin_amdgcn_ballot_w64(!(f1_max <= WSU_F8_RANGE)) != 0 && lane == 0) atomicOr(a.range_flag, 1u);
+    }
+#ifdef WSU_PL_STAMPS
+    if (lane == 0 && LW == 0 && blockIdx.x < 128) {
+        unsigned long long* d = g_pl_stamps + (blockIdx.x * 2 + 1) * 8;
+        d[0] = __builtin_amdgcn_s_memtime() - t0; d[1] = __builtin_amdgcn_s_memrealtime() - rt0;
+        d[2] = t_wait; d[3] = t_bar; d[4] = t_dma; d[5] = 0; d[6] = 0; d[7] = (unsigned long long)J;
+    }
+#endif
+}
+
+// The fused-first-layer loaders keep 27 image values and 16 accumulators per lane: inlined four times beside the matrix waves' code the
+// register allocator spilled ~160 registers; as out-of-line functions each instantiation is allocated on its own.
+template <int LW, bool XRES, bool F1, bool GRAD>
+__device__ __attribute__((noinline)) void pl_loader_outlined(const PlArgs& a, char* smem, int lane, int lw, int G, int J) {
+    pl_loader<LW, XRES, F1, GRAD>(a, smem, lane, lw, G, J);
+}
 
 // HEAD / POOL are compile-time: the kernel sits at the 168-register step (three waves per SIMD), and the head's partial sums or the pool's
 // exchange registers would otherwise be carried -- and spilled -- by the variants that do not use them.
@@ -224,160 +402,22 @@ __global__ __launch_bounds__(NT) void conv3x3_pl_kernel(const PlArgs a) {
 #endif
 
     if (wv >= NWAVE) {
-        // ================= loader waves: the whole DMA of step j+1 right after the barrier that opens step j ========================
-        const int lw8 = wv - NWAVE;
-        int goff[IN_PER_WAVE];
-        Tile t = tile_of(a, lw);
-        // ---- fused first layer (F1): the loaders COMPUTE the input planes of a step instead of fetching them -- relu(b1 + w1 * 3x3 window of
-        // the image), fp32 FMAs in the tap order of first_pl_kernel, the same encodings, written where the DMA would have put them: the
-        // result is bitwise that of first_pl + this kernel, xe11 never exists in HBM.  Lane = 3 of the tile's 612 positions (fixed per
-        // tile, their 27 image values stay in registers over the 4 chunks); only the 36 weight pieces of a step still come by DMA.
-        constexpr int F1_PX = (NPIX + NLOAD * 64 - 1) / (NLOAD * 64);           // 3
-        float pimg[F1 ? F1_PX : 1][9];
-        float f1_max = 0.f;                                                     // range flag of the computed (never stored) xe11 values
-        auto f1_window = [&](const Tile& tt) __attribute__((always_inline)) {
-            if constexpr (F1) {
-                const float* img = a.img + (size_t)tt.n * a.h * a.w;
-#pragma unroll
-                for (int k = 0; k < F1_PX; ++k) {
-                    const int idx = min(lw8 * 64 + lane + NLOAD * 64 * k, NPIX - 1);
-                    const int r = idx / IW, cc = idx - r * IW;
-                    const int yy = wsu_reflect(tt.y0 - 1 + r, a.h), xx = wsu_reflect(tt.x0 - 1 + cc, a.w);
-#pragma unroll
-                    for (int tp = 0; tp < 9; ++tp)
-                        pimg[k][tp] = img[(size_t)wsu_reflect(yy + tp / 3 - 1, a.h) * a.w + wsu_reflect(xx + tp % 3 - 1, a.w)];
-                }
-            }
-        };
-        auto f1_chunk = [&](int c, char* st) __attribute__((always_inline)) {
-            if constexpr (F1) {
-#pragma unroll
-                for (int k = 0; k < F1_PX; ++k) {
-                    const int idx = lw8 * 64 + lane + NLOAD * 64 * k;
-                    f32x4 v[4];
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) v[g] = *reinterpret_cast<const f32x4*>(s_b1 + c * 16 + 4 * g);
-#pragma unroll
-                    for (int tp = 0; tp < 9; ++tp)
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            const f32x4 w4 = *reinterpret_cast<const f32x4*>(s_w1 + tp * 64 + c * 16 + 4 * g);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[g][e] = fmaf(pimg[k][tp], w4[e], v[g][e]);
-                        }
-                    uint32_t h[8], lo[4];
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { v[g][e] = fmaxf(v[g][e], 0.f); f1_max = fmaxf(f1_max, v[g][e]); }
-                        wsu_split4_f16r8(v[g], WSU_F8_XLO_DIV, h[2 * g], h[2 * g + 1], lo[g]);
-                    }
-                    // the e4m3 copies from the f16 values, exactly as derive_x8 makes them for fetched planes
-                    const u32x2 xa = wsu_f16x8_to_fp8(mk_u4(h[0], h[1], h[2], h[3])), xb = wsu_f16x8_to_fp8(mk_u4(h[4], h[5], h[6], h[7]));
-                    if (idx < NPIX) {
-                        char* d = st + idx * 16;
-                        *reinterpret_cast<u32x4*>(d) = mk_u4(h[0], h[1], h[2], h[3]);
-                        *reinterpret_cast<u32x4*>(d + PLANE) = mk_u4(h[4], h[5], h[6], h[7]);
-                        *reinterpret_cast<u32x4*>(d + 2 * PLANE) = mk_u4(lo[0], lo[1], lo[2], lo[3]);
-                        *reinterpret_cast<u32x4*>(d + 3 * PLANE) = mk_u4(xa.x, xa.y, xb.x, xb.y);
-                    }
-                }
-            }
-        };
-        // LDS plane 3 (the e4m3 copies e4m3(x / 4) of the second cross term) is not stored in HBM: each loader derives it from the f16 granules
-        // IT fetched (same lane, after its own vmcnt wait -- no cross-wave dependency), 3 instructions per pair of values.
-        auto derive_x8 = [&](char* st) __attribute__((always_inline)) {
-            if constexpr (!F1) {
-#pragma unroll
-                for (int k = 0; k < IN_PER_WAVE; ++k) {
-                    const int slot = lw8 + NLOAD * k;
-                    const int plane = slot / IN_SEG, seg = slot - plane * IN_SEG;
-                    const int idx = seg * 64 + lane;
-                    if (plane < 2 && idx < NPIX) {
-                        const u32x4 hgr = *reinterpret_cast<const u32x4*>(st + plane * PLANE + idx * 16);
-                        *reinterpret_cast<u32x2*>(st + 3 * PLANE + idx * 16 + plane * 8) = GRAD ? wsu_f16x8_to_fp8_grad(hgr) : wsu_f16x8_to_fp8(hgr);
-                    }
-                }
-            }
-        };
-        // GRAD: the ReLU mask of the tile = sign test of the producing layer's f16 planes at the tile's 512 pixels x 64 output channels:
-        // 16 granules per loader lane, fetched during the tile's first step and committed as one byte each before its second barrier
-        // (the epilogue reads them after the last one; needs nch >= 2).
-        constexpr int MK = GRAD ? 16 : 1;
-        u32x4 mreg[MK];
-        bool mask_pending = false;
-        auto mask_issue = [&](const Tile& tt) __attribute__((always_inline)) {
-            if constexpr (GRAD) {
-                const bool d1 = tt.cb * 4 < a.nco1;
-                const char* mk = d1 ? a.mask : a.mask2;
-                if (mk == nullptr) return;
-                const int ncm = d1 ? a.nco1 : (a.cout >> 4) - a.nco1, oc0 = d1 ? tt.cb * 4 : tt.cb * 4 - a.nco1;
-                const size_t hw = (size_t)a.h * a.w;
-#pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    const int combo = k >> 1, pix = (k & 1) * 256 + lw8 * 64 + lane;          // combo = output chunk * 2 + plane
-                    const int yy = min(tt.y0 + (pix >> 5), a.h - 1), xx = min(tt.x0 + (pix & 31), a.w - 1);
-                    mreg[k] = *reinterpret_cast<const u32x4*>(mk + ((((size_t)tt.n * ncm + oc0 + (combo >> 1)) * HBM_PLANES + (combo & 1)) * hw + (size_t)yy * a.w + xx) * 16);
-                }
-                mask_pending = true;
-            }
-        };
-        auto mask_commit = [&]() __attribute__((always_inline)) {
-            if constexpr (GRAD) {
-#pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    unsigned bits = 0;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {                                             // f16 > 0 <=> its 16 bits > 0 as a signed integer
-                        const int wd = (int)mreg[k][e];
-                        bits |= ((short)(wd & 0xFFFF) > 0 ? 1u : 0u) << (2 * e);
-                        bits |= (wd >= 0x10000 ? 1u : 0u) << (2 * e + 1);
-                    }
-                    s_mask[(k >> 1) * 512 + (k & 1) * 256 + lw8 * 64 + lane] = (unsigned char)bits;
-                }
-            }
-        };
-        if (J > 0) {
-            if constexpr (F1) f1_window(t); else plan_tile<GRAD>(a, t, lw8, lane, goff);
-            issue_dma<F1>(a, t.n, t.cb, 0, smem, lw8, lane, goff);
-            f1_chunk(0, smem);
-        }
-        int c = 0, kt = 0;
-        for (int j = 0; j < J; ++j) {
-            STAMP(s0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // this wave's pieces of step j have landed
-            derive_x8(smem + (j & 1) * STAGE);
-            if (mask_pending) { mask_commit(); mask_pending = false; }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                // ... and its derived / computed planes are written
-            STAMP(s1);
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            STAMP(s2);
-            const bool first_chunk = c == 0;
-            const Tile tj = t;
-            if (j + 1 < J && !(a.ablate & 1)) {
-                if (++c == a.nch) {
-                    c = 0; ++kt;
-                    t = tile_of(a, lw + kt * G);
-                    if constexpr (F1) f1_window(t); else plan_tile<GRAD>(a, t, lw8, lane, goff);
-                }
-                issue_dma<F1>(a, t.n, t.cb, c, smem + ((j + 1) & 1) * STAGE, lw8, lane, goff);
-                f1_chunk(c, smem + ((j + 1) & 1) * STAGE);
-            }
-            if (GRAD && first_chunk) mask_issue(tj);
-            STAMP(s3);
-            t_wait += s1 - s0; t_bar += s2 - s1; t_dma += s3 - s2;
-        }
+        // ================= loader waves (pl_loader<LW, ...>: the slot geometry of a wave is compile-time) ===========================
         if constexpr (F1) {
-            if (a.range_flag && __builtin_amdgcn_ballot_w64(!(f1_max <= WSU_F8_RANGE)) != 0 && lane == 0) atomicOr(a.range_flag, 1u);
+            switch (wv - NWAVE) {
+                case 0: pl_loader_outlined<0, XRES, F1, GRAD>(a, smem, lane, lw, G, J); break;
+                case 1: pl_loader_outlined<1, XRES, F1, GRAD>(a, smem, lane, lw, G, J); break;
+                case 2: pl_loader_outlined<2, XRES, F1, GRAD>(a, smem, lane, lw, G, J); break;
+                default: pl_loader_outlined<3, XRES, F1, GRAD>(a, smem, lane, lw, G, J); break;
+            }
+        } else {
+            switch (wv - NWAVE) {
+                case 0: pl_loader<0, XRES, F1, GRAD>(a, smem, lane, lw, G, J); break;
+                case 1: pl_loader<1, XRES, F1, GRAD>(a, smem, lane, lw, G, J); break;
+                case 2: pl_loader<2, XRES, F1, GRAD>(a, smem, lane, lw, G, J); break;
+                default: pl_loader<3, XRES, F1, GRAD>(a, smem, lane, lw, G, J); break;
+            }
         }
-#ifdef WSU_PL_STAMPS
-        if (lane == 0 && wv == NWAVE && blockIdx.x < 128) {
-            unsigned long long* d = g_pl_stamps + (blockIdx.x * 2 + 1) * 8;
-            d[0] = __builtin_amdgcn_s_memtime() - t0; d[1] = __builtin_amdgcn_s_memrealtime() - rt0;
-            d[2] = t_wait; d[3] = t_bar; d[4] = t_dma; d[5] = 0; d[6] = 0; d[7] = (unsigned long long)J;
-        }
-#endif
         return;
     }
 
@@ -455,7 +495,9 @@ _Pragma("unroll")
         // fences (two ahead needs 190 registers).
         if constexpr (XRES) {
             WSU_STATIC_FOR(5, tp, {
+#if WSU_PROBE != 3                                                      // timing probe 3 (make probes): no cross terms at all = plain f16, 9 units
                 cross(std::integral_constant<int, tp>{});
+#endif
                 main_term(std::integral_constant<int, 2 * tp>{});
                 if constexpr (2 * tp + 1 < 9) main_term(std::integral_constant<int, 2 * tp + 1>{});
             });
@@ -497,6 +539,7 @@ _Pragma("unroll")
             const int nco = a.cout >> 4;                                       // output chunks
             float hz[2][HC > 0 ? HC : 1];
             float vmax = 0.f;                                                  // largest stored activation of this lane (range flag)
+            const float relu_floor = a.relu ? 0.f : -__builtin_inff();
 #pragma unroll
             for (int q = 0; q < 2; ++q)
 #pragma unroll
@@ -531,8 +574,8 @@ _Pragma("unroll")
                     for (int q = 0; q < 2; ++q) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            float x = acc[m][q][8 * cp + e] + bx[e], y = acc[m][q][8 * cp + 4 + e] + by[e];
-                            if (a.relu) { x = fmaxf(x, 0.f); y = fmaxf(y, 0.f); }
+                            // ReLU as one max against a wave-uniform floor (0 or -inf): no select per value
+                            const float x = fmaxf(acc[m][q][8 * cp + e] + bx[e], relu_floor), y = fmaxf(acc[m][q][8 * cp + 4 + e] + by[e], relu_floor);
                             vx[q][e] = x; vy[q][e] = y;
                             vmax = fmaxf(vmax, fmaxf(fabsf(x), fabsf(y)));
                         }
@@ -706,7 +749,7 @@ int wsu_conv3x3_pl_fwd(const void* x1, const void* x2, const void* w_packed, con
     WSU_REQUIRE(!y_pool || (h % 2 == 0 && w % 2 == 0), "conv3x3_pl: fused pool needs even h, w");
     WSU_REQUIRE(!(y_pool && head_w), "conv3x3_pl: the fused pool and the fused head exclude each other");
     WSU_REQUIRE(x_residual || (!y_pool && !head_w), "conv3x3_pl: x_residual = 0 is built for the plain variant (no fused pool / head)");
-    WSU_REQUIRE((long long)h * w * 4 < 0x7FFFFFFFLL, "conv3x3_pl: h*w too large");
+    WSU_REQUIRE((long long)h * w * 48 < 0xFFFFFFF0LL, "conv3x3_pl: h*w too large (a plane triple must stay below 4 GiB)");
     PlArgs a;
     a.x1 = (const char*)x1; a.x2 = (const char*)x2; a.wp = (const char*)w_packed; a.bias = bias;
     a.y = (char*)y; a.ypool = (char*)y_pool;
@@ -732,7 +775,7 @@ int wsu_conv3x3_pl_fused_first_fwd(const float* img, const float* w1, const floa
     WSU_REQUIRE(n > 0 && h >= 2 && w >= 2, "conv3x3_pl_fused_first: bad shape n=%d h=%d w=%d (reflect pad 1 needs h,w >= 2)", n, h, w);
     WSU_REQUIRE(cout > 0 && cout % WSU_COB == 0 && cout <= 1024, "conv3x3_pl_fused_first: cout=%d must be a multiple of %d (<= 1024)", cout, WSU_COB);
     WSU_REQUIRE(!y_pool || (h % 2 == 0 && w % 2 == 0), "conv3x3_pl_fused_first: fused pool needs even h, w");
-    WSU_REQUIRE((long long)h * w * 4 < 0x7FFFFFFFLL, "conv3x3_pl_fused_first: h*w too large");
+    WSU_REQUIRE((long long)h * w * 48 < 0xFFFFFFF0LL, "conv3x3_pl_fused_first: h*w too large (a plane triple must stay below 4 GiB)");
     PlArgs a;
     a.x1 = nullptr; a.x2 = nullptr; a.wp = (const char*)w_packed; a.bias = bias;
     a.y = (char*)y; a.ypool = (char*)y_pool;
@@ -774,7 +817,7 @@ int wsu_conv3x3_pl_bwd_data(const void* g, const void* w_packed_dgrad, const voi
     WSU_REQUIRE(cin > 0 && cin % WSU_COB == 0 && cin <= 1024, "conv3x3_pl_bwd_data: cin=%d must be a multiple of %d (<= 1024)", cin, WSU_COB);
     WSU_REQUIRE(csplit > 0 && csplit <= cin && csplit % WSU_COB == 0 && (csplit < cin) == (dx2 != nullptr), "conv3x3_pl_bwd_data: csplit=%d (cin=%d) must be a multiple of %d, dx2 given iff csplit < cin", csplit, cin, WSU_COB);
     WSU_REQUIRE(!mask2 || dx2, "conv3x3_pl_bwd_data: mask2 without dx2");
-    WSU_REQUIRE((long long)h * w * 4 < 0x7FFFFFFFLL, "conv3x3_pl_bwd_data: h*w too large");
+    WSU_REQUIRE((long long)h * w * 48 < 0xFFFFFFF0LL && (long long)n * ((h > w ? h : w) + 2) * 48 < 0xFFFFFFF0LL, "conv3x3_pl_bwd_data: h*w too large (a plane triple must stay below 4 GiB)");
     hipStream_t s = static_cast<hipStream_t>(stream);
     PlArgs a;
     a.x1 = (const char*)g; a.x2 = nullptr; a.wp = (const char*)w_packed_dgrad; a.bias = nullptr;

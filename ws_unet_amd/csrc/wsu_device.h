@@ -100,6 +100,15 @@ typedef __attribute__((ext_vector_type(8))) int i32x8;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 typedef __attribute__((ext_vector_type(2))) short i16x2;
+// v - float(f16 half of `hpair`) in ONE instruction: v_fma_mix_f32 reads the f16 half directly (float(h) * -1 + v, exact: float(h) is exact and
+// the subtraction rounds once like v_sub_f32 -- bitwise the two-instruction form v_cvt_f32_f16 + v_sub_f32 that hipcc emits for the C
+// expression; it does not form the mixed instruction itself).  One VALU instruction less per stored value in every encoding epilogue.
+__device__ __forceinline__ float wsu_sub_f16_lo(float v, uint32_t hpair) {
+    float r; asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hpair), "v"(v)); return r;
+}
+__device__ __forceinline__ float wsu_sub_f16_hi(float v, uint32_t hpair) {
+    float r; asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hpair), "v"(v)); return r;
+}
 // 4 values -> 2 dwords of f16 (round to nearest even), 1 dword of residuals, 1 dword of e4m3 copies: 5.5 VALU instructions per value
 // (v_cvt_pk_f16_f32, widen + subtract, two v_med3 -- the fp8 conversions overflow to NaN instead of saturating, also with
 // MODE.FP16_OVFL set (tools/split_probe.hip) -- and the scaling conversions).  |v| > 65504 overflows the f16 part like any f16 pipeline.
@@ -108,8 +117,8 @@ __device__ __forceinline__ void wsu_split4_f16f8(const f32x4& v, float div_lo, f
     const f16x2 ha = __builtin_convertvector(a, f16x2), hb = __builtin_convertvector(b, f16x2);
     h01 = __builtin_bit_cast(uint32_t, ha); h23 = __builtin_bit_cast(uint32_t, hb);
     const float lim_lo = 448.f * div_lo, lim_x = 448.f * div_x;
-    const float r0 = __builtin_amdgcn_fmed3f(v[0] - (float)ha[0], -lim_lo, lim_lo), r1 = __builtin_amdgcn_fmed3f(v[1] - (float)ha[1], -lim_lo, lim_lo);
-    const float r2 = __builtin_amdgcn_fmed3f(v[2] - (float)hb[0], -lim_lo, lim_lo), r3 = __builtin_amdgcn_fmed3f(v[3] - (float)hb[1], -lim_lo, lim_lo);
+    const float r0 = __builtin_amdgcn_fmed3f(wsu_sub_f16_lo(v[0], h01), -lim_lo, lim_lo), r1 = __builtin_amdgcn_fmed3f(wsu_sub_f16_hi(v[1], h01), -lim_lo, lim_lo);
+    const float r2 = __builtin_amdgcn_fmed3f(wsu_sub_f16_lo(v[2], h23), -lim_lo, lim_lo), r3 = __builtin_amdgcn_fmed3f(wsu_sub_f16_hi(v[3], h23), -lim_lo, lim_lo);
     i16x2 l = {0, 0}, x = {0, 0};
     l = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(l, r0, r1, div_lo, false);
     l = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(l, r2, r3, div_lo, true);
@@ -123,8 +132,8 @@ __device__ __forceinline__ void wsu_split4_f16r8(const f32x4& v, float div_lo, u
     const f16x2 ha = __builtin_convertvector(a, f16x2), hb = __builtin_convertvector(b, f16x2);
     h01 = __builtin_bit_cast(uint32_t, ha); h23 = __builtin_bit_cast(uint32_t, hb);
     const float lim_lo = 448.f * div_lo;
-    const float r0 = __builtin_amdgcn_fmed3f(v[0] - (float)ha[0], -lim_lo, lim_lo), r1 = __builtin_amdgcn_fmed3f(v[1] - (float)ha[1], -lim_lo, lim_lo);
-    const float r2 = __builtin_amdgcn_fmed3f(v[2] - (float)hb[0], -lim_lo, lim_lo), r3 = __builtin_amdgcn_fmed3f(v[3] - (float)hb[1], -lim_lo, lim_lo);
+    const float r0 = __builtin_amdgcn_fmed3f(wsu_sub_f16_lo(v[0], h01), -lim_lo, lim_lo), r1 = __builtin_amdgcn_fmed3f(wsu_sub_f16_hi(v[1], h01), -lim_lo, lim_lo);
+    const float r2 = __builtin_amdgcn_fmed3f(wsu_sub_f16_lo(v[2], h23), -lim_lo, lim_lo), r3 = __builtin_amdgcn_fmed3f(wsu_sub_f16_hi(v[3], h23), -lim_lo, lim_lo);
     i16x2 l = {0, 0};
     l = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(l, r0, r1, div_lo, false);
     l = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(l, r2, r3, div_lo, true);

@@ -227,9 +227,10 @@ class Trainer:
             "state_dict": {k: v.detach().clone() for k, v in self.model.state_dict().items()},
             "best_val_loss": self.best_val_loss,
             "patience": self.patience,
-            "optimizer": self.opt.state_dict(),
+            # the checkpoint keeps the reference's six keys (src/detector/train.py:281-288); the count of optimiser steps the finite guard
+            # suppressed rides inside the optimiser state ("step" counts APPLIED updates, FlatAdamW.forget_skipped)
+            "optimizer": {**self.opt.state_dict(), "skipped_steps": self._skipped_seen},
             "scheduler": None,
-            "skipped_steps": self._skipped_seen,                        # extra key (the reference's readers use epoch / state_dict only)
         }, latest)
         if val_loss < self.best_val_loss:
             shutil.copyfile(latest, self.out_dir / "model" / "best_model.pt.tar")
