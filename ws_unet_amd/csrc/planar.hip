@@ -74,26 +74,75 @@ __device__ __forceinline__ CtTile ct_tile_of(const CtpArgs& a, int t) {
     return r;
 }
 
-__device__ __forceinline__ void ct_issue_dma(const CtpArgs& a, const CtTile& t, int step, char* st, int lw8, int lane) {
+typedef __attribute__((address_space(3))) char lds_char;
+
+// Loader wave LW of the transposed conv (round 3, same treatment as conv3x3_pl.hip: the slot -> (chunk, plane, segment) geometry is
+// compile-time, a piece is one `buffer_load_dwordx4 ... offen lds` with a wave-uniform descriptor + scalar offset and a per-lane pixel
+// offset computed once per tile; round 2 recomputed a clamped 64-bit address per piece and step).
+template <int LW>
+__device__ __forceinline__ void ct_issue_dma(const CtpArgs& a, const CtTile& t, int step, lds_char* st, int lane, const unsigned (&pixoff)[2]) {
     using namespace ct;
-    const size_t hw = (size_t)a.h * a.w;
+    const unsigned hw16 = (unsigned)(a.h * a.w) * 16u;
     const int nch = a.cin >> 4;
-    // input: slot = lw8 + 4 k -> (chunk-in-step, plane, segment); lane -> pixel of the tile (clamped: out-of-image lanes are never stored)
+    const char* in_base = a.x + ((size_t)t.n * nch + 2 * step) * HBM_PLANES * hw16;        // the step's two chunks: 6 planes
+    const auto rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(in_base), 0, (int)(6u * hw16), 0x00020000);
+    const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(a.wp), 0, 0x7FFFFFF0, 0x00020000);
+    const int w_base = (t.cb * nch + 2 * step) * W1;
+    const unsigned lane16 = (unsigned)lane * 16u;
+    WSU_STATIC_FOR(IN_PER, k, {
+        constexpr int slot = LW + NLOAD * k, ck = slot / 6, plane = (slot % 6) >> 1, seg = slot & 1;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void*)(st + ck * CHUNK + plane * PLANE + seg * 1024), 16, pixoff[seg],
+                                                 (int)((ck * HBM_PLANES + plane) * hw16), 0, 0);
+    });
+    WSU_STATIC_FOR(W_PER, k, {
+        constexpr int slot = LW + NLOAD * k, ck = slot >> 4, piece = slot & 15;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void*)(st + ck * CHUNK + IN1 + piece * 1024), 16, lane16, w_base + ck * W1 + piece * 1024, 0, 0);
+    });
+}
+
+template <int LW>
+__device__ __forceinline__ void ct_loader(const CtpArgs& a, char* smem, int lane, int lw, int G, int J) {
+    using namespace ct;
+    static_assert(IN_PER + W_PER == 11, "the vmcnt immediate below");
+    // ---- every wave issues IN_PER + W_PER = 11 pieces per step (all lanes live), so `vmcnt(11)` = "my pieces of step j have landed, those of
+    //      step j+1 are still in flight" ---------------------------------------------------------------------------------------------------
+    lds_char* smem3 = (lds_char*)smem;
+    CtTile t = ct_tile_of(a, lw);                                       // tile / step of the NEXT issue
+    int c = 0, kt = 0;
+    unsigned pixoff[2];
+    auto plan = [&]() __attribute__((always_inline)) {                   // lane -> pixel of the tile (clamped: out-of-image lanes are never stored)
 #pragma unroll
-    for (int k = 0; k < IN_PER; ++k) {
-        const int slot = lw8 + NLOAD * k;
-        const int ck = slot / 6, plane = (slot % 6) >> 1, seg = slot & 1;
-        const int pix = seg * 64 + lane;
-        const int yy = min(t.y0 + pix / TW, a.h - 1), xx = min(t.x0 + pix % TW, a.w - 1);
-        const char* src = a.x + ((((size_t)t.n * nch + 2 * step + ck) * HBM_PLANES + plane) * hw + (size_t)yy * a.w + xx) * 16;
-        __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(st + ck * CHUNK + plane * PLANE + seg * 1024), 16, 0, 0);
-    }
-#pragma unroll
-    for (int k = 0; k < W_PER; ++k) {
-        const int slot = lw8 + NLOAD * k;
-        const int ck = slot >> 4, piece = slot & 15;
-        const char* src = a.wp + ((size_t)t.cb * nch + 2 * step + ck) * W1 + piece * 1024 + lane * 16;
-        __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(st + ck * CHUNK + IN1 + piece * 1024), 16, 0, 0);
+        for (int seg = 0; seg < 2; ++seg) {
+            const int pix = seg * 64 + lane;
+            const int yy = min(t.y0 + pix / TW, a.h - 1), xx = min(t.x0 + pix % TW, a.w - 1);
+            pixoff[seg] = (unsigned)(yy * a.w + xx) * 16u;
+        }
+    };
+    plan();
+    auto issue_next = [&](int j_issue) __attribute__((always_inline)) {
+        ct_issue_dma<LW>(a, t, c, smem3 + (j_issue % NSTAGE) * STAGE, lane, pixoff);
+        if (++c == a.nst) { c = 0; ++kt; t = ct_tile_of(a, lw + kt * G); plan(); }
+    };
+    if (J > 0) issue_next(0);
+    if (J > 1) issue_next(1);
+    for (int j = 0; j < J; ++j) {
+        if (j + 1 < J) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+        else           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        {   // LDS plane 3 = e4m3 copies of the f16 granules this wave fetched (same lanes: no cross-wave dependency)
+            char* st = smem + (j % NSTAGE) * STAGE;
+            WSU_STATIC_FOR(IN_PER, k, {
+                constexpr int slot = LW + NLOAD * k, ck = slot / 6, plane = (slot % 6) >> 1, seg = slot & 1;
+                if constexpr (plane < 2) {
+                    const int pix = seg * 64 + lane;
+                    const u32x4 hgr = *reinterpret_cast<const u32x4*>(st + ck * CHUNK + plane * PLANE + pix * 16);
+                    *reinterpret_cast<u32x2*>(st + ck * CHUNK + 3 * PLANE + pix * 16 + plane * 8) = wsu_f16x8_to_fp8(hgr);
+                }
+            });
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (j + 2 < J) issue_next(j + 2);                               // its stage held step j-1: every matrix wave is past it
     }
 }
 
@@ -110,38 +159,11 @@ __global__ __launch_bounds__(ct::NT) void convt2x2_pl_kernel(const CtpArgs a) {
     for (int i = tid; i < a.cout; i += NT) s_bias[i] = a.bias ? a.bias[i] : 0.f;
 
     if (wv >= NWAVE) {
-        // ---- loader waves: every wave issues IN_PER + W_PER = 11 pieces per step (all lanes live), so `vmcnt(11)` = "my pieces of step j have
-        //      landed, those of step j+1 are still in flight" ------------------------------------------------------------------------------
-        const int lw8 = wv - NWAVE;
-        static_assert(IN_PER + W_PER == 11, "the vmcnt immediate below");
-        CtTile t = ct_tile_of(a, lw);                                   // tile / step of the NEXT issue
-        int c = 0, kt = 0;
-        auto issue_next = [&](int j_issue) __attribute__((always_inline)) {
-            ct_issue_dma(a, t, c, smem + (j_issue % NSTAGE) * STAGE, lw8, lane);
-            if (++c == a.nst) { c = 0; ++kt; t = ct_tile_of(a, lw + kt * G); }
-        };
-        if (J > 0) issue_next(0);
-        if (J > 1) issue_next(1);
-        for (int j = 0; j < J; ++j) {
-            if (j + 1 < J) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
-            else           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            {   // LDS plane 3 = e4m3 copies of the f16 granules this wave fetched (same lanes: no cross-wave dependency)
-                char* st = smem + (j % NSTAGE) * STAGE;
-#pragma unroll
-                for (int k = 0; k < IN_PER; ++k) {
-                    const int slot = lw8 + NLOAD * k;
-                    const int ck = slot / 6, plane = (slot % 6) >> 1, seg = slot & 1;
-                    if (plane < 2) {
-                        const int pix = seg * 64 + lane;
-                        const u32x4 hgr = *reinterpret_cast<const u32x4*>(st + ck * CHUNK + plane * PLANE + pix * 16);
-                        *reinterpret_cast<u32x2*>(st + ck * CHUNK + 3 * PLANE + pix * 16 + plane * 8) = wsu_f16x8_to_fp8(hgr);
-                    }
-                }
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            if (j + 2 < J) issue_next(j + 2);                           // its stage held step j-1: every matrix wave is past it
+        switch (wv - NWAVE) {
+            case 0: ct_loader<0>(a, smem, lane, lw, G, J); break;
+            case 1: ct_loader<1>(a, smem, lane, lw, G, J); break;
+            case 2: ct_loader<2>(a, smem, lane, lw, G, J); break;
+            default: ct_loader<3>(a, smem, lane, lw, G, J); break;
         }
         return;
     }
@@ -269,24 +291,60 @@ __device__ __forceinline__ CtTile ctb_tile_of(const CtbPlArgs& a, int t) {
     return r;
 }
 
-__device__ __forceinline__ void ctb_issue_dma(const CtbPlArgs& a, const CtTile& t, int c, char* st, int lw8, int lane) {
+// Loader wave LW (0..7) of the transposed conv's data gradient: slot = LW + 8 k -> k = 0..2 are the wave's three input pieces (plane k of ONE
+// (sub-position, 64-pixel segment) pair: sub = (LW >> 1) & 3, seg = LW & 1 -- so a lane has ONE pixel offset per tile), k = 3, 4 its two
+// weight pieces.  Descriptors + scalar plane offsets as in ct_issue_dma.
+template <int LW>
+__device__ __forceinline__ void ctb_loader(const CtbPlArgs& a, char* smem, int lane, int lw, int G, int J) {
     using namespace ctb;
+    static_assert(PER == 5 && IN_SLOTS == 24 && NLOAD == 8, "the slot arithmetic and the vmcnt immediate below");   // every piece has live lanes: PER DMA instructions per wave and step
+    constexpr int sub = (LW >> 1) & 3, seg = LW & 1;
+    lds_char* smem3 = (lds_char*)smem;
     const int oh = 2 * a.h, ow = 2 * a.w;
-    const size_t ohw = (size_t)oh * ow;
-#pragma unroll
-    for (int k = 0; k < PER; ++k) {
-        const int slot = lw8 + NLOAD * k;
-        if (slot < IN_SLOTS) {
-            const int plane = slot >> 3, sub = (slot >> 1) & 3, seg = slot & 1;
+    const unsigned ohw16 = (unsigned)(oh * ow) * 16u;
+    CtTile t = ctb_tile_of(a, lw);                                      // tile / chunk of the NEXT issue
+    int c = 0, kt = 0;
+    unsigned pixoff = 0;
+    auto plan = [&]() __attribute__((always_inline)) {
+        const int pix = seg * 64 + lane;
+        const int oy = min(2 * (t.y0 + pix / TW) + (sub >> 1), oh - 1), ox = min(2 * (t.x0 + pix % TW) + (sub & 1), ow - 1);
+        pixoff = (unsigned)(oy * ow + ox) * 16u;
+    };
+    plan();
+    const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(a.wp), 0, 0x7FFFFFF0, 0x00020000);
+    const unsigned lane16 = (unsigned)lane * 16u;
+    auto issue_next = [&](int j_issue) __attribute__((always_inline)) {
+        lds_char* st = smem3 + (j_issue % NSTAGE) * STAGE;
+        const char* in_base = a.dy + ((size_t)t.n * a.nch + c) * 3 * ohw16;
+        const auto rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(in_base), 0, (int)(3u * ohw16), 0x00020000);
+        const int w_base = (t.cb * a.nch + c) * W1;
+        WSU_STATIC_FOR(3, plane, {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void*)(st + ((plane * 4 + sub) * NPIX + seg * 64) * 16), 16, pixoff, (int)(plane * ohw16), 0, 0);
+        });
+        WSU_STATIC_FOR(2, k, {
+            constexpr int piece = LW + NLOAD * k;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void*)(st + IN1 + piece * 1024), 16, lane16, w_base + piece * 1024, 0, 0);
+        });
+        if (++c == a.nch) { c = 0; ++kt; t = ctb_tile_of(a, lw + kt * G); plan(); }
+    };
+    if (J > 0) issue_next(0);
+    if (J > 1) issue_next(1);
+    for (int j = 0; j < J; ++j) {
+        if (j + 1 < J) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");   // my pieces of step j landed, step j+1's stay in flight
+        else           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        {   // LDS plane 3 = e4m3(g * 4) of the f16 granules this wave fetched
+            char* st = smem + (j % NSTAGE) * STAGE;
             const int pix = seg * 64 + lane;
-            const int oy = min(2 * (t.y0 + pix / TW) + (sub >> 1), oh - 1), ox = min(2 * (t.x0 + pix % TW) + (sub & 1), ow - 1);
-            const char* src = a.dy + ((((size_t)t.n * a.nch + c) * 3 + plane) * ohw + (size_t)oy * ow + ox) * 16;
-            __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(st + ((plane * 4 + sub) * NPIX + seg * 64) * 16), 16, 0, 0);
-        } else {
-            const int piece = slot - IN_SLOTS;
-            const char* src = a.wp + ((size_t)t.cb * a.nch + c) * W1 + piece * 1024 + lane * 16;
-            __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(st + IN1 + piece * 1024), 16, 0, 0);
+#pragma unroll
+            for (int plane = 0; plane < 2; ++plane) {
+                const u32x4 hgr = *reinterpret_cast<const u32x4*>(st + ((plane * 4 + sub) * NPIX + pix) * 16);
+                *reinterpret_cast<u32x2*>(st + ((3 * 4 + sub) * NPIX + pix) * 16 + plane * 8) = wsu_f16x8_to_fp8_grad(hgr);
+            }
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (j + 2 < J) issue_next(j + 2);                               // its stage held step j-1: every matrix wave is past it
     }
 }
 
@@ -301,36 +359,15 @@ __global__ __launch_bounds__(ctb::NT) void convt2x2_bwd_pl_kernel(const CtbPlArg
     const int J = K * a.nch;
 
     if (wv >= NWAVE) {
-        const int lw8 = wv - NWAVE;
-        static_assert(PER == 5, "the vmcnt immediate below");           // every piece has live lanes: PER DMA instructions per wave and step
-        CtTile t = ctb_tile_of(a, lw);                                  // tile / chunk of the NEXT issue
-        int c = 0, kt = 0;
-        auto issue_next = [&](int j_issue) __attribute__((always_inline)) {
-            ctb_issue_dma(a, t, c, smem + (j_issue % NSTAGE) * STAGE, lw8, lane);
-            if (++c == a.nch) { c = 0; ++kt; t = ctb_tile_of(a, lw + kt * G); }
-        };
-        if (J > 0) issue_next(0);
-        if (J > 1) issue_next(1);
-        for (int j = 0; j < J; ++j) {
-            if (j + 1 < J) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");   // my pieces of step j landed, step j+1's stay in flight
-            else           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            {   // LDS plane 3 = e4m3(g * 4) of the f16 granules this wave fetched
-                char* st = smem + (j % NSTAGE) * STAGE;
-#pragma unroll
-                for (int k = 0; k < PER; ++k) {
-                    const int slot = lw8 + NLOAD * k;
-                    const int plane = slot >> 3, sub = (slot >> 1) & 3, seg = slot & 1;
-                    if (slot < IN_SLOTS && plane < 2) {
-                        const int pix = seg * 64 + lane;
-                        const u32x4 hgr = *reinterpret_cast<const u32x4*>(st + ((plane * 4 + sub) * NPIX + pix) * 16);
-                        *reinterpret_cast<u32x2*>(st + ((3 * 4 + sub) * NPIX + pix) * 16 + plane * 8) = wsu_f16x8_to_fp8_grad(hgr);
-                    }
-                }
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            if (j + 2 < J) issue_next(j + 2);                           // its stage held step j-1: every matrix wave is past it
+        switch (wv - NWAVE) {
+            case 0: ctb_loader<0>(a, smem, lane, lw, G, J); break;
+            case 1: ctb_loader<1>(a, smem, lane, lw, G, J); break;
+            case 2: ctb_loader<2>(a, smem, lane, lw, G, J); break;
+            case 3: ctb_loader<3>(a, smem, lane, lw, G, J); break;
+            case 4: ctb_loader<4>(a, smem, lane, lw, G, J); break;
+            case 5: ctb_loader<5>(a, smem, lane, lw, G, J); break;
+            case 6: ctb_loader<6>(a, smem, lane, lw, G, J); break;
+            default: ctb_loader<7>(a, smem, lane, lw, G, J); break;
         }
         return;
     }
@@ -510,7 +547,7 @@ int wsu_convt2x2_pl_fwd(const void* x, const void* w_packed, const float* bias, 
     WSU_REQUIRE(n > 0 && h > 0 && w > 0, "convt2x2_pl: bad shape n=%d h=%d w=%d", n, h, w);
     WSU_REQUIRE(cin > 0 && cin % 32 == 0, "convt2x2_pl: cin=%d must be a multiple of 32", cin);
     WSU_REQUIRE(cout > 0 && cout % WSU_COB == 0 && cout <= 1024, "convt2x2_pl: cout=%d must be a multiple of %d (<= 1024)", cout, WSU_COB);
-    WSU_REQUIRE((long long)h * w * 16 < 0x7FFFFFFFLL, "convt2x2_pl: h*w too large");
+    WSU_REQUIRE((long long)h * w * 96 < 0xFFFFFFF0LL, "convt2x2_pl: h*w too large (two input chunks and one output plane triple must stay below 4 GiB)");
     CtpArgs a;
     a.x = (const char*)x; a.wp = (const char*)w_packed; a.bias = bias; a.y = (char*)y; a.range_flag = range_flag;
     a.n = n; a.h = h; a.w = w; a.cin = cin; a.cout = cout;
@@ -547,7 +584,7 @@ int wsu_convt2x2_pl_bwd_data(const void* dy, const void* w_packed_dgrad, void* d
                              int n, int h, int w, int cin, int cout, void* stream) {
     WSU_REQUIRE(dy && w_packed_dgrad && dx, "convt2x2_pl_bwd_data: null pointer");
     WSU_REQUIRE(n > 0 && h > 0 && w > 0 && cin > 0 && cin % WSU_COB == 0 && cout > 0 && cout % 16 == 0, "convt2x2_pl_bwd_data: bad shape (cin %% 64, cout %% 16)");
-    WSU_REQUIRE((long long)h * w * 64 < 0x7FFFFFFFLL, "convt2x2_pl_bwd_data: h*w too large");
+    WSU_REQUIRE((long long)h * w * 192 < 0xFFFFFFF0LL, "convt2x2_pl_bwd_data: h*w too large (a plane triple of dy must stay below 4 GiB)");
     CtbPlArgs a;
     a.dy = (const char*)dy; a.wp = (const char*)w_packed_dgrad; a.dx = (char*)dx; a.mask = (const char*)mask;
     a.n = n; a.h = h; a.w = w; a.cin = cin; a.cout = cout;

@@ -1,6 +1,10 @@
 // Bandwidth-bound kernels of the forward path: first layer (few input planes), 1x1 head + sigmoid,
 // stand-alone max-pool, UniformDropout, u8 -> unit float, WS residual statistics.
 #include "wsu_device.h"
+// No fused multiply-adds in this file: the residual statistics follow numpy's float32 operation sequence (src/unet/evaluate.py:125-132).
+// (Until round 3 the SLP vectorizer happened to pack these products into v_pk_mul_f32 / v_pk_add_f32, which cannot fuse; built without it
+// (Makefile) hipcc's default -ffp-contract=fast would fuse them.)
+#pragma clang fp contract(off)
 
 namespace {
 

@@ -8,6 +8,11 @@
 // Optimiser: torch.optim.AdamW(params, lr) as in src/detector/train.py:228 (betas .9/.999, eps 1e-8, wd 1e-2).
 // Reductions are per-image fp64 trees in a fixed order (deterministic); the scalar loss is fp32.
 #include "wsu_device.h"
+// No fused multiply-adds in this file: the loss follows the reference's float32 operation sequence (out * 255 rounded, then subtracted: src/_defs/losses.py:55-63) -- a fused multiply-add
+// rounds once and moves the WS term by ~1e-4 relative through its cancellation.
+// (Until round 3 the SLP vectorizer happened to pack these products into v_pk_mul_f32 / v_pk_add_f32, which cannot fuse; built without it
+// (Makefile) hipcc's default -ffp-contract=fast would fuse them.)
+#pragma clang fp contract(off)
 #include <cmath>
 
 namespace {

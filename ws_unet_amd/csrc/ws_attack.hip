@@ -14,6 +14,10 @@
 // float32 for uint8 pixels, whatever the order of the nine products.
 // HBM-bound: 1 B (pixel, neighbours hit L1/L2) + 4 B (prediction) [+ 4 B bias prediction] per pixel.
 #include "wsu_device.h"
+// No fused multiply-adds in this file: the WS estimator follows numpy's float32 operation sequence (src/ws/estimate.py:90-121).
+// (Until round 3 the SLP vectorizer happened to pack these products into v_pk_mul_f32 / v_pk_add_f32, which cannot fuse; built without it
+// (Makefile) hipcc's default -ffp-contract=fast would fuse them.)
+#pragma clang fp contract(off)
 
 namespace {
 
