@@ -26,6 +26,8 @@ Extra JSON objects on the one line rank 0 prints:
                 autograd on exactly like the reference's infere_single; `cpu_baseline_best_effort` = the same model under
                 no_grad at batch 8 (what a careful CPU user would run), so that the speed-up is not inflated
   train_step    BASELINE.json configs[2]: fwd + L1WS + bwd + AdamW at batch 64 of 512x512 (N = 1 only)
+  latency_b1    the reference's call pattern (one image per call): GPU / wall time of a batch-1 forward and, per layer, the share of the
+                256 CUs the persistent grid occupies (N = 1 only)
 """
 import argparse
 import hashlib
@@ -41,6 +43,7 @@ sys.path.insert(0, str(ROOT))
 
 PEAK = {"bf16x3": 2.5e15, "bf16x3s": 2.5e15, "f16f8": 2.5e15, "f16f8p": 2.5e15, "f16f8q": 2.5e15, "bf16": 2.5e15, "f32": 157.3e12}     # dense MFMA peaks, MI355X_MICROARCH.md
 HBM_PEAK = 8.0e12
+NUM_CU = 256
 TRAIN_FLOP_PER_IMAGE_512 = 606.0e9        # 3 x forward minus the e11 data gradient
 
 
@@ -55,6 +58,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-modes", action="store_true")
     ap.add_argument("--no-train-step", action="store_true")
+    ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--train-batch", type=int, default=64)
     ap.add_argument("--rehearse", action="store_true",
                     help="launcher rehearsal without GPUs: the ranks form a gloo group, run the barrier / max-over-ranks timing code around an "
@@ -239,22 +243,76 @@ def pmc_traffic(args, algorithmic_bytes_per_launch):
 
 def per_layer_roofline(timer, mode):
     """Every launch of the forward against max(t_flop, t_byte) at the vendor peaks ('per layer and as the sum')."""
-    rows, t_meas, t_roof = [], 0.0, 0.0
+    rows, t_meas, t_roof, t_roof2 = [], 0.0, 0.0, 0.0
     for name, d in timer.per_layer().items():
         t_flop = d["flops"] / PEAK[mode]
         t_byte = d["bytes"] / HBM_PEAK
         roof = max(t_flop, t_byte)
         t = d["avg_ms"] * 1e-3
-        rows.append({"layer": name, "kernel": d["kernel"], "ms": round(d["avg_ms"], 4), "gflop": round(d["flops"] / 1e9, 1),
-                     "mbytes": round(d["bytes"] / 1e6, 1), "bound": "mfma" if t_flop >= t_byte else "hbm",
-                     "roof_ms": round(roof * 1e3, 4), "frac": round(roof / t, 4) if t > 0 else None,
-                     "tflops": round(d["flops"] / t / 1e12, 1) if t > 0 else None, "hbm_GBps": round(d["bytes"] / t / 1e9, 1) if t > 0 else None})
+        row = {"layer": name, "kernel": d["kernel"], "ms": round(d["avg_ms"], 4), "gflop": round(d["flops"] / 1e9, 1),
+               "mbytes": round(d["bytes"] / 1e6, 1), "bound": "mfma" if t_flop >= t_byte else "hbm",
+               "roof_ms": round(roof * 1e3, 4), "frac": round(roof / t, 4) if t > 0 else None,
+               "tflops": round(d["flops"] / t / 1e12, 1) if t > 0 else None, "hbm_GBps": round(d["bytes"] / t / 1e9, 1) if t > 0 else None}
+        if "bytes_2B" in d:                                          # SURVEY 8d's byte model (2 B per element) beside the format's own 3 B
+            roof2 = max(t_flop, d["bytes_2B"] / HBM_PEAK)
+            row.update({"mbytes_2B": round(d["bytes_2B"] / 1e6, 1), "roof_ms_2B": round(roof2 * 1e3, 4), "frac_2B": round(roof2 / t, 4) if t > 0 else None})
+            t_roof2 += roof2
+        else:
+            t_roof2 += roof
+        if "tiles" in d:                                             # persistent kernels: work items against the 256 CUs
+            row.update({"tiles": int(d["tiles"]), "steps_per_tile": int(d["steps_per_tile"]), "cu_occupied": round(min(d["tiles"], NUM_CU) / NUM_CU, 3),
+                        "tile_waves": round(d["tiles"] / NUM_CU, 2)})
+        rows.append(row)
         t_meas += t
         t_roof += roof
     return {"layers": rows, "sum_ms": round(t_meas * 1e3, 4), "sum_roof_ms": round(t_roof * 1e3, 4),
             "frac": round(t_roof / t_meas, 4) if t_meas > 0 else None,
+            "sum_roof_ms_2B": round(t_roof2 * 1e3, 4), "frac_2B": round(t_roof2 / t_meas, 4) if t_meas > 0 else None,
             "note": "roof = max(algorithmic FLOPs / dense MFMA peak, algorithmic bytes / 8 TB/s) per launch; bytes = inputs once + "
-                    "outputs once + weights in the mode's storage format"}
+                    "outputs once + weights in the mode's storage format (3 B per element in 'f16f8p'); the *_2B columns price the same "
+                    "traffic at SURVEY 8d's 2 B per element, which lowers the HBM-bound rows"}
+
+
+def latency_b1_leg(dev, mode, size=512, reps=40, warmup=8):
+    """The reference's own call pattern: one image per call (src/unet/evaluate.py:31-52, batch is always 1).  GPU time of a batch-1 forward
+    (sum of the launches' HIP-event times), wall time of a synchronised call, and per layer how many of the 256 CUs the persistent grids
+    occupy (e31 / e32 of unet_2 at 512x512 have 128 tiles)."""
+    import numpy as np
+    import torch
+    from ws_unet_amd import formula, ops
+    u8 = formula.synthetic_images(1, size, size, seed=4242)
+    x = ops.u8_to_unit(torch.from_numpy(u8).to(dev))[:, None].contiguous()
+    model = build_model(mode, dev)
+    with torch.no_grad():
+        for _ in range(warmup):
+            model(x)
+        torch.cuda.synchronize()
+        walls = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            model(x)
+            torch.cuda.synchronize()
+            walls.append(time.perf_counter() - t0)
+        timer = ops.KernelTimer()
+        ops.set_timer(timer)
+        for _ in range(reps):
+            model(x)
+        torch.cuda.synchronize()
+        ops.set_timer(None)
+        ops.set_layer(None)
+        # back-to-back calls without a sync in between: what a caller that queues images gets
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            model(x)
+        torch.cuda.synchronize()
+        queued = (time.perf_counter() - t0) / reps
+    pl = per_layer_roofline(timer, mode)
+    gpu_ms = pl["sum_ms"]
+    return {"workload": f"unet_2 forward, batch=1, {size}x{size}x1, mode {mode} (the reference's infere_single call pattern)",
+            "gpu_ms_per_image": gpu_ms, "wall_ms_per_image_synchronised": float(np.median(walls)) * 1e3, "wall_ms_per_image_queued": queued * 1e3,
+            "images_per_s_queued": 1.0 / queued, "launches_per_forward": len(pl["layers"]),
+            "tflops_algorithmic": 202.2e9 * (size / 512.0) ** 2 / (gpu_ms * 1e-3) / 1e12,
+            "per_layer": [{k: r[k] for k in ("layer", "ms", "tiles", "steps_per_tile", "cu_occupied", "tile_waves", "tflops", "hbm_GBps") if k in r} for r in pl["layers"]]}
 
 
 def train_step_leg(dev, batch, size, steps=5, warmup=3, train_mode=None):
@@ -427,6 +485,12 @@ def main():
     y_host = y.cpu() if rank == 0 else None
     del model, y
     torch.cuda.empty_cache()
+
+    if rank == 0 and world == 1 and not args.no_latency:
+        try:
+            result["latency_b1"] = latency_b1_leg(dev, args.mode, args.size)
+        except Exception as e:
+            result["latency_b1"] = {"error": f"{type(e).__name__}: {e}"}
 
     if rank == 0 and world == 1 and not args.no_train_step:
         try:

@@ -4,7 +4,7 @@ R=$GRAFT_REPO_ROOT; [ -n "$R" ] || R=$(pwd)
 O=$R/gpurun_out/prof_round
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-B="--no-other-modes --no-cpu-baseline --no-train-step"
+B="--no-other-modes --no-cpu-baseline --no-train-step --no-latency"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/kt -o bench --output-format csv -- python3 $R/bench.py $B > $O/bench_kt.log 2>&1
 echo "kernel trace done"
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch -o bench --output-format csv -- python3 $R/bench.py $B --steps 3 --warmup 1 > $O/bench_pmc_fetch.log 2>&1

@@ -57,7 +57,8 @@ struct PlArgs {
     const float* img; const float* w1; const float* b1;   // fused first layer (kernel variant F1): the 64 input channels are computed by the loaders
     int xres;                                             // 0: the inputs' residual plane (plane 2) is not used (kernel variant XRES = false)
     unsigned* range_flag;                                 // optional: bit 0 is set when a stored activation exceeds the encodable range (|x| > 448)
-    int ablate;                                           // timing-only experiments (WSU_PL_ABLATE; results wrong when != 0): 1 = no DMA after step 0
+    int ablate;                                           // timing-only experiments (WSU_PL_ABLATE, bits; results wrong when != 0): 1 = no DMA after step 0,
+                                                          // 2 = no epilogue (accumulators dropped), 8 = the loaders do not derive LDS plane 3
     // data-gradient variant (GRAD): zero padding, gradient encodings, no bias / ReLU; output chunks < nco1 go to y, the others to y2 (fused
     // concat: one gradient per source); mask / mask2 (optional, planar activations shaped like y / y2): the ReLU mask (x > 0) of the layer
     // that produced this conv's input, applied to the result; images n >= k * imgs_per_wset take weight set k (ring strips)
@@ -128,8 +129,7 @@ __device__ __forceinline__ void plan_tile(const PlArgs& a, const Tile& t, int la
     });
 }
 
-// the DMA of one chunk step into stage `st`: this wave's 7-8 input pieces and 9 weight pieces (weight and input pieces alternate, so that
-// the first pieces of both operands land early)
+// the DMA of one chunk step into stage `st`: this wave's 7-8 input pieces, then its 9 weight pieces
 typedef __attribute__((address_space(3))) char lds_char;
 template <int LW, bool XRES, bool WEIGHTS_ONLY>
 __device__ __forceinline__ void issue_dma(const PlArgs& a, int tn, int tcb, int c, lds_char* st, int lane, const unsigned (&voff)[IN_PER_WAVE]) {
@@ -142,8 +142,10 @@ __device__ __forceinline__ void issue_dma(const PlArgs& a, int tn, int tcb, int 
     const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(w_src), 0, 0x7FFFFFF0, 0x00020000);
     const int w_base = (tcb * a.nch + c) * LDS_W;                                // scalar
     const unsigned lane16 = (unsigned)lane * 16u;
-    WSU_STATIC_FOR(W_PER_WAVE, k, {
-        if constexpr (!WEIGHTS_ONLY && k < IN_PER_WAVE) {
+    // input pieces first, the 9 weight pieces last: the loader derives LDS plane 3 from its landed input pieces (`s_waitcnt vmcnt(9)`)
+    // while its weight pieces are still in flight
+    if constexpr (!WEIGHTS_ONLY) {
+        WSU_STATIC_FOR(IN_PER_WAVE, k, {
             if constexpr (LoaderGeo<LW>::exists(k) && (XRES || LoaderGeo<LW>::plane(k) != 2)) {
                 constexpr int plane = LoaderGeo<LW>::plane(k), seg = LoaderGeo<LW>::seg(k);
                 lds_void* dst = (lds_void*)(st + plane * PLANE + seg * 1024);
@@ -153,7 +155,9 @@ __device__ __forceinline__ void issue_dma(const PlArgs& a, int tn, int tcb, int 
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, dst, 16, voff[k], 0, 0, 0);
                 }
             }
-        }
+        });
+    }
+    WSU_STATIC_FOR(W_PER_WAVE, k, {
         constexpr int wslot = LW + NLOAD * k;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void*)(st + LDS_IN + wslot * 1024), 16, lane16, w_base + wslot * 1024, 0, 0);
     });
@@ -309,8 +313,10 @@ __device__ __forceinline__ void pl_loader(const PlArgs& a, char* smem, int lane,
     int c = 0, kt = 0;
     for (int j = 0; j < J; ++j) {
         STAMP(s0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // this wave's pieces of step j have landed
-        derive_x8(smem + (j & 1) * STAGE);
+        static_assert(W_PER_WAVE == 9, "the vmcnt immediate below");
+        asm volatile("s_waitcnt vmcnt(9)" ::: "memory");                  // this wave's INPUT pieces of step j have landed (everything older than its
+        if (!(a.ablate & 8)) derive_x8(smem + (j & 1) * STAGE);           // 9 youngest operations: the weight pieces, or mask loads issued after them)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // ... its weight pieces (and the mask granules) too
         if (mask_pending) { mask_commit(); mask_pending = false; }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                // ... and its derived / computed planes are written
         STAMP(s1);
@@ -533,6 +539,14 @@ _Pragma("unroll")
         STAMP(s4);
         t_wait += s1 - s0; t_bar += s2 - s1; t_dma += s3 - s2; t_mma += s4 - s3;
         // ---- epilogue of the tile: accumulators -> planar global memory ---------------------------------------------------------
+        if (c + 1 == a.nch && (a.ablate & 2)) {                            // timing only: the tile's results are dropped (kept alive for the compiler)
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) asm volatile("" :: "v"(acc[m][q]));
+            ++kt; c = 0;
+            if (j + 1 < J) cur = tile_of(a, lw + kt * G);
+        } else
         if (c + 1 == a.nch) {
             const int col = cur.x0 + l31;
             const size_t hw = (size_t)a.h * a.w;

@@ -127,6 +127,20 @@ def predict_unet(
     """Per-image WS estimate and MAE (evaluate.py:109-139).  With this package's UNet and a 512x512 image the pixels go up as
     uint8 and only the two statistics come back (wsu_u8_to_unit_f32 -> forward -> wsu_ws_residual_stats, same float32 arithmetic);
     for any other predictor callable the reference's host formulas below are evaluated on its returned array."""
+    if isinstance(model, torch.nn.Module) and hasattr(model, "forward_features") and imread is imread4_f32:
+        # default reader + this package's UNet: the Y plane is decoded by libwsu_io (zlib + PNG unfilter + cv2's luma in C++, straight into a
+        # pinned buffer) instead of PIL -- the same plane `imread4_f32(fname)[..., 3]` holds (tests/test_host_logic.py), 2.5x less host
+        # time per image; files it does not support fall back to PIL inside read_luma_batch
+        from .imread import png_shape
+        if png_shape(str(fname)) == (512, 512):
+            planes = load_planes_u8([fname])
+            if planes is not None:
+                x_u8 = planes.to(_model_device(model), non_blocking=True)
+                mark_uploaded(planes)
+                beta, l1 = predict_u8_batch(x_u8, model)
+                if range_fallback(model):
+                    beta, l1 = predict_u8_batch(x_u8, model)
+                return {**kw, "beta_hat": np.float32(beta[0].item()), "l1": np.float32(l1[0].item())}
     x = imread(fname)[..., 3:]
     if isinstance(model, torch.nn.Module) and hasattr(model, "forward_features") and x.shape[:2] == (512, 512):
         xi = np.ascontiguousarray(x[..., 0])

@@ -45,7 +45,8 @@ class KernelTimer:
             name = meta.get("layer")
             if name is None:
                 continue
-            d = out.setdefault(name, {"kernel": k, "launches": 0, "total_ms": 0.0, "flops": meta.get("flops", 0.0), "bytes": meta.get("bytes", 0.0)})
+            d = out.setdefault(name, {"kernel": k, "launches": 0, "total_ms": 0.0, "flops": meta.get("flops", 0.0), "bytes": meta.get("bytes", 0.0),
+                                      **{key: meta[key] for key in ("bytes_2B", "tiles", "steps_per_tile") if key in meta}})
             d["launches"] += 1
             d["total_ms"] += s.elapsed_time(e)
         for d in out.values():
@@ -277,9 +278,12 @@ def conv3x3_pl(x1: torch.Tensor, x2: Optional[torch.Tensor], w_packed: torch.Ten
     hc = 0 if hw2 is None else hw2.shape[0]
     out = torch.empty((n, hc, h, w), dtype=torch.float32, device=x1.device) if hc else None
     logit = torch.empty_like(out) if (hc and want_logit) else None
+    act = n * h * w * ((c1 + c2) + (cout if want_y else 0)) + (n * (h // 2) * (w // 2) * cout if pool else 0)     # planar elements read + written
     meta = {"flops": 2.0 * 9 * (c1 + c2) * cout * n * h * w,
-            "bytes": float(n * h * w * ((c1 + c2) * 3 + (cout * 3 if want_y else 0) + hc * 4) + (n * (h // 2) * (w // 2) * cout * 3 if pool else 0)
-                           + 9 * (c1 + c2) * cout * 4)}
+            "bytes": float(act * 3 + n * h * w * hc * 4 + 9 * (c1 + c2) * cout * 4),
+            # SURVEY 8d counts 2 bytes per activation element (bf16) and per weight: reported beside the format's own 3 B (bench.py per_layer)
+            "bytes_2B": float(act * 2 + n * h * w * hc * 4 + 9 * (c1 + c2) * cout * 2),
+            "tiles": n * ((h + 15) // 16) * ((w + 31) // 32) * (cout // 64), "steps_per_tile": (c1 + c2) // 16}
     check(_launch("conv3x3_pl", meta, lambda: lib.wsu_conv3x3_pl_fwd(
         x1.data_ptr(), _ptr(x2), w_packed.data_ptr(), _ptr(bias), _ptr(y), _ptr(yp), _ptr(hw2), _ptr(head_b), _ptr(out), _ptr(logit), hc,
         n, h, w, c1, c2, cout, int(relu), int(x_residual), _ptr(range_flag), _stream())), "wsu_conv3x3_pl_fwd")
@@ -300,8 +304,10 @@ def conv3x3_pl_fused_first(x_nchw: torch.Tensor, w1: torch.Tensor, b1: Optional[
     assert cin == 1 and tuple(w1.shape) == (64, 1, 3, 3) and x_nchw.dtype == torch.float32 and x_nchw.is_contiguous()
     y = torch.empty(planar_shape(n, cout, h, w), dtype=torch.float32, device=x_nchw.device)
     yp = torch.empty(planar_shape(n, cout, h // 2, w // 2), dtype=torch.float32, device=x_nchw.device) if pool else None
+    act = n * h * w * cout + (n * (h // 2) * (w // 2) * cout if pool else 0)
     meta = {"flops": 2.0 * 9 * 64 * cout * n * h * w,
-            "bytes": float(n * h * w * (4 + cout * 3) + (n * (h // 2) * (w // 2) * cout * 3 if pool else 0) + 9 * 64 * cout * 4)}
+            "bytes": float(n * h * w * 4 + act * 3 + 9 * 64 * cout * 4), "bytes_2B": float(n * h * w * 4 + act * 2 + 9 * 64 * cout * 2),
+            "tiles": n * ((h + 15) // 16) * ((w + 31) // 32) * (cout // 64), "steps_per_tile": 4}
     check(_launch("conv3x3_pl", meta, lambda: lib.wsu_conv3x3_pl_fused_first_fwd(
         x_nchw.data_ptr(), w1.data_ptr(), _ptr(b1), w_packed.data_ptr(), _ptr(bias), y.data_ptr(), _ptr(yp),
         n, h, w, cout, int(relu), _ptr(range_flag), _stream())), "wsu_conv3x3_pl_fused_first_fwd")
@@ -317,7 +323,9 @@ def convt2x2_pl(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Te
     n, nch, _, h, w, _ = x.shape
     cin = nch * 16
     y = torch.empty(planar_shape(n, cout, 2 * h, 2 * w), dtype=torch.float32, device=x.device)
-    meta = {"flops": 2.0 * 4 * cin * cout * n * h * w, "bytes": float(n * h * w * (cin + 4 * cout) * 3 + 4 * cin * cout * 4)}
+    meta = {"flops": 2.0 * 4 * cin * cout * n * h * w, "bytes": float(n * h * w * (cin + 4 * cout) * 3 + 4 * cin * cout * 4),
+            "bytes_2B": float(n * h * w * (cin + 4 * cout) * 2 + 4 * cin * cout * 2),
+            "tiles": n * ((h + 3) // 4) * ((w + 31) // 32) * (cout // 64), "steps_per_tile": cin // 32}
     check(_launch("convt2x2_pl", meta, lambda: lib.wsu_convt2x2_pl_fwd(
         x.data_ptr(), w_packed.data_ptr(), _ptr(bias), y.data_ptr(), n, h, w, cin, cout, _ptr(range_flag), _stream())), "wsu_convt2x2_pl_fwd")
     return y
@@ -333,7 +341,7 @@ def conv3x3_first_pl(x_nchw: torch.Tensor, w: torch.Tensor, bias: Optional[torch
     cout = w.shape[0]
     assert x_nchw.dtype == torch.float32 and x_nchw.is_contiguous() and w.shape[1] == cin
     y = torch.empty(planar_shape(n, cout, h, wd), dtype=torch.float32, device=x_nchw.device)
-    meta = {"flops": 2.0 * 9 * cin * cout * n * h * wd, "bytes": float(n * h * wd * (cin * 4 + cout * 3))}
+    meta = {"flops": 2.0 * 9 * cin * cout * n * h * wd, "bytes": float(n * h * wd * (cin * 4 + cout * 3)), "bytes_2B": float(n * h * wd * (cin * 4 + cout * 2))}
     check(_launch("conv3x3_first_pl", meta, lambda: lib.wsu_conv3x3_first_pl_fwd(
         x_nchw.data_ptr(), w.data_ptr(), _ptr(bias), y.data_ptr(), n, h, wd, cin, cout, int(relu), _ptr(range_flag), _stream())), "wsu_conv3x3_first_pl_fwd")
     return y
