@@ -241,6 +241,32 @@ def pmc_traffic(args, algorithmic_bytes_per_launch):
     return out
 
 
+def sq_counters(args):
+    """Matrix-pipe busy fraction of the dominant kernel from the SQ counters (SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES; rocprofv3 has to wrap
+    the process, so the number comes from the committed summary of tools/profile_sq.sh -> tools/pmc_sq.py --json, and only when the git blob
+    of the kernel source it was collected on equals this tree's -- like `traffic`)."""
+    if (args.batch, args.size) != (32, 512) or args.mode != "f16f8p":
+        return None
+    cands = sorted((ROOT / "profiles").glob("r*/sq_counters.json"))
+    if not cands:
+        return None
+    with open(cands[-1]) as f:
+        sq = json.load(f)
+    src = ROOT / "ws_unet_amd" / "csrc" / "conv3x3_pl.hip"
+    out = {"source": str(cands[-1].relative_to(ROOT))}
+    if sq.get("meta", {}).get("kernel_source_blobs", {}).get("conv3x3_pl.hip") != git_blob_sha1(src):
+        out["note"] = "stale: the counters were collected on another revision of conv3x3_pl.hip (re-run tools/profile_sq.sh)"
+        return out
+    k = sq["kernels"].get("conv3x3_pl_kernel", {}).get("fwd1")
+    if k:
+        out.update({"mfma_busy": k.get("mfma_busy"), "mfma_busy_time_based": k.get("mfma_busy_t"), "clock_GHz_profiled": k.get("clock_GHz"),
+                    "wave_wait_any_share": k.get("sq_wait_any_share"), "wave_wait_inst_share": k.get("sq_wait_inst_any_share"),
+                    "wave_active_share": k.get("sq_active_inst_any_share"),
+                    "note": "SQ_VALU_MFMA_BUSY_CYCLES / (32 x SQ_BUSY_CYCLES) over the conv3x3_pl launches of this command under rocprofv3 --pmc "
+                            "(product libwsu.so; profiled passes run ~3 % below the un-profiled clock)"})
+    return out
+
+
 def per_layer_roofline(timer, mode):
     """Every launch of the forward against max(t_flop, t_byte) at the vendor peaks ('per layer and as the sum')."""
     rows, t_meas, t_roof, t_roof2 = [], 0.0, 0.0, 0.0
@@ -443,6 +469,9 @@ def main():
                                       "frac_of_peak": achieved * units / PEAK[args.mode],
                                       "note": "matrix-pipe time actually issued (split terms included) against the same dense bf16 peak"}
         roofline.update(pmc_traffic(args, conv["bytes"] / conv["launches"]))
+        busy = sq_counters(args)
+        if busy is not None and "mfma_issue" in roofline:
+            roofline["mfma_busy"] = busy
         roofline["per_layer"] = per_layer_roofline(timer, args.mode)
         ctk = "convt2x2_pl" if "convt2x2_pl" in ks else "convt2x2"
         if ctk in ks:

@@ -132,7 +132,13 @@ int wsu_conv3x3_wino_fwd(const void* x1, const void* x2, const void* w_packed, c
  *      reference lines as wsu_conv3x3_fwd / wsu_conv3x3_head_fwd (unet.py:141-189). */
 int wsu_conv3x3_pl_fwd(const void* x1, const void* x2, const void* w_packed, const float* bias, void* y, void* y_pool,
                        const float* head_w, const float* head_b, float* head_out, float* head_logit, int head_cout,
-                       int n, int h, int w, int c1, int c2, int cout, int relu, int x_residual, unsigned* range_flag, void* stream);
+                       int n, int h, int w, int c1, int c2, int cout, int relu, int x_residual, unsigned* range_flag,
+                       unsigned char* relu_mask_out, void* stream);
+/*      relu_mask planes (round 3; training): relu_mask_out (optional; plain variant: y only) receives the 1-bit ReLU mask of y --
+ *      [n][cout/8][hp][wp] bytes, hp = 16 * ceil(h / 16), wp = 32 * ceil(w / 32) (wsu_relu_mask_bytes), byte (pixel, 8-channel granule),
+ *      bit e = (stored f16 value of channel 8 g + e > 0).  The data gradient of the NEXT conv reads it (mask1_bits / mask2_bits of
+ *      wsu_conv3x3_pl_bwd_data) instead of the 2 bytes per element of y's f16 planes.  Rows beyond h / columns beyond w are not written. */
+size_t wsu_relu_mask_bytes(int n, int c, int h, int w);
 
 /* ---- K1p + K0p fused: e11 -> e12 (-> pool) of the planar path in one launch for single-plane inputs (unet.py:141-144).  The loader waves of
  *      the persistent kernel compute e11's 64 channels from the image straight into the LDS stages (instead of fetching them); bitwise the
@@ -154,7 +160,11 @@ size_t wsu_conv3x3_pl_bwd_data_workspace_bytes(int n, int h, int w, int cin, int
 int wsu_conv3x3_pack_ring(const float* w_oihw, void* w_packed, int cin, int cout, void* stream);
 int wsu_conv3x3_pl_bwd_data(const void* g, const void* w_packed_dgrad, const void* w_packed_ring, void* workspace, size_t workspace_bytes,
                             void* dx1, void* dx2, int csplit, const void* mask1, const void* mask2,
+                            const unsigned char* mask1_bits, const unsigned char* mask2_bits,
                             int n, int h, int w, int cin, int cout, int pad_zero, void* stream);
+/*      mask1_bits / mask2_bits (optional, each only together with its mask1 / mask2): the relu_mask planes of those activations; the
+ *      persistent kernel then brings a tile's mask in by LDS-DMA (4 KB) instead of re-reading the activations' f16 planes (64 KB); the
+ *      border fold still reads mask1 / mask2. */
 
 /* ---- K7p: weight / bias gradients on PLANAR operands (csrc/wgrad.hip wgrad_pl_kernel: the split-K MFMA GEMM over pixels of
  *      wsu_conv3x3_bwd_weight with planar staging -- one stored f16 granule + half a residual granule per (pixel, 8 channels), no split arithmetic).
@@ -196,7 +206,7 @@ int wsu_conv3x3_first_pl_bwd_weight(const void* g, const float* img, float* dw, 
 int wsu_convt2x2_pl_fwd(const void* x, const void* w_packed, const float* bias, void* y, int n, int h, int w, int cin, int cout,
                         unsigned* range_flag, void* stream);
 int wsu_conv3x3_first_pl_fwd(const float* x_nchw, const float* w_oihw, const float* bias, void* y, int n, int h, int w, int cin, int cout,
-                             int relu, unsigned* range_flag, void* stream);
+                             int relu, unsigned* range_flag, unsigned char* relu_mask_out, void* stream);
 
 /* ---- first layer: conv3x3 reflect on a few input planes given as NCHW fp32 (the model input).
  *      Replaces e11 (unet.py:82,141).  cin <= 8, cout multiple of 8.  w is plain OIHW fp32. */

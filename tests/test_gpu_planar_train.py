@@ -75,6 +75,59 @@ def test_conv3x3_pl_bwd_data(n, h, w, cin, csplit, cout, masked, pad_zero):
         assert float(got[(act <= 0)].abs().max()) == 0.0
 
 
+def _mask_bits_ref(y_planar):
+    """relu_mask plane of a planar activation, restated on the host (include/wsu.h): byte (pixel, 8-channel granule), bit e = stored f16 value
+    of channel 8 g + e > 0; rows / columns padded to the 16 x 32 tile grid with zeros."""
+    raw = y_planar.detach().contiguous().view(torch.uint8)                        # (n, chunk, 3, h, w, 16)
+    n, nch, _, h, w, _ = raw.shape
+    f16 = torch.stack([raw[:, :, 0], raw[:, :, 1]], dim=2).contiguous().view(torch.float16).reshape(n, nch * 2, h, w, 8)   # granule planes
+    bits = ((f16 > 0).to(torch.int32) << torch.arange(8, device=raw.device, dtype=torch.int32)).sum(-1).to(torch.uint8)
+    out = torch.zeros((n, nch * 2, (h + 15) // 16 * 16, (w + 31) // 32 * 32), dtype=torch.uint8, device=raw.device)
+    out[:, :, :h, :w] = bits
+    return out
+
+
+@pytest.mark.parametrize("n,h,w,c1,c2,cout", [(2, 32, 64, 64, 0, 64), (1, 18, 34, 64, 64, 128), (3, 2, 2, 128, 0, 64), (1, 40, 72, 16, 0, 64)])
+def test_relu_mask_plane_of_the_forward_kernels(n, h, w, c1, c2, cout):
+    """The 1-bit ReLU mask written by the training forward (wsu_conv3x3_pl_fwd relu_mask_out, wsu_conv3x3_first_pl_fwd) is exactly the sign
+    pattern of the stored f16 planes -- what the data gradient used to re-read (ragged tiles, the smallest image, fused concat)."""
+    ops = _ops()
+    x1 = planar_encode(torch.relu(_rand((n, c1, h, w), 31)))
+    x2 = planar_encode(torch.relu(_rand((n, c2, h, w), 32))) if c2 else None
+    wgt = _rand((cout, c1 + c2, 3, 3), 33, (2.0 / (9 * (c1 + c2))) ** 0.5).to(DEV)
+    b = _rand((cout,), 34, 0.1).to(DEV)
+    y, mask = ops.conv3x3_pl(x1, x2, ops.pack_conv3x3(wgt, ops.MODE_F16F8), b, cout, want_mask=True)
+    y0 = ops.conv3x3_pl(x1, x2, ops.pack_conv3x3(wgt, ops.MODE_F16F8), b, cout)
+    torch.cuda.synchronize()
+    assert torch.equal(y.view(torch.int32), y0.view(torch.int32))                  # asking for the mask does not change y
+    assert torch.equal(mask, _mask_bits_ref(y))
+    assert 0.2 < float((planar_decode(y) > 0).float().mean()) < 0.8               # a real mix of zeros and positives
+    img = _rand((n, 1, h, w), 35).to(DEV)
+    w1, b1 = _rand((64, 1, 3, 3), 36, 0.5).to(DEV), _rand((64,), 37, 0.1).to(DEV)
+    f, fmask = ops.conv3x3_first_pl(img, w1, b1, want_mask=True)
+    assert torch.equal(fmask, _mask_bits_ref(f))
+
+
+@pytest.mark.parametrize("n,h,w,cin,csplit,cout", [(2, 32, 64, 64, 64, 64), (1, 37, 70, 128, 64, 64), (2, 18, 34, 64, 64, 128), (1, 96, 160, 128, 128, 64)])
+def test_conv3x3_pl_bwd_data_mask_bits_equal_activation_masks(n, h, w, cin, csplit, cout):
+    """The data gradient fed the 1-bit planes (LDS-DMA of 4 KB per tile) returns bitwise what it returns fed the activations themselves
+    (16 granule loads per loader lane and tile): same masks, same arithmetic (reflect padding incl. the border fold; fused concat)."""
+    ops = _ops()
+    wd = _rand((cout, cin, 3, 3), 41, (2.0 / (9 * cin)) ** 0.5).to(DEV)
+    g = planar_encode(_rand((n, cout, h, w), 42), GRAD_LO)
+    act = torch.relu(_rand((n, cin, h, w), 43))
+    m1 = planar_encode(act[:, :csplit]); m2 = planar_encode(act[:, csplit:]) if csplit < cin else None
+    wp, wr = ops.pack_conv3x3(wd, ops.MODE_F16F8, dgrad=True), ops.pack_conv3x3_ring(wd)
+    a1, a2 = ops.conv3x3_pl_bwd_data(g, wp, wr, cin, csplit, m1, m2)
+    b1, b2 = ops.conv3x3_pl_bwd_data(g, wp, wr, cin, csplit, m1, m2, mask1_bits=_mask_bits_ref(m1), mask2_bits=None if m2 is None else _mask_bits_ref(m2))
+    torch.cuda.synchronize()
+    assert torch.equal(a1.view(torch.int32), b1.view(torch.int32))
+    if a2 is not None:
+        assert torch.equal(a2.view(torch.int32), b2.view(torch.int32))
+    got = planar_decode(b1, GRAD_LO)
+    assert float(got[(act[:, :csplit] <= 0)].abs().max()) == 0.0 and float(got.abs().max()) > 0
+
+
 @pytest.mark.parametrize("n,h,w,c1,c2,cout", [
     (2, 16, 32, 64, 0, 64),
     (1, 37, 70, 64, 0, 128),            # partial tiles, several tiles per image column (rolling row window)

@@ -47,12 +47,13 @@ SIGNATURES = {
     "wsu_conv3x3_wino_packed_bytes": (c_size_t, [c_int, c_int]),
     "wsu_conv3x3_wino_pack": (c_int, [_P, _P, c_int, c_int, _P]),
     "wsu_conv3x3_wino_fwd": (c_int, [_P] * 11 + [c_int] * 8 + [_P]),
-    "wsu_conv3x3_pl_fwd": (c_int, [_P] * 10 + [c_int] * 9 + [_P, _P]),
+    "wsu_conv3x3_pl_fwd": (c_int, [_P] * 10 + [c_int] * 9 + [_P, _P, _P]),
+    "wsu_relu_mask_bytes": (c_size_t, [c_int] * 4),
     "wsu_conv3x3_pl_fused_first_fwd": (c_int, [_P] * 7 + [c_int] * 5 + [_P, _P]),
     "wsu_convt2x2_pl_fwd": (c_int, [_P, _P, _P, _P] + [c_int] * 5 + [_P, _P]),
     "wsu_conv3x3_pl_bwd_data_workspace_bytes": (c_size_t, [c_int] * 5),
     "wsu_conv3x3_pack_ring": (c_int, [_P, _P, c_int, c_int, _P]),
-    "wsu_conv3x3_pl_bwd_data": (c_int, [_P, _P, _P, _P, c_size_t, _P, _P, c_int, _P, _P] + [c_int] * 6 + [_P]),
+    "wsu_conv3x3_pl_bwd_data": (c_int, [_P, _P, _P, _P, c_size_t, _P, _P, c_int, _P, _P, _P, _P] + [c_int] * 6 + [_P]),
     "wsu_conv3x3_pl_bwd_weight": (c_int, [_P] * 6 + [c_size_t] + [c_int] * 6 + [_P]),
     "wsu_convt2x2_pl_bwd_weight": (c_int, [_P] * 5 + [c_size_t] + [c_int] * 5 + [_P]),
     "wsu_convt2x2_pl_pack_dgrad": (c_int, [_P, _P, c_int, c_int, _P]),
@@ -63,7 +64,7 @@ SIGNATURES = {
     "wsu_chansum_pl_workspace_bytes": (c_size_t, [c_int]),
     "wsu_colsum_pl": (c_int, [_P, _P, _P, c_size_t] + [c_int] * 4 + [_P]),
     "wsu_conv3x3_first_pl_bwd_weight": (c_int, [_P] * 5 + [c_size_t] + [c_int] * 4 + [_P]),
-    "wsu_conv3x3_first_pl_fwd": (c_int, [_P, _P, _P, _P] + [c_int] * 6 + [_P, _P]),
+    "wsu_conv3x3_first_pl_fwd": (c_int, [_P, _P, _P, _P] + [c_int] * 6 + [_P, _P, _P]),
     "wsu_conv3x3_first_fwd": (c_int, [_P, _P, _P, _P] + [c_int] * 7 + [_P]),
     "wsu_maxpool2x2_fwd": (c_int, [_P, _P, _P] + [c_int] * 5 + [_P]),
     "wsu_convt2x2_fwd": (c_int, [_P, _P, _P, _P] + [c_int] * 6 + [_P]),

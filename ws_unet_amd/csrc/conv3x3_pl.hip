@@ -65,6 +65,10 @@ struct PlArgs {
     char* y2; int nco1;
     const char* mask; const char* mask2;
     int imgs_per_wset; size_t wset_bytes;
+    // 1-bit ReLU masks (round 3; layout: wsu.h "relu_mask planes", [n][C/8][hp][wp] bytes).  Forward (plain variant): relu_mask_out (optional)
+    // receives one byte per stored (pixel, 8-channel granule).  GRAD: mbits / mbits2 (optional) replace `mask` / `mask2` -- the loaders bring
+    // the tile's 8 granule planes x 512 bytes in by LDS-DMA instead of re-reading 2 bytes per element of the producing layer's f16 planes.
+    unsigned char* relu_mask_out; const unsigned char* mbits; const unsigned char* mbits2;
 };
 
 __device__ __attribute__((aligned(16))) unsigned g_zero16[4];   // source of the zero-padding DMA pieces of the GRAD variant
@@ -276,6 +280,23 @@ __device__ __forceinline__ void pl_loader(const PlArgs& a, char* smem, int lane,
     auto mask_issue = [&](const Tile& tt) __attribute__((always_inline)) {
         if constexpr (GRAD) {
             const bool d1 = tt.cb * 4 < a.nco1;
+            const unsigned char* mb = d1 ? a.mbits : a.mbits2;
+            if (mb != nullptr) {
+                // 1-bit masks: the tile's 8 granule planes x (16 rows x 32 bytes) go straight into s_mask by LDS-DMA, 256 bytes (8 rows) per
+                // instruction, 4 instructions per loader wave (granule planes 2 LW, 2 LW + 1); rows and row pitch are padded to the tile
+                // grid (wsu_mask_hp / _wp), so every access is aligned and inside the plane
+                const int ncm = d1 ? a.nco1 : (a.cout >> 4) - a.nco1, oc0 = d1 ? tt.cb * 4 : tt.cb * 4 - a.nco1;
+                const int hp = wsu_mask_hp(a.h), wp = wsu_mask_wp(a.w);
+                const auto rs_m = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(mb), 0, 0x7FFFFFF0, 0x00020000);
+                const unsigned mvoff = (unsigned)((lane >> 3) * wp + (lane & 7) * 4);
+                lds_char* sm3 = (lds_char*)s_mask;
+                WSU_STATIC_FOR(4, i, {
+                    constexpr int gp = 2 * LW + (i >> 1), half = i & 1;
+                    const int soff = (((tt.n * ncm * 2 + oc0 * 2 + gp) * hp) + tt.y0 + half * 8) * wp + tt.x0;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_m, (lds_void*)(sm3 + gp * 512 + half * 256), 4, mvoff, soff, 0, 0);
+                });
+                return;
+            }
             const char* mk = d1 ? a.mask : a.mask2;
             if (mk == nullptr) return;
             const int ncm = d1 ? a.nco1 : (a.cout >> 4) - a.nco1, oc0 = d1 ? tt.cb * 4 : tt.cb * 4 - a.nco1;
@@ -567,7 +588,7 @@ _Pragma("unroll")
                     f32x4 vx[2], vy[2];
                     if constexpr (GRAD) {
                         const bool d1 = oc < a.nco1;                           // wave-uniform
-                        const bool masked = (d1 ? a.mask : a.mask2) != nullptr;
+                        const bool masked = d1 ? (a.mask != nullptr || a.mbits != nullptr) : (a.mask2 != nullptr || a.mbits2 != nullptr);
 #pragma unroll
                         for (int q = 0; q < 2; ++q) {
                             unsigned mx = 0xFu, my = 0xFu;
@@ -608,7 +629,7 @@ _Pragma("unroll")
                     }
                     // addresses = wave-uniform 64-bit base (image, output chunk) + 32-bit lane offset (pixel, plane): the stores take the
                     // SGPR-base form and the epilogue carries no 64-bit address registers (it sits at the 168-register step)
-                    auto store_px = [&](const f32x4& X, const f32x4& Y, char* base, uint32_t off, uint32_t plane_bytes, bool ok) __attribute__((always_inline)) {
+                    auto store_px = [&](const f32x4& X, const f32x4& Y, char* base, uint32_t off, uint32_t plane_bytes, bool ok, unsigned char* mdst = nullptr) __attribute__((always_inline)) {
                         uint32_t xh0, xh1, xlo, yh0, yh1, ylo;
                         wsu_split4_f16r8(X, GRAD ? WSU_F8_GLO_DIV : WSU_F8_XLO_DIV, xh0, xh1, xlo);
                         wsu_split4_f16r8(Y, GRAD ? WSU_F8_GLO_DIV : WSU_F8_XLO_DIV, yh0, yh1, ylo);
@@ -618,6 +639,9 @@ _Pragma("unroll")
                         if (ok) {
                             *reinterpret_cast<u32x4*>(base + off + hh * plane_bytes) = mk_u4(xh0, xh1, yh0, yh1);
                             if (!hh) *reinterpret_cast<u32x4*>(base + off + 2 * plane_bytes) = mk_u4(xlo, xlp, ylo, ylp);
+                            if constexpr (!GRAD && !HEAD && !POOL) {            // the training forward's ReLU-mask byte of this lane's granule
+                                if (mdst) *mdst = (unsigned char)wsu_f16x8_pos_bits(mk_u4(xh0, xh1, yh0, yh1));
+                            }
                         }
                     };
                     if constexpr (GRAD) {
@@ -635,23 +659,24 @@ _Pragma("unroll")
                         for (int q = 0; q < 2; ++q) {
                             const int row = cur.y0 + 2 * wv + q;
                             char* base = a.y + (((size_t)cur.n * nco + oc) * HBM_PLANES) * hw * 16;
-                            store_px(vx[q], vy[q], base, (uint32_t)(row * a.w + col) * 16u, (uint32_t)hw * 16u, row < a.h && col < a.w);
+                            unsigned char* mdst = nullptr;
+                            if constexpr (!GRAD && !HEAD && !POOL) {
+                                if (a.relu_mask_out)
+                                    mdst = a.relu_mask_out + (((size_t)cur.n * (nco * 2) + oc * 2 + hh) * wsu_mask_hp(a.h) + row) * wsu_mask_wp(a.w) + col;
+                            }
+                            store_px(vx[q], vy[q], base, (uint32_t)(row * a.w + col) * 16u, (uint32_t)hw * 16u, row < a.h && col < a.w, mdst);
                         }
                     }
                     if constexpr (POOL) {                                      // every lane takes part in the exchanges
                         f32x4 px, py;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {                           // window order (0,0) (0,1) (1,0) (1,1); max is order-free, NaN propagates
-                            const float x1 = dpp_xor1(vx[0][e]), x3 = dpp_xor1(vx[1][e]);      // the neighbouring column (lane ^ 1)
-                            const float y1 = dpp_xor1(vy[0][e]), y3 = dpp_xor1(vy[1][e]);
-                            float bxv = vx[0][e], byv = vy[0][e];
-                            if (x1 > bxv || x1 != x1) bxv = x1;
-                            if (vx[1][e] > bxv || vx[1][e] != vx[1][e]) bxv = vx[1][e];
-                            if (x3 > bxv || x3 != x3) bxv = x3;
-                            if (y1 > byv || y1 != y1) byv = y1;
-                            if (vy[1][e] > byv || vy[1][e] != vy[1][e]) byv = vy[1][e];
-                            if (y3 > byv || y3 != y3) byv = y3;
-                            px[e] = bxv; py[e] = byv;
+                        for (int e = 0; e < 4; ++e) {
+                            // 2x2 window = this lane's two rows x the lane pair (l, l ^ 1): one max down the column, one across the pair (the
+                            // neighbour arrives as a DPP operand).  Round 2 spent ~14 instructions per pooled value on a NaN-propagating
+                            // compare / select chain; values reaching this point went through v_max(x, floor), which never returns NaN
+                            // for floor = 0 (ReLU) -- with relu = 0 a NaN in one window element is dropped like IEEE maxNum drops it.
+                            const float cx = fmaxf(vx[0][e], vx[1][e]), cy = fmaxf(vy[0][e], vy[1][e]);
+                            px[e] = fmaxf(cx, dpp_xor1(cx)); py[e] = fmaxf(cy, dpp_xor1(cy));
                         }
                         const int hp = a.h >> 1, wp2 = a.w >> 1;
                         const int gy = (cur.y0 >> 1) + wv, gx = (cur.x0 >> 1) + (l31 >> 1);
@@ -747,6 +772,11 @@ int wsu_debug_read_pl_stamps(unsigned long long* host_dst, int nblocks) {
     return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_pl_stamps), (size_t)nblocks * 8 * sizeof(unsigned long long)) == hipSuccess ? 0 : -2;
 }
 
+size_t wsu_relu_mask_bytes(int n, int c, int h, int w) {
+    if (n <= 0 || c <= 0 || h <= 0 || w <= 0) return 0;
+    return (size_t)n * (size_t)((c + 7) / 8) * (size_t)wsu_mask_hp(h) * (size_t)wsu_mask_wp(w);
+}
+
 // Forward 3x3 reflect conv + bias + ReLU on planar F16F8P activations (layout: wsu.h).  x1 (c1 channels) and optional x2 (c2, fused
 // concat), packed weights of wsu_conv3x3_pack(mode F16F8); range_flag (optional device word): bit 0 is OR-ed in when a stored value leaves
 // the format's full-accuracy range; outputs, each optional: y (cout channels, planar), y_pool (2x2 max-pooled,
@@ -754,8 +784,11 @@ int wsu_debug_read_pl_stamps(unsigned long long* host_dst, int nblocks) {
 // cout of 64.  Asynchronous on `stream`; allocates nothing.
 int wsu_conv3x3_pl_fwd(const void* x1, const void* x2, const void* w_packed, const float* bias, void* y, void* y_pool,
                        const float* head_w, const float* head_b, float* head_out, float* head_logit, int head_cout,
-                       int n, int h, int w, int c1, int c2, int cout, int relu, int x_residual, unsigned* range_flag, void* stream) {
+                       int n, int h, int w, int c1, int c2, int cout, int relu, int x_residual, unsigned* range_flag,
+                       unsigned char* relu_mask_out, void* stream) {
     WSU_REQUIRE(x1 && w_packed && (y || y_pool || head_w), "conv3x3_pl: null pointer");
+    WSU_REQUIRE(!relu_mask_out || (y && !y_pool && !head_w && x_residual), "conv3x3_pl: relu_mask_out needs the plain variant (y only)");
+    WSU_REQUIRE(!relu_mask_out || (long long)n * (cout / 8) * wsu_mask_hp(h) * wsu_mask_wp(w) < 0x7FFFFFF0LL, "conv3x3_pl: mask plane too large");
     WSU_REQUIRE(n > 0 && h >= 2 && w >= 2, "conv3x3_pl: bad shape n=%d h=%d w=%d (reflect pad 1 needs h,w >= 2)", n, h, w);
     WSU_REQUIRE(c1 > 0 && c1 % 16 == 0 && c2 >= 0 && c2 % 16 == 0 && (c2 == 0) == (x2 == nullptr), "conv3x3_pl: c1=%d c2=%d must be multiples of 16", c1, c2);
     WSU_REQUIRE(cout > 0 && cout % WSU_COB == 0 && cout <= 1024, "conv3x3_pl: cout=%d must be a multiple of %d (<= 1024)", cout, WSU_COB);
@@ -777,6 +810,7 @@ int wsu_conv3x3_pl_fwd(const void* x1, const void* x2, const void* w_packed, con
     a.ntiles = (int)nt;
     a.img = nullptr; a.w1 = nullptr; a.b1 = nullptr;
     a.y2 = nullptr; a.nco1 = cout / 16; a.mask = nullptr; a.mask2 = nullptr; a.imgs_per_wset = 0; a.wset_bytes = 0;
+    a.relu_mask_out = relu_mask_out; a.mbits = nullptr; a.mbits2 = nullptr;
     return pl_launch(a, false, static_cast<hipStream_t>(stream));
 }
 
@@ -803,6 +837,7 @@ int wsu_conv3x3_pl_fused_first_fwd(const float* img, const float* w1, const floa
     WSU_REQUIRE(nt > 0 && nt < 0x3FFFFFFFLL, "conv3x3_pl_fused_first: %lld tiles out of range", nt);
     a.ntiles = (int)nt;
     a.y2 = nullptr; a.nco1 = cout / 16; a.mask = nullptr; a.mask2 = nullptr; a.imgs_per_wset = 0; a.wset_bytes = 0;
+    a.relu_mask_out = nullptr; a.mbits = nullptr; a.mbits2 = nullptr;
     return pl_launch(a, true, static_cast<hipStream_t>(stream));
 }
 
@@ -824,6 +859,7 @@ int wsu_ring_fold_pl(const void* strips_out, void* dx1, void* dx2, const void* m
 
 int wsu_conv3x3_pl_bwd_data(const void* g, const void* w_packed_dgrad, const void* w_packed_ring, void* workspace, size_t workspace_bytes,
                             void* dx1, void* dx2, int csplit, const void* mask1, const void* mask2,
+                            const unsigned char* mask1_bits, const unsigned char* mask2_bits,
                             int n, int h, int w, int cin, int cout, int pad_zero, void* stream) {
     WSU_REQUIRE(g && w_packed_dgrad && dx1, "conv3x3_pl_bwd_data: null pointer");
     WSU_REQUIRE(n > 0 && h >= 2 && w >= 2, "conv3x3_pl_bwd_data: bad shape n=%d h=%d w=%d", n, h, w);
@@ -831,6 +867,8 @@ int wsu_conv3x3_pl_bwd_data(const void* g, const void* w_packed_dgrad, const voi
     WSU_REQUIRE(cin > 0 && cin % WSU_COB == 0 && cin <= 1024, "conv3x3_pl_bwd_data: cin=%d must be a multiple of %d (<= 1024)", cin, WSU_COB);
     WSU_REQUIRE(csplit > 0 && csplit <= cin && csplit % WSU_COB == 0 && (csplit < cin) == (dx2 != nullptr), "conv3x3_pl_bwd_data: csplit=%d (cin=%d) must be a multiple of %d, dx2 given iff csplit < cin", csplit, cin, WSU_COB);
     WSU_REQUIRE(!mask2 || dx2, "conv3x3_pl_bwd_data: mask2 without dx2");
+    WSU_REQUIRE((!mask1_bits || mask1) && (!mask2_bits || mask2), "conv3x3_pl_bwd_data: the 1-bit masks come WITH the activations they were taken from (the border fold reads those)");
+    WSU_REQUIRE(!(mask1_bits || mask2_bits) || (long long)n * (cin / 8) * wsu_mask_hp(h) * wsu_mask_wp(w) < 0x7FFFFFF0LL, "conv3x3_pl_bwd_data: mask plane too large");
     WSU_REQUIRE((long long)h * w * 48 < 0xFFFFFFF0LL && (long long)n * ((h > w ? h : w) + 2) * 48 < 0xFFFFFFF0LL, "conv3x3_pl_bwd_data: h*w too large (a plane triple must stay below 4 GiB)");
     hipStream_t s = static_cast<hipStream_t>(stream);
     PlArgs a;
@@ -839,6 +877,7 @@ int wsu_conv3x3_pl_bwd_data(const void* g, const void* w_packed_dgrad, const voi
     a.head_w = nullptr; a.head_b = nullptr; a.head_out = nullptr; a.head_logit = nullptr; a.head_cout = 0;
     a.range_flag = nullptr; a.xres = 1; a.img = nullptr; a.w1 = nullptr; a.b1 = nullptr;
     a.imgs_per_wset = 0; a.wset_bytes = 0;
+    a.relu_mask_out = nullptr; a.mbits = mask1_bits; a.mbits2 = mask2_bits;
     a.n = n; a.h = h; a.w = w; a.c1 = cout; a.c2 = 0; a.cout = cin;
     a.tiles_x = (w + TW - 1) / TW; a.tiles_y = (h + TH - 1) / TH; a.ncb = cin / WSU_COB;
     a.nch1 = cout / 16; a.nch = cout / 16; a.relu = 0;
@@ -857,6 +896,7 @@ int wsu_conv3x3_pl_bwd_data(const void* g, const void* w_packed_dgrad, const voi
     if (rc) return rc;
     PlArgs r = a;
     r.x1 = strips_in; r.wp = (const char*)w_packed_ring; r.y = strips_out; r.y2 = nullptr; r.nco1 = cin / 16; r.mask = nullptr; r.mask2 = nullptr;
+    r.mbits = nullptr; r.mbits2 = nullptr;
     r.imgs_per_wset = 1; r.wset_bytes = (size_t)cin * cout * 9 * 4;
     r.n = 4; r.h = n; r.w = L + 2;
     r.tiles_x = (r.w + TW - 1) / TW; r.tiles_y = (r.h + TH - 1) / TH;

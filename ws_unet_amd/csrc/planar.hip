@@ -470,7 +470,7 @@ __global__ void pack_convt_dgrad_pl_kernel(const float* __restrict__ w, char* __
 // time from tap-major weights in LDS; fp32 FMAs in the tap order of conv3x3_first_kernel (pointwise.hip), so the values before encoding are
 // bitwise those of the NHWC first-layer kernel.  HBM-write bound: 4 bytes per output element.
 // =====================================================================================================================================
-struct FirstPlArgs { const float* x; const float* w; const float* b; char* y; unsigned* range_flag; int n, h, w_, cin, cout, relu; };
+struct FirstPlArgs { const float* x; const float* w; const float* b; char* y; unsigned* range_flag; int n, h, w_, cin, cout, relu; unsigned char* relu_mask_out; };
 
 __global__ __launch_bounds__(256) void first_pl_kernel(const FirstPlArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -530,6 +530,11 @@ __global__ __launch_bounds__(256) void first_pl_kernel(const FirstPlArgs a) {
             *reinterpret_cast<u32x4*>(dst) = mk_u4(h[0], h[1], h[2], h[3]);
             *reinterpret_cast<u32x4*>(dst + hw * 16) = mk_u4(h[4], h[5], h[6], h[7]);
             *reinterpret_cast<u32x4*>(dst + 2 * hw * 16) = mk_u4(lo[0], lo[1], lo[2], lo[3]);
+            if (a.relu_mask_out) {                                       // the training forward's 1-bit ReLU mask: one byte per (pixel, 8 channels)
+                unsigned char* m = a.relu_mask_out + (((size_t)img * (nco * 2) + oc * 2) * wsu_mask_hp(a.h) + y) * wsu_mask_wp(a.w_) + x;
+                m[0] = (unsigned char)wsu_f16x8_pos_bits(mk_u4(h[0], h[1], h[2], h[3]));
+                m[(size_t)wsu_mask_hp(a.h) * wsu_mask_wp(a.w_)] = (unsigned char)wsu_f16x8_pos_bits(mk_u4(h[4], h[5], h[6], h[7]));
+            }
         }
     }
     if (a.range_flag && !(vmax <= WSU_F8_RANGE)) atomicOr(a.range_flag, 1u);      // rare: at most one atomic per lane
@@ -609,10 +614,11 @@ int wsu_convt2x2_pl_bwd_data(const void* dy, const void* w_packed_dgrad, void* d
 
 // K0p: first layer into planar storage.  x_nchw: (N, cin, H, W) fp32, cin 1..8; w_oihw: (cout, cin, 3, 3); cout a multiple of 16 (<= 128).
 int wsu_conv3x3_first_pl_fwd(const float* x_nchw, const float* w_oihw, const float* bias, void* y, int n, int h, int w, int cin, int cout,
-                             int relu, unsigned* range_flag, void* stream) {
+                             int relu, unsigned* range_flag, unsigned char* relu_mask_out, void* stream) {
     WSU_REQUIRE(x_nchw && w_oihw && y, "conv3x3_first_pl: null pointer");
     WSU_REQUIRE(n > 0 && h >= 2 && w >= 2 && cin >= 1 && cin <= 8 && cout > 0 && cout % 16 == 0 && cout <= 128, "conv3x3_first_pl: bad shape");
-    FirstPlArgs a{x_nchw, w_oihw, bias, (char*)y, range_flag, n, h, w, cin, cout, relu};
+    WSU_REQUIRE(!relu_mask_out || (long long)n * (cout / 8) * wsu_mask_hp(h) * wsu_mask_wp(w) < 0x7FFFFFF0LL, "conv3x3_first_pl: mask plane too large");
+    FirstPlArgs a{x_nchw, w_oihw, bias, (char*)y, range_flag, n, h, w, cin, cout, relu, relu_mask_out};
     const long long total = (long long)n * h * w;
     const unsigned nblk = (unsigned)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
     const size_t lds = ((size_t)cin * 9 * cout + cout) * sizeof(float);

@@ -134,12 +134,11 @@ __global__ __launch_bounds__(256) void ring_fold_pl_kernel(const char* __restric
 
 // 8 channels of one pixel: f16 granule + its 8 residual bytes -> fp32; and back
 __device__ __forceinline__ void pl_decode8(const u32x4& h, const u32x2& r, float lo_mul, float (&v)[8]) {
-    const f16x8 a = __builtin_bit_cast(f16x8, h);
-    const int r0 = (int)r.x, r1 = (int)r.y;
-    v[0] = (float)a[0] + __builtin_amdgcn_cvt_f32_fp8(r0, 0) * lo_mul; v[1] = (float)a[1] + __builtin_amdgcn_cvt_f32_fp8(r0, 1) * lo_mul;
-    v[2] = (float)a[2] + __builtin_amdgcn_cvt_f32_fp8(r0, 2) * lo_mul; v[3] = (float)a[3] + __builtin_amdgcn_cvt_f32_fp8(r0, 3) * lo_mul;
-    v[4] = (float)a[4] + __builtin_amdgcn_cvt_f32_fp8(r1, 0) * lo_mul; v[5] = (float)a[5] + __builtin_amdgcn_cvt_f32_fp8(r1, 1) * lo_mul;
-    v[6] = (float)a[6] + __builtin_amdgcn_cvt_f32_fp8(r1, 2) * lo_mul; v[7] = (float)a[7] + __builtin_amdgcn_cvt_f32_fp8(r1, 3) * lo_mul;
+    const int r0 = (int)r.x, r1 = (int)r.y;                  // value = residual * lo_mul + f16 part: one v_cvt_f32_fp8 + one v_fma_mix_f32 per value
+    v[0] = wsu_fma_f16_lo(__builtin_amdgcn_cvt_f32_fp8(r0, 0), lo_mul, h.x); v[1] = wsu_fma_f16_hi(__builtin_amdgcn_cvt_f32_fp8(r0, 1), lo_mul, h.x);
+    v[2] = wsu_fma_f16_lo(__builtin_amdgcn_cvt_f32_fp8(r0, 2), lo_mul, h.y); v[3] = wsu_fma_f16_hi(__builtin_amdgcn_cvt_f32_fp8(r0, 3), lo_mul, h.y);
+    v[4] = wsu_fma_f16_lo(__builtin_amdgcn_cvt_f32_fp8(r1, 0), lo_mul, h.z); v[5] = wsu_fma_f16_hi(__builtin_amdgcn_cvt_f32_fp8(r1, 1), lo_mul, h.z);
+    v[6] = wsu_fma_f16_lo(__builtin_amdgcn_cvt_f32_fp8(r1, 2), lo_mul, h.w); v[7] = wsu_fma_f16_hi(__builtin_amdgcn_cvt_f32_fp8(r1, 3), lo_mul, h.w);
 }
 __device__ __forceinline__ void pl_encode8(const float (&v)[8], float div_lo, u32x4& h, u32x2& r) {
     uint32_t h0, h1, h2, h3, l0, l1;

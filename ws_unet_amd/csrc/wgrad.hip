@@ -693,7 +693,7 @@ static_assert(NPIECE % NLOAD == 0 && U_HH % 1024 == 0 && U_BH % 1024 == 0, "piec
 static_assert(LDS_TOTAL <= 160 * 1024, "LDS budget");
 }
 
-__device__ __attribute__((aligned(16))) unsigned g_wg_zero16[4];     // zeros for out-of-image U pixels
+
 
 typedef __attribute__((address_space(3))) void lds_void_w;
 typedef __attribute__((address_space(1))) const void glb_void_w;
@@ -741,6 +741,17 @@ __device__ __forceinline__ u32x4 wgr_frag8(const char* img, int row0) {
     return mk_u4((uint32_t)r0[0], (uint32_t)r0[1], (uint32_t)r1[0], (uint32_t)r1[1]);
 }
 
+typedef __attribute__((address_space(3))) char lds_char_w;
+constexpr unsigned WGR_OOB = 0xFFFFFFF0u;                             // beyond every descriptor below: the hardware range check returns zeros
+
+// Round 3: the loader's instruction stream.  Round 2 built a 64-bit source address per piece and step (tile origin, reflected column, row
+// select, inside-the-image test and a select between the address and a block of zeros): ~260 vector instructions per step and wave, issued
+// on the SIMD its three matrix waves need.  Now a piece is one `buffer_load_dwordx4 ... offen lds`:
+//   * U pieces: descriptor = the (image, 64-channel block)'s 12 planes, scalar offset = the tile's origin, per-lane offset = the unit's
+//     (chunk, plane, row, column) inside the tile -- computed ONCE per kernel; lanes beyond the tile's pixels carry an out-of-range offset
+//     and read zeros.  Only tiles that cross the image's right / bottom edge take a per-step select (wave-uniform branch).
+//   * V pieces: per-lane offset = unit (chunk, plane) + reflected column, recomputed when the walk enters a new tile column; the two rows of
+//     the pair differ by a scalar (+- one image row): one multiply-add per piece and step.
 template <int LW>
 __device__ __forceinline__ void wgr_loader(const WgPlArgs& a, char* smem, int lane, int split, int mb, int nb, int t0, int t1) {
     using namespace wgr;
@@ -748,15 +759,17 @@ __device__ __forceinline__ void wgr_loader(const WgPlArgs& a, char* smem, int la
     const char* vsrc; int cv, vch0;
     if (nb * 64 < a.cv1) { vsrc = a.v1; cv = a.cv1; vch0 = nb * 64; }
     else                 { vsrc = a.v2; cv = a.cv2; vch0 = nb * 64 - a.cv1; }
-    const size_t hw = (size_t)a.hu * a.wu;
+    const unsigned hw16 = (unsigned)(a.hu * a.wu) * 16u;
     const bool bias_on = a.bpart != nullptr && nb == 0;
     if (t0 >= t1) {                                                     // empty split: no barriers on either side; the partials it owns are zeros
         if (bias_on && L < 64) a.bpart[(size_t)split * (a.nmb * 64) + mb * 64 + L] = 0.f;
         return;
     }
-    // per piece k (p = LW + 4 k): the lane's unit -- alive or beyond the image's pixels --, the tile-independent part of its source address
-    // 16 * ((chunk * 3 + plane) * H * W [+ r * W + c for U]), its (row, column) inside the tile / row pair, and where its e4m3 copy goes
-    int coff[PER], rc[PER], c8off[PER];
+    lds_char_w* smem3 = (lds_char_w*)smem;
+    // per piece k (p = LW + 4 k), fixed for the kernel: the lane's unit -- alive or beyond the slot's pixels --, its (row, column) inside the
+    // tile / row pair, its offset 16 * ((chunk * 3 + plane) * H * W [+ r * W + c for U]) and where its e4m3 copy goes
+    unsigned uoff[PER];                                                 // U pieces: complete; V pieces: the (chunk, plane) part
+    int rc[PER], c8off[PER];
     unsigned alive = 0;
     WSU_STATIC_FOR(PER, k, {
         constexpr int p = LW + NLOAD * k, kd = wgr_kind(p), upr = (kd & 1) ? 2 : 4, npx = kd < 2 ? U_PIX : V_PIX, roww = kd < 2 ? TW : VW;
@@ -768,32 +781,62 @@ __device__ __forceinline__ void wgr_loader(const WgPlArgs& a, char* smem, int la
         const int chunk = (kd & 1) ? g : g >> 1, plane = (kd & 1) ? 2 : (g & 1);        // f16: unit = 2 chunk + plane; residual: unit = chunk
         const int r = pxl / roww, c = pxl - r * roww;
         rc[k] = r * 256 + c;
-        coff[k] = (int)((chunk * 3 + plane) * hw) * 16 + (kd < 2 ? (r * a.wu + c) * 16 : 0);
+        uoff[k] = (unsigned)(chunk * 3 + plane) * hw16 + (kd < 2 ? (unsigned)(r * a.wu + c) * 16u : 0u);
+        if (!(pxl < npx)) { uoff[k] = WGR_OOB; rc[k] = 0; }             // a dead lane stays out of range whatever is added per step (its row index is 0)
         c8off[k] = half * (kd < 2 ? U_BH : V_BH) + pxl * BROW + u * 8; // the 8 copies of an f16 unit inside the copy image
     });
+    unsigned vxoff[PER];                                                // V pieces: uoff + 16 * reflected column of the current tile column
+    int vx_tx = -1;
     auto issue = [&](const WgrWalk& w, int k_step) __attribute__((always_inline)) {
         const int y0 = w.ty * 2, x0 = w.tx * TW;
-        const char* ubase = a.u + ((size_t)w.n * (a.cu >> 4) + mb * 4) * 3 * hw * 16 + ((size_t)y0 * a.wu + x0) * 16;     // wave-uniform
-        const char* vbase = vsrc + ((size_t)w.n * (cv >> 4) + (vch0 >> 4)) * 3 * hw * 16;
+        const char* ubase = a.u + ((size_t)w.n * (a.cu >> 4) + mb * 4) * 3 * hw16;                 // wave-uniform
+        const char* vbase = vsrc + ((size_t)w.n * (cv >> 4) + (vch0 >> 4)) * 3 * hw16;
+        const auto rs_u = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(ubase), 0, (int)(12u * hw16), 0x00020000);
+        const auto rs_v = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(vbase), 0, (int)(12u * hw16), 0x00020000);
+        const int u_org = (y0 * a.wu + x0) * 16;                        // scalar offset of the tile's first pixel
         const int vy = w.pro ? y0 - 1 : y0 + 1;                         // first of the two padded rows this step brings
-        const int vrow0 = wsu_reflect(vy, a.hu) * a.wu * 16, vrow1 = wsu_reflect(vy + 1, a.hu) * a.wu * 16;
-        const int ulim = min(a.hu - y0, 2) * 256 + min(a.wu - x0, TW);  // U pixel (r, c) is inside the image iff r < ulim_y && c < ulim_x
-        char* us = smem + (k_step % NU) * U_SLOT;
-        char* vs = smem + V_BASE + (k_step % NV) * V_SLOT;
+        // the two rows of the pair are one image row apart, in either order (reflection at the top / bottom edge): the scalar offset carries the
+        // smaller one, the lanes of the other row add the (positive) distance -- a per-lane offset must never go below zero (it would wrap
+        // around 2^32 and the range check would turn the access into zeros)
+        const int vrA = wsu_reflect(vy, a.hu) * a.wu * 16, vrB = wsu_reflect(vy + 1, a.hu) * a.wu * 16;
+        const int vrow0 = min(vrA, vrB), dvrow = abs(vrB - vrA), rsel = vrB > vrA ? 1 : 0;                 // lanes with row index == rsel add dvrow
+        const int ulim_y = min(a.hu - y0, 2), ulim_x = min(a.wu - x0, TW);
+        const bool u_full = ulim_y == 2 && ulim_x == TW;               // wave-uniform: every U pixel of the tile is inside the image
+        if (vx_tx != w.tx) {                                            // a new tile column: the reflected columns of the V units
+            vx_tx = w.tx;
+            WSU_STATIC_FOR(PER, k, {
+                constexpr int p = LW + NLOAD * k, kd = wgr_kind(p);
+                if constexpr (kd >= 2) {
+                    const int xx = wsu_reflect(x0 - 1 + (rc[k] & 255), a.wu);
+                    vxoff[k] = (alive & (1u << k)) ? uoff[k] + (unsigned)xx * 16u : WGR_OOB;
+                } else {
+                    vxoff[k] = 0;
+                }
+            });
+        }
+        lds_char_w* us = smem3 + (k_step % NU) * U_SLOT;
+        lds_char_w* vs = smem3 + V_BASE + (k_step % NV) * V_SLOT;
         WSU_STATIC_FOR(PER, k, {
             constexpr int p = LW + NLOAD * k, kd = wgr_kind(p);
-            if (alive & (1u << k)) {
-                const char* src;
-                if constexpr (kd < 2) {                                 // (a prologue step fetches its tile's U too -- unused, it keeps the piece count constant)
-                    const bool inside = (rc[k] >> 8) < (ulim >> 8) && (rc[k] & 255) < (ulim & 255);
-                    src = inside ? ubase + coff[k] : reinterpret_cast<const char*>(g_wg_zero16);
-                } else {
-                    const int xx = wsu_reflect(x0 - 1 + (rc[k] & 255), a.wu);
-                    src = vbase + (coff[k] + ((rc[k] >> 8) ? vrow1 : vrow0) + xx * 16);
+            // every piece has live lanes (static layout): a wave issues exactly PER DMA instructions per step -- the vmcnt arithmetic below
+            if constexpr (kd < 2) {                                     // (a prologue step fetches its tile's U too -- unused, it keeps the piece count constant)
+                unsigned vo = uoff[k];
+                if (!u_full) {
+                    const bool inside = (rc[k] >> 8) < ulim_y && (rc[k] & 255) < ulim_x;
+                    vo = inside ? vo : WGR_OOB;
                 }
-                char* dst = (kd < 2 ? us : vs) + wgr_piece_off(p);
-                __builtin_amdgcn_global_load_lds((glb_void_w*)src, (lds_void_w*)dst, 16, 0, 0);
-            }           // every piece has live lanes (static layout): a wave issues exactly PER DMA instructions per step -- the vmcnt arithmetic below
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_u, (lds_void_w*)(us + wgr_piece_off(p)), 16, vo, u_org, 0, 0);
+            } else {
+                const unsigned v2 = vxoff[k] + ((rc[k] >> 8) == rsel ? (unsigned)dvrow : 0u);
+                // the last piece of a V half-image is only partly alive (68 pixels): its dead lanes must not write -- their LDS bytes belong
+                // to the next half-image
+                constexpr int upr = (kd & 1) ? 2 : 4, pih = wgr_pidx(p) % wgr_pph(kd), live = V_PIX * upr - pih * 64;
+                if constexpr (live < 64) {
+                    if (lane < live) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_v, (lds_void_w*)(vs + wgr_piece_off(p)), 16, v2, vrow0, 0, 0);
+                } else {
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_v, (lds_void_w*)(vs + wgr_piece_off(p)), 16, v2, vrow0, 0, 0);
+                }
+            }
         });
     };
     // e4m3 copies of the f16 units this lane fetched for step k_step (its own 16 bytes, landed: vmcnt)
@@ -820,13 +863,14 @@ __device__ __forceinline__ void wgr_loader(const WgPlArgs& a, char* smem, int la
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int p = (L & 31) + 32 * k;
-            const f16x8 hv8 = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(us + U_HI + (cg >> 2) * U_HH + p * HROW + (cg & 3) * 16));
+            const u32x4 hq = *reinterpret_cast<const u32x4*>(us + U_HI + (cg >> 2) * U_HH + p * HROW + (cg & 3) * 16);
             const u32x2 rr = *reinterpret_cast<const u32x2*>(us + U_L8 + (cg >> 2) * U_BH + p * BROW + (cg & 3) * 8);
             const int r0 = (int)rr.x, r1 = (int)rr.y;
-            bs[0] += (float)hv8[0] + __builtin_amdgcn_cvt_f32_fp8(r0, 0) * WSU_F8_GLO_DIV; bs[1] += (float)hv8[1] + __builtin_amdgcn_cvt_f32_fp8(r0, 1) * WSU_F8_GLO_DIV;
-            bs[2] += (float)hv8[2] + __builtin_amdgcn_cvt_f32_fp8(r0, 2) * WSU_F8_GLO_DIV; bs[3] += (float)hv8[3] + __builtin_amdgcn_cvt_f32_fp8(r0, 3) * WSU_F8_GLO_DIV;
-            bs[4] += (float)hv8[4] + __builtin_amdgcn_cvt_f32_fp8(r1, 0) * WSU_F8_GLO_DIV; bs[5] += (float)hv8[5] + __builtin_amdgcn_cvt_f32_fp8(r1, 1) * WSU_F8_GLO_DIV;
-            bs[6] += (float)hv8[6] + __builtin_amdgcn_cvt_f32_fp8(r1, 2) * WSU_F8_GLO_DIV; bs[7] += (float)hv8[7] + __builtin_amdgcn_cvt_f32_fp8(r1, 3) * WSU_F8_GLO_DIV;
+            // sum += f16 part (v_fma_mix_f32 reads the half directly) + residual * 2^-14: three instructions per value
+            bs[0] = fmaf(__builtin_amdgcn_cvt_f32_fp8(r0, 0), WSU_F8_GLO_DIV, wsu_add_f16_lo(bs[0], hq.x)); bs[1] = fmaf(__builtin_amdgcn_cvt_f32_fp8(r0, 1), WSU_F8_GLO_DIV, wsu_add_f16_hi(bs[1], hq.x));
+            bs[2] = fmaf(__builtin_amdgcn_cvt_f32_fp8(r0, 2), WSU_F8_GLO_DIV, wsu_add_f16_lo(bs[2], hq.y)); bs[3] = fmaf(__builtin_amdgcn_cvt_f32_fp8(r0, 3), WSU_F8_GLO_DIV, wsu_add_f16_hi(bs[3], hq.y));
+            bs[4] = fmaf(__builtin_amdgcn_cvt_f32_fp8(r1, 0), WSU_F8_GLO_DIV, wsu_add_f16_lo(bs[4], hq.z)); bs[5] = fmaf(__builtin_amdgcn_cvt_f32_fp8(r1, 1), WSU_F8_GLO_DIV, wsu_add_f16_hi(bs[5], hq.z));
+            bs[6] = fmaf(__builtin_amdgcn_cvt_f32_fp8(r1, 2), WSU_F8_GLO_DIV, wsu_add_f16_lo(bs[6], hq.w)); bs[7] = fmaf(__builtin_amdgcn_cvt_f32_fp8(r1, 3), WSU_F8_GLO_DIV, wsu_add_f16_hi(bs[7], hq.w));
         }
     };
     // Every existing step k gets exactly one barrier k on both sides, plus two closing barriers: S + 2 barriers per wave (S >= 2).
@@ -1142,6 +1186,7 @@ int wsu_conv3x3_pl_bwd_weight(const void* g, const void* x1, const void* x2, flo
     WSU_REQUIRE(n > 0 && h >= 2 && w >= 2, "conv3x3_pl_bwd_weight: bad shape");
     WSU_REQUIRE(c1 > 0 && c1 % 64 == 0 && c2 >= 0 && c2 % 64 == 0 && (c2 == 0) == (x2 == nullptr), "conv3x3_pl_bwd_weight: c1=%d c2=%d must be multiples of 64", c1, c2);
     WSU_REQUIRE(cout > 0 && cout % 64 == 0, "conv3x3_pl_bwd_weight: cout=%d must be a multiple of 64", cout);
+    WSU_REQUIRE((long long)h * w * 192 < 0xFFFFFFF0LL, "conv3x3_pl_bwd_weight: h*w too large (the 12 planes of a 64-channel block must stay below 4 GiB)");
     WgPlArgs a{};
     a.u = (const char*)g; a.v1 = (const char*)x1; a.v2 = (const char*)x2; a.n = n; a.hu = h; a.wu = w; a.cu = cout; a.cv1 = c1; a.cv2 = c2;
     return run_wgrad_pl<0>(a, dw, db, workspace, workspace_bytes, static_cast<hipStream_t>(stream));

@@ -109,6 +109,36 @@ __device__ __forceinline__ float wsu_sub_f16_lo(float v, uint32_t hpair) {
 __device__ __forceinline__ float wsu_sub_f16_hi(float v, uint32_t hpair) {
     float r; asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hpair), "v"(v)); return r;
 }
+// a * b + float(f16 half of `hpair`) in one instruction (decoding a stored value: residual * 2^-k + f16 part; bitwise fmaf(a, b, float(h)))
+__device__ __forceinline__ float wsu_fma_f16_lo(float a, float b, uint32_t hpair) {
+    float r; asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[0,0,1]" : "=v"(r) : "v"(a), "v"(b), "v"(hpair)); return r;
+}
+__device__ __forceinline__ float wsu_fma_f16_hi(float a, float b, uint32_t hpair) {
+    float r; asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(a), "v"(b), "v"(hpair)); return r;
+}
+// 8 stored f16 values (one 16-byte granule) -> 8 bits "value > 0" (bit e = channel e of the granule): the ReLU-mask byte of the planar
+// training path (include/wsu.h, relu_mask planes).  f16 > 0 <=> its 16 bits > 0 as a signed integer (-0, NaN with the sign bit: not positive).
+__device__ __forceinline__ unsigned wsu_f16x8_pos_bits(const u32x4& h) {
+    unsigned bits = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int wd = (int)h[e];
+        bits |= ((short)(wd & 0xFFFF) > 0 ? 1u : 0u) << (2 * e);
+        bits |= (wd >= 0x10000 ? 1u : 0u) << (2 * e + 1);
+    }
+    return bits;
+}
+// geometry of a ReLU-mask plane: rows padded to 32 pixels, row count to 16 (a tile of the persistent conv is 16 x 32: its mask rows are whole,
+// aligned 32-byte runs that the data gradient's loaders bring in by LDS-DMA)
+__host__ __device__ inline int wsu_mask_wp(int w) { return (w + 31) & ~31; }
+__host__ __device__ inline int wsu_mask_hp(int h) { return (h + 15) & ~15; }
+// acc + float(f16 half) in one instruction (running sums over stored values)
+__device__ __forceinline__ float wsu_add_f16_lo(float acc, uint32_t hpair) {
+    float r; asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hpair), "v"(acc)); return r;
+}
+__device__ __forceinline__ float wsu_add_f16_hi(float acc, uint32_t hpair) {
+    float r; asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hpair), "v"(acc)); return r;
+}
 // 4 values -> 2 dwords of f16 (round to nearest even), 1 dword of residuals, 1 dword of e4m3 copies: 5.5 VALU instructions per value
 // (v_cvt_pk_f16_f32, widen + subtract, two v_med3 -- the fp8 conversions overflow to NaN instead of saturating, also with
 // MODE.FP16_OVFL set (tools/split_probe.hip) -- and the scaling conversions).  |v| > 65504 overflows the f16 part like any f16 pipeline.

@@ -72,12 +72,16 @@ def _forward_train_pl(model, x: torch.Tensor) -> Dict[str, torch.Tensor]:
     e11 = model.e11
     rf = model._range_flag_tensor(x.device)         # OR-ed by every epilogue that stores an activation beyond +-448 (UNet.range_exceeded)
     head = dict(head_w=model.outconv.weight.detach(), head_b=model.outconv.bias.detach())
-    cur = t["xe11"] = ops.conv3x3_first_pl(x, e11.weight, e11.bias.detach(), range_flag=rf)
+    # 1-bit ReLU masks (relu_mask planes, include/wsu.h) of every activation whose mask a data gradient applies: written by the producing
+    # kernel's epilogue, read by the consumer's loaders by LDS-DMA (1/8 byte per element instead of 2)
+    cur, t["m_xe11"] = ops.conv3x3_first_pl(x, e11.weight, e11.bias.detach(), range_flag=rf, want_mask=True)
+    t["xe11"] = cur
     for lvl in range(model.nsteps + 1):
         a, b = ENC[lvl]
         if lvl >= 1:
             la = getattr(model, a)
-            cur = t["x" + a] = ops.conv3x3_pl(cur, None, model._packed(a, W, "conv"), la.bias.detach(), la.out_channels, range_flag=rf)
+            cur, t["m_x" + a] = ops.conv3x3_pl(cur, None, model._packed(a, W, "conv"), la.bias.detach(), la.out_channels, range_flag=rf, want_mask=True)
+            t["x" + a] = cur
         lb = getattr(model, b)
         if lvl < model.nsteps:
             t["x" + b], cur = ops.conv3x3_pl(cur, None, model._packed(b, W, "conv"), lb.bias.detach(), lb.out_channels, pool=True, range_flag=rf)
@@ -91,7 +95,8 @@ def _forward_train_pl(model, x: torch.Tensor) -> Dict[str, torch.Tensor]:
         up, c1, c2 = dec_names(depth)
         lu, l1, l2 = getattr(model, up), getattr(model, c1), getattr(model, c2)
         xu = t["xu" + up[-1]] = ops.convt2x2_pl(cur, model._packed(up, W, "convt"), lu.bias.detach(), lu.out_channels, range_flag=rf)
-        cur = t["x" + c1] = ops.conv3x3_pl(xu, t["x" + ENC[depth - 1][1]], model._packed(c1, W, "conv"), l1.bias.detach(), l1.out_channels, range_flag=rf)
+        cur, t["m_x" + c1] = ops.conv3x3_pl(xu, t["x" + ENC[depth - 1][1]], model._packed(c1, W, "conv"), l1.bias.detach(), l1.out_channels, range_flag=rf, want_mask=True)
+        t["x" + c1] = cur
         if depth == 1:
             t["out"], cur = ops.conv3x3_pl(cur, None, model._packed(c2, W, "conv"), l2.bias.detach(), l2.out_channels, range_flag=rf, **head)
             t["x" + c2] = cur
@@ -109,20 +114,20 @@ def _backward_pl(model, t: Dict[str, torch.Tensor], x: torch.Tensor, dout: torch
     scale = ops.pow2_grad_scale(dout)
     dout = ops.scale_by(dout, scale[0:1])
 
-    def conv_bwd(name, g, x1, x2, mask1, need_dx=True):
+    def conv_bwd(name, g, x1, x2, mask1, need_dx=True, mask1_bits=None):
         layer = getattr(model, name)
         grads[name + ".weight"], grads[name + ".bias"] = ops.conv3x3_pl_bwd_weight(g, x1, x2)
         if not need_dx:
             return None, None
         return ops.conv3x3_pl_bwd_data(g, model._packed(name, W, "dgrad"), model._packed(name, W, "ring"), layer.in_channels,
-                                       x1.shape[1] * 16, mask1, None)
+                                       x1.shape[1] * 16, mask1, None, mask1_bits=mask1_bits)
 
     g, grads["outconv.weight"], grads["outconv.bias"] = ops.conv1x1_sigmoid_pl_bwd(t["last"], model.outconv.weight, t["out"], dout)
     skip_g: Dict[int, torch.Tensor] = {}
     for depth in range(1, model.nsteps + 1):
         up, c1, c2 = dec_names(depth)
         xc1, xu, skip = t["x" + c1], t["xu" + up[-1]], t["x" + ENC[depth - 1][1]]
-        g, _ = conv_bwd(c2, g, xc1, None, xc1)
+        g, _ = conv_bwd(c2, g, xc1, None, xc1, mask1_bits=t.get("m_x" + c1))
         dxu, skip_g[depth] = conv_bwd(c1, g, xu, skip, None)              # neither half is masked here: the upconv output has no ReLU, the skip's
         below = t["x" + (dec_names(depth + 1)[2] if depth < model.nsteps else ENC[model.nsteps][1])]    # mask meets the pool routing below
         lu = getattr(model, up)
@@ -133,7 +138,7 @@ def _backward_pl(model, t: Dict[str, torch.Tensor], x: torch.Tensor, dout: torch
         if lvl < model.nsteps:
             g = ops.maxpool2x2_pl_bwd(skip_g[lvl + 1], g, t["x" + b])
         xa = t["x" + a]
-        g, _ = conv_bwd(b, g, xa, None, xa)
+        g, _ = conv_bwd(b, g, xa, None, xa, mask1_bits=t.get("m_x" + a))
         if lvl == 0:
             grads[a + ".weight"], grads[a + ".bias"] = ops.conv3x3_first_pl_bwd_weight(g, x)
         else:

@@ -259,7 +259,7 @@ def planar_shape(n: int, c: int, h: int, w: int):
 def conv3x3_pl(x1: torch.Tensor, x2: Optional[torch.Tensor], w_packed: torch.Tensor, bias: Optional[torch.Tensor], cout: int,
                relu: bool = True, pool: bool = False, want_y: bool = True,
                head_w: Optional[torch.Tensor] = None, head_b: Optional[torch.Tensor] = None, want_logit: bool = False,
-               range_flag: Optional[torch.Tensor] = None, x_residual: bool = True):
+               range_flag: Optional[torch.Tensor] = None, x_residual: bool = True, want_mask: bool = False):
     """3x3 reflect conv (+ReLU, +2x2 max-pool, +1x1 head and sigmoid) on planar F16F8P activations (wsu_conv3x3_pl_fwd).
     x1 / x2: planar tensors (N, C/16, 4, H, W, 4); w_packed from pack_conv3x3(mode f16f8).  Returns y [, y_pool] or, with head_w,
     out [, logit][, y]."""
@@ -278,6 +278,7 @@ def conv3x3_pl(x1: torch.Tensor, x2: Optional[torch.Tensor], w_packed: torch.Ten
     hc = 0 if hw2 is None else hw2.shape[0]
     out = torch.empty((n, hc, h, w), dtype=torch.float32, device=x1.device) if hc else None
     logit = torch.empty_like(out) if (hc and want_logit) else None
+    mask = relu_mask_alloc(n, cout, h, w, x1.device) if want_mask else None      # 1-bit ReLU mask of y for the next conv's data gradient (training)
     act = n * h * w * ((c1 + c2) + (cout if want_y else 0)) + (n * (h // 2) * (w // 2) * cout if pool else 0)     # planar elements read + written
     meta = {"flops": 2.0 * 9 * (c1 + c2) * cout * n * h * w,
             "bytes": float(act * 3 + n * h * w * hc * 4 + 9 * (c1 + c2) * cout * 4),
@@ -286,10 +287,12 @@ def conv3x3_pl(x1: torch.Tensor, x2: Optional[torch.Tensor], w_packed: torch.Ten
             "tiles": n * ((h + 15) // 16) * ((w + 31) // 32) * (cout // 64), "steps_per_tile": (c1 + c2) // 16}
     check(_launch("conv3x3_pl", meta, lambda: lib.wsu_conv3x3_pl_fwd(
         x1.data_ptr(), _ptr(x2), w_packed.data_ptr(), _ptr(bias), _ptr(y), _ptr(yp), _ptr(hw2), _ptr(head_b), _ptr(out), _ptr(logit), hc,
-        n, h, w, c1, c2, cout, int(relu), int(x_residual), _ptr(range_flag), _stream())), "wsu_conv3x3_pl_fwd")
+        n, h, w, c1, c2, cout, int(relu), int(x_residual), _ptr(range_flag), _ptr(mask), _stream())), "wsu_conv3x3_pl_fwd")
     if hc:
         res = [out] + ([logit] if want_logit else []) + ([y] if want_y else [])
         return res[0] if len(res) == 1 else tuple(res)
+    if want_mask:
+        return y, mask
     return (y, yp) if pool else y
 
 
@@ -331,9 +334,15 @@ def convt2x2_pl(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Te
     return y
 
 
+def relu_mask_alloc(n: int, c: int, h: int, w: int, device) -> torch.Tensor:
+    """A relu_mask plane (include/wsu.h): uint8 (N, C/8, 16 * ceil(h / 16), 32 * ceil(w / 32)); rows / columns beyond the image are padding
+    that nothing reads as a mask of a stored pixel -- zeroed so that the allocation is deterministic."""
+    return torch.zeros((n, c // 8, (h + 15) // 16 * 16, (w + 31) // 32 * 32), dtype=torch.uint8, device=device)
+
+
 def conv3x3_first_pl(x_nchw: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], relu: bool = True,
-                     range_flag: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """First layer (N, cin <= 8, H, W) fp32 -> planar F16F8P tensor with w.shape[0] channels (wsu_conv3x3_first_pl_fwd)."""
+                     range_flag: Optional[torch.Tensor] = None, want_mask: bool = False):
+    """First layer (N, cin <= 8, H, W) fp32 -> planar F16F8P tensor with w.shape[0] channels (wsu_conv3x3_first_pl_fwd) [, its relu_mask plane]."""
     lib = _lib.load()
     w = w.detach().contiguous()
     _dev_check(x_nchw, w, bias)
@@ -341,10 +350,11 @@ def conv3x3_first_pl(x_nchw: torch.Tensor, w: torch.Tensor, bias: Optional[torch
     cout = w.shape[0]
     assert x_nchw.dtype == torch.float32 and x_nchw.is_contiguous() and w.shape[1] == cin
     y = torch.empty(planar_shape(n, cout, h, wd), dtype=torch.float32, device=x_nchw.device)
+    mask = relu_mask_alloc(n, cout, h, wd, x_nchw.device) if want_mask else None
     meta = {"flops": 2.0 * 9 * cin * cout * n * h * wd, "bytes": float(n * h * wd * (cin * 4 + cout * 3)), "bytes_2B": float(n * h * wd * (cin * 4 + cout * 2))}
     check(_launch("conv3x3_first_pl", meta, lambda: lib.wsu_conv3x3_first_pl_fwd(
-        x_nchw.data_ptr(), w.data_ptr(), _ptr(bias), y.data_ptr(), n, h, wd, cin, cout, int(relu), _ptr(range_flag), _stream())), "wsu_conv3x3_first_pl_fwd")
-    return y
+        x_nchw.data_ptr(), w.data_ptr(), _ptr(bias), y.data_ptr(), n, h, wd, cin, cout, int(relu), _ptr(range_flag), _ptr(mask), _stream())), "wsu_conv3x3_first_pl_fwd")
+    return (y, mask) if want_mask else y
 
 
 def pack_conv3x3_ring(w: torch.Tensor) -> torch.Tensor:
@@ -359,13 +369,16 @@ def pack_conv3x3_ring(w: torch.Tensor) -> torch.Tensor:
 
 
 def conv3x3_pl_bwd_data(g: torch.Tensor, w_packed_dgrad: torch.Tensor, w_packed_ring: Optional[torch.Tensor], cin: int, csplit: int,
-                        mask1: Optional[torch.Tensor] = None, mask2: Optional[torch.Tensor] = None, pad_zero: bool = False):
+                        mask1: Optional[torch.Tensor] = None, mask2: Optional[torch.Tensor] = None, pad_zero: bool = False,
+                        mask1_bits: Optional[torch.Tensor] = None, mask2_bits: Optional[torch.Tensor] = None):
     """Data gradient of the 3x3 conv on planar tensors (wsu_conv3x3_pl_bwd_data).  g: planar gradient (N, Cout/16, 3, H, W, 4); returns
     dx1 (csplit channels) and dx2 (cin - csplit channels, or None), planar gradients."""
     lib = _lib.load()
-    _dev_check(g, w_packed_dgrad, w_packed_ring, mask1, mask2)
+    _dev_check(g, w_packed_dgrad, w_packed_ring, mask1, mask2, mask1_bits, mask2_bits)
     assert g.dtype == torch.float32 and g.dim() == 6 and g.shape[2] == PLANAR_PLANES and g.is_contiguous()
     n, nch, _, h, w, _ = g.shape
+    for mb, cm in ((mask1_bits, csplit), (mask2_bits, cin - csplit)):
+        assert mb is None or (mb.dtype == torch.uint8 and mb.is_contiguous() and tuple(mb.shape) == (n, cm // 8, (h + 15) // 16 * 16, (w + 31) // 32 * 32)), "relu_mask plane shape"
     cout = nch * 16
     dx1 = torch.empty(planar_shape(n, csplit, h, w), dtype=torch.float32, device=g.device)
     dx2 = torch.empty(planar_shape(n, cin - csplit, h, w), dtype=torch.float32, device=g.device) if csplit < cin else None
@@ -374,7 +387,8 @@ def conv3x3_pl_bwd_data(g: torch.Tensor, w_packed_dgrad: torch.Tensor, w_packed_
     meta = {"flops": 2.0 * 9 * cin * cout * n * h * w, "bytes": float(n * h * w * (cin * 5 + cout * 3))}
     check(_launch("conv3x3_pl_bwd_data", meta, lambda: lib.wsu_conv3x3_pl_bwd_data(
         g.data_ptr(), w_packed_dgrad.data_ptr(), _ptr(w_packed_ring), _ptr(ws), 0 if ws is None else ws.numel() * 4,
-        dx1.data_ptr(), _ptr(dx2), csplit, _ptr(mask1), _ptr(mask2), n, h, w, cin, cout, int(pad_zero), _stream())), "wsu_conv3x3_pl_bwd_data")
+        dx1.data_ptr(), _ptr(dx2), csplit, _ptr(mask1), _ptr(mask2), _ptr(mask1_bits), _ptr(mask2_bits), n, h, w, cin, cout, int(pad_zero),
+        _stream())), "wsu_conv3x3_pl_bwd_data")
     return dx1, dx2
 
 
