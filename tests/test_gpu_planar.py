@@ -244,3 +244,29 @@ def test_unet_planar_with_fused_first_layer():
         big.invalidate_packed()
         big(x.to(DEV))
     assert big.mode == "bf16x3s"
+
+
+def test_small_grid_split_equals_the_unsplit_kernel():
+    """Round 3: a plain conv with fewer tiles than half the CUs runs as half-blocks of 32 output channels (kernel variant MSPLIT, csrc/
+    conv3x3_pl.hip) -- most shapes of this file do.  The unsplit kernel on the same shapes (WSU_PL_MSPLIT=0, read once per process: a fresh
+    interpreter) must pass the same oracle tests, and both must return bitwise the same planes (same arithmetic, same accumulation order)."""
+    import os, subprocess, sys
+    from pathlib import Path
+    here = Path(__file__).resolve().parent
+    env = dict(os.environ, WSU_PL_MSPLIT="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", str(here / "test_gpu_planar.py"), "-q", "-x", "-k", "matches_oracle or fused_head_and_no_relu or one_cross_term"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    code = ("import sys, torch; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "from gpu_util import planar_encode, rand_act\nfrom ws_unet_amd import ops, formula\n"
+            "x = planar_encode(rand_act((1, 128, 32, 64), 'ms/x'))\n"
+            "w = torch.from_numpy(formula.formula_tensor('ms/w', (256, 128, 3, 3), 0.04)).cuda(); b = torch.zeros(256, device='cuda')\n"
+            "y = ops.conv3x3_pl(x, None, ops.pack_conv3x3(w, ops.mode_id('f16f8')), b, 256)\n"
+            "torch.cuda.synchronize(); torch.save(y.cpu(), sys.argv[1])\n") % (str(here.parent), str(here))
+    outs = []
+    for flag in ("1", "0"):
+        out = str(here / f".msplit_{flag}.pt")
+        rr = subprocess.run([sys.executable, "-c", code, out], env=dict(os.environ, WSU_PL_MSPLIT=flag), capture_output=True, text=True, timeout=300)
+        assert rr.returncode == 0, rr.stderr[-2000:]
+        outs.append(torch.load(out, weights_only=True)); os.remove(out)
+    assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32))       # 8 tiles x 4 blocks = 32 items -> 64 half-items when split

@@ -15,5 +15,5 @@ echo "fwd pass 2 done"
 timeout -k 10 300 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_VALU_MFMA_MOPS_F8 GRBM_GUI_ACTIVE -d $O/train1 -o train --output-format csv -- python3 $R/tools/bench_train.py --batch 64 --steps 2 > $O/train1.log 2>&1 || { tail -5 $O/train1.log; echo "train pass failed"; }
 echo "train pass done"
 cd $R
-python3 tools/pmc_sq.py $O > $O/summary.md 2>&1 || echo "summary failed"
+python3 tools/pmc_sq.py $O --json $O/sq_counters.json > $O/summary.md 2>&1 || echo "summary failed"
 cat $O/summary.md | head -60

@@ -69,11 +69,12 @@ struct PlArgs {
     // receives one byte per stored (pixel, 8-channel granule).  GRAD: mbits / mbits2 (optional) replace `mask` / `mask2` -- the loaders bring
     // the tile's 8 granule planes x 512 bytes in by LDS-DMA instead of re-reading 2 bytes per element of the producing layer's f16 planes.
     unsigned char* relu_mask_out; const unsigned char* mbits; const unsigned char* mbits2;
+    int msplit;                                           // 1: work items are half-blocks of 32 output channels (kernel variant MSPLIT); ncb = 2 * cout / 64
 };
 
 __device__ __attribute__((aligned(16))) unsigned g_zero16[4];   // source of the zero-padding DMA pieces of the GRAD variant
 
-struct Tile { int n, y0, x0, cb; };
+struct Tile { int n, y0, x0, cb, mh; };                   // mh: the 32-channel half of block cb this item computes (kernel variant MSPLIT), else 0
 
 // Diagnostic stamps (only in the -DWSU_PL_STAMPS build): per workgroup the accumulated shader cycles of each phase of the chunk loop and
 // the s_memrealtime span, read back with wsu_debug_read_pl_stamps().  Values go to a buffer nothing else reads.
@@ -85,6 +86,8 @@ __device__ __forceinline__ Tile tile_of(const PlArgs& a, int t) {
     const int tx = t % a.tiles_x; t /= a.tiles_x;
     const int ty = t % a.tiles_y;
     r.n = t / a.tiles_y; r.y0 = ty * TH; r.x0 = tx * TW;
+    r.mh = 0;
+    if (a.msplit) { r.mh = r.cb & 1; r.cb >>= 1; }         // a.ncb counts half-blocks then
     return r;
 }
 
@@ -386,7 +389,10 @@ __device__ __attribute__((noinline)) void pl_loader_outlined(const PlArgs& a, ch
 // transposed / flipped weights (wsu_conv3x3_pack_dgrad) -- zero padding, the gradient's e4m3 scalings, no bias / ReLU, the ReLU mask of
 // the producing layer applied from a bit image that the loader waves build in LDS from that layer's stored f16 planes.  The reflect
 // adjoint's border ring is added by the caller (train_pl.hip).
-template <int HC, bool POOL, bool XRES = true, bool F1 = false, bool GRAD = false>   // HC = head planes compiled in: 0 (no head), 1 (the reference's single output plane) or 4 (1..4)
+// MSPLIT (round 3, small grids): a work item is HALF a tile's output channels (32 of the 64: m-half = item & 1 -- each matrix wave keeps 2
+// instead of 4 accumulator tiles), so a layer with fewer tiles than CUs (e31 / e32 of unet_2 at batch 1: 128 tiles) occupies twice as many
+// CUs with half the matrix work per step each; the input tile and the whole 64-channel weight slice are fetched as before.
+template <int HC, bool POOL, bool XRES = true, bool F1 = false, bool GRAD = false, bool MSPLIT = false>   // HC = head planes compiled in: 0 (no head), 1 (the reference's single output plane) or 4 (1..4)
 __global__ __launch_bounds__(NT) void conv3x3_pl_kernel(const PlArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -453,7 +459,9 @@ __global__ __launch_bounds__(NT) void conv3x3_pl_kernel(const PlArgs a) {
     __builtin_amdgcn_s_setprio(WSU_PL_MATRIX_PRIO);                           // experiment: matrix waves above the loader wave of their SIMD
 #endif
     Tile cur = tile_of(a, lw);
-    f32x16 acc[2][2];
+    constexpr int MH = MSPLIT ? 1 : 2;                                        // accumulator tiles along the output channels
+    f32x16 acc[2][2];                                                         // [MH][2] used (declared with the template-dependent bound, hipcc (ROCm 7.2)
+                                                                              // silently emits no host stub for ANY instantiation of the kernel)
     const int sc_a = hh ? WSU_F8_SCALE_WLO : WSU_F8_SCALE_W;
     const int sc_b = GRAD ? (hh ? WSU_F8_SCALE_G : WSU_F8_SCALE_GLO) : (hh ? WSU_F8_SCALE_X : WSU_F8_SCALE_XLO);
     int c = 0, kt = 0;                                                        // chunk inside the tile, tile counter
@@ -468,14 +476,14 @@ __global__ __launch_bounds__(NT) void conv3x3_pl_kernel(const PlArgs a) {
         STAMP(s3);
         if (c == 0) {
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+            for (int m = 0; m < MH; ++m)
 #pragma unroll
                 for (int q = 0; q < 2; ++q)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[m][q][r] = 0.f;
         }
         // ---- matrix section: identical arithmetic (and accumulation order) to conv3x3_kernel<F16F8> -----------------------------
-        const char* ldsA = st + LDS_IN + l31 * 16;                            // + ((tap*4 + g)*64 + m*32)*16
+        const char* ldsA = st + LDS_IN + (cur.mh * 32 + l31) * 16;            // + ((tap*4 + g)*64 + m*32)*16
         const char* ldsB = st + ((2 * wv) * IW + l31) * 16;                   // + g*PLANE + ((q+dy)*IW + dx)*16
         auto cross = [&](auto tp_c) __attribute__((always_inline)) {
             constexpr int tp = decltype(tp_c)::value;
@@ -485,7 +493,7 @@ __global__ __launch_bounds__(NT) void conv3x3_pl_kernel(const PlArgs a) {
             const int boff = 2 * PLANE + (hh ? ((t1 / 3) * IW + t1 % 3) : ((t0 / 3) * IW + t0 % 3)) * 16;
             u32x4 a0[2], a1[2], b0[2], b1[2];
 _Pragma("unroll")
-            for (int m = 0; m < 2; ++m) {
+            for (int m = 0; m < MH; ++m) {
                 a0[m] = *reinterpret_cast<const u32x4*>(ldsA + aoff + m * 32 * 16);
                 a1[m] = *reinterpret_cast<const u32x4*>(ldsA + aoff + 64 * 16 + m * 32 * 16);
             }
@@ -497,11 +505,11 @@ _Pragma("unroll")
             if (single && hh) {
                 const u32x4 z = mk_u4(0, 0, 0, 0);
 _Pragma("unroll")
-                for (int m = 0; m < 2; ++m) { a0[m] = z; a1[m] = z; }
+                for (int m = 0; m < MH; ++m) { a0[m] = z; a1[m] = z; }
                 b0[0] = z; b0[1] = z; b1[0] = z; b1[1] = z;
             }
 _Pragma("unroll")
-            for (int m = 0; m < 2; ++m)
+            for (int m = 0; m < MH; ++m)
 _Pragma("unroll")
                 for (int q = 0; q < 2; ++q) wsu_mfma_f8x2(a0[m], a1[m], b0[q], b1[q], sc_a, sc_b, acc[m][q]);
         };
@@ -509,11 +517,11 @@ _Pragma("unroll")
             constexpr int tap = decltype(tap_c)::value, dy = tap / 3, dx = tap % 3;
             u32x4 ah[2], bh[2];
 _Pragma("unroll")
-            for (int m = 0; m < 2; ++m) ah[m] = *reinterpret_cast<const u32x4*>(ldsA + ((tap * 4 + hh) * 64 + m * 32) * 16);
+            for (int m = 0; m < MH; ++m) ah[m] = *reinterpret_cast<const u32x4*>(ldsA + ((tap * 4 + hh) * 64 + m * 32) * 16);
 _Pragma("unroll")
             for (int q = 0; q < 2; ++q) bh[q] = *reinterpret_cast<const u32x4*>(ldsB + hh * PLANE + ((q + dy) * IW + dx) * 16);
 _Pragma("unroll")
-            for (int m = 0; m < 2; ++m)
+            for (int m = 0; m < MH; ++m)
 _Pragma("unroll")
                 for (int q = 0; q < 2; ++q) wsu_mfma_f16(ah[m], bh[q], acc[m][q]);
         };
@@ -542,12 +550,12 @@ _Pragma("unroll")
                     const bool dead = hh ? tb > 8 : ta > 8;
                     const u32x4 z = mk_u4(0, 0, 0, 0);
 _Pragma("unroll")
-                    for (int m = 0; m < 2; ++m) { ab[b][m] = *reinterpret_cast<const u32x4*>(ldsA + aoff + m * 32 * 16); if (dead) ab[b][m] = z; }
+                    for (int m = 0; m < MH; ++m) { ab[b][m] = *reinterpret_cast<const u32x4*>(ldsA + aoff + m * 32 * 16); if (dead) ab[b][m] = z; }
 _Pragma("unroll")
                     for (int q = 0; q < 2; ++q) { bb[b][q] = *reinterpret_cast<const u32x4*>(ldsB + boff + q * IW * 16); if (dead) bb[b][q] = z; }
                 });
 _Pragma("unroll")
-                for (int m = 0; m < 2; ++m)
+                for (int m = 0; m < MH; ++m)
 _Pragma("unroll")
                     for (int q = 0; q < 2; ++q) wsu_mfma_f8x2(ab[0][m], ab[1][m], bb[0][q], bb[1][q], WSU_F8_SCALE_WLO, WSU_F8_SCALE_X, acc[m][q]);
             };
@@ -562,7 +570,7 @@ _Pragma("unroll")
         // ---- epilogue of the tile: accumulators -> planar global memory ---------------------------------------------------------
         if (c + 1 == a.nch && (a.ablate & 2)) {                            // timing only: the tile's results are dropped (kept alive for the compiler)
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+            for (int m = 0; m < MH; ++m)
 #pragma unroll
                 for (int q = 0; q < 2; ++q) asm volatile("" :: "v"(acc[m][q]));
             ++kt; c = 0;
@@ -580,10 +588,10 @@ _Pragma("unroll")
 #pragma unroll
                 for (int o = 0; o < (HC > 0 ? HC : 1); ++o) hz[q][o] = 0.f;
 #pragma unroll
-            for (int m = 0; m < 2; ++m) {
+            for (int m = 0; m < MH; ++m) {
 #pragma unroll
                 for (int cp = 0; cp < 2; ++cp) {                               // 16 output channels = accumulator groups g4 = 2cp, 2cp+1
-                    const int oc = cur.cb * 4 + m * 2 + cp;
+                    const int oc = cur.cb * 4 + (m + cur.mh) * 2 + cp;
                     const int co0 = oc * 16 + 4 * hh;                          // this lane: channels co0..co0+3 (X) and co0+8..co0+11 (Y)
                     f32x4 vx[2], vy[2];
                     if constexpr (GRAD) {
@@ -742,11 +750,22 @@ int pl_launch(PlArgs a, bool first, hipStream_t s, bool grad = false) {
                               reinterpret_cast<const void*>(&conv3x3_pl_kernel<1, false>), reinterpret_cast<const void*>(&conv3x3_pl_kernel<4, false>),
                               reinterpret_cast<const void*>(&conv3x3_pl_kernel<0, false, false>),
                               reinterpret_cast<const void*>(&conv3x3_pl_kernel<0, false, true, true>), reinterpret_cast<const void*>(&conv3x3_pl_kernel<0, true, true, true>)};
+        hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_pl_kernel<0, false, true, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
+        if (e0 != hipSuccess) { wsu_set_error("hipFuncSetAttribute(conv3x3_pl): %s", hipGetErrorString(e0)); return WSU_ERR_HIP; }
         for (const void* fn : fns) {
             hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
             if (e != hipSuccess) { wsu_set_error("hipFuncSetAttribute(conv3x3_pl): %s", hipGetErrorString(e)); return WSU_ERR_HIP; }
         }
         ncu = prop.multiProcessorCount;
+    }
+    // small grids: the plain variant splits every tile's 64 output channels over two work items when that still fits the CUs
+    static int msplit_on = -1;
+    if (msplit_on < 0) { const char* e = getenv("WSU_PL_MSPLIT"); msplit_on = e ? atoi(e) : 1; }
+    a.msplit = 0;
+    if (msplit_on && !grad && !first && !a.head_w && !a.ypool && a.xres && 2 * (long long)a.ntiles <= ncu) {
+        a.msplit = 1; a.ncb *= 2; a.ntiles *= 2;
+        hipLaunchKernelGGL((conv3x3_pl_kernel<0, false, true, false, false, true>), dim3(a.ntiles), dim3(NT), LDS_TOTAL, s, a);
+        return wsu_check_launch("conv3x3_pl_kernel");
     }
     const int grid = a.ntiles < ncu ? a.ntiles : ncu;
     const dim3 g(grid), b(NT);
