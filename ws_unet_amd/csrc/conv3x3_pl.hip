@@ -139,7 +139,7 @@ __device__ __forceinline__ void plan_tile(const PlArgs& a, const Tile& t, int la
 // the DMA of one chunk step into stage `st`: this wave's 7-8 input pieces, then its 9 weight pieces
 typedef __attribute__((address_space(3))) char lds_char;
 template <int LW, bool XRES, bool WEIGHTS_ONLY>
-__device__ __forceinline__ void issue_dma(const PlArgs& a, int tn, int tcb, int c, lds_char* st, int lane, const unsigned (&voff)[IN_PER_WAVE]) {
+__device__ __forceinline__ void issue_dma(const PlArgs& a, int tn, int tcb, int c, lds_char* st, int lane, const unsigned (&voff)[IN_PER_WAVE], int lw_rt = LW) {
     const unsigned plane4 = (unsigned)(a.h * a.w) * 16u * HBM_PLANES;          // bytes of one chunk of one image (3 stored planes)
     const char* in_src = c < a.nch1 ? a.x1 + ((size_t)tn * a.nch1 + c) * plane4
                                     : a.x2 + ((size_t)tn * (a.nch - a.nch1) + (c - a.nch1)) * plane4;
@@ -165,7 +165,7 @@ __device__ __forceinline__ void issue_dma(const PlArgs& a, int tn, int tcb, int 
         });
     }
     WSU_STATIC_FOR(W_PER_WAVE, k, {
-        constexpr int wslot = LW + NLOAD * k;
+        const int wslot = (WEIGHTS_ONLY ? lw_rt : LW) + NLOAD * k;               // compile-time unless the fused-first-layer loader (one copy, run-time wave index)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void*)(st + LDS_IN + wslot * 1024), 16, lane16, w_base + wslot * 1024, 0, 0);
     });
 }
@@ -190,8 +190,10 @@ __device__ __forceinline__ void swap32(uint32_t& upper_of, uint32_t& lower_of) {
 
 // ================= loader wave LW: the whole DMA of step j+1 right after the barrier that opens step j ====================================
 template <int LW, bool XRES, bool F1, bool GRAD>
-__device__ __forceinline__ void pl_loader(const PlArgs& a, char* smem, int lane, int lw, int G, int J) {
-    constexpr int lw8 = LW;
+__device__ __forceinline__ void pl_loader(const PlArgs& a, char* smem, int lane, int lw, int G, int J, int lw_rt = LW) {
+    // F1 (the loaders compute e11): ONE copy of this body with a run-time wave index -- its 27 image values + 16 accumulators per lane, inlined
+    // four times beside the matrix waves' code, made the register allocator spill ~160 registers; the input-slot geometry is unused there
+    const int lw8 = F1 ? lw_rt : LW;
     float* s_w1 = reinterpret_cast<float*>(smem + LDS_F1);
     float* s_b1 = s_w1 + 9 * 64;
     unsigned char* s_mask = reinterpret_cast<unsigned char*>(smem + LDS_EXTRA);   // GRAD: [4 output chunks][2 f16 planes][512 px] bytes of 8 mask bits (the bias slot)
@@ -331,7 +333,7 @@ __device__ __forceinline__ void pl_loader(const PlArgs& a, char* smem, int lane,
     lds_char* smem3 = (lds_char*)smem;                                    // LDS address space from here on: no generic-pointer null checks per piece
     if (J > 0) {
         if constexpr (F1) f1_window(t); else plan_tile<LW, GRAD>(a, t, lane, voff);
-        issue_dma<LW, XRES, F1>(a, t.n, t.cb, 0, smem3, lane, voff);
+        issue_dma<LW, XRES, F1>(a, t.n, t.cb, 0, smem3, lane, voff, lw8);
         f1_chunk(0, smem);
     }
     int c = 0, kt = 0;
@@ -355,7 +357,7 @@ __device__ __forceinline__ void pl_loader(const PlArgs& a, char* smem, int lane,
                 t = tile_of(a, lw + kt * G);
                 if constexpr (F1) f1_window(t); else plan_tile<LW, GRAD>(a, t, lane, voff);
             }
-            issue_dma<LW, XRES, F1>(a, t.n, t.cb, c, smem3 + ((j + 1) & 1) * STAGE, lane, voff);
+            issue_dma<LW, XRES, F1>(a, t.n, t.cb, c, smem3 + ((j + 1) & 1) * STAGE, lane, voff, lw8);
             f1_chunk(c, smem + ((j + 1) & 1) * STAGE);
         }
         if (GRAD && first_chunk) mask_issue(tj);
@@ -372,13 +374,6 @@ __device__ __forceinline__ void pl_loader(const PlArgs& a, char* smem, int lane,
         d[2] = t_wait; d[3] = t_bar; d[4] = t_dma; d[5] = 0; d[6] = 0; d[7] = (unsigned long long)J;
     }
 #endif
-}
-
-// The fused-first-layer loaders keep 27 image values and 16 accumulators per lane: inlined four times beside the matrix waves' code the
-// register allocator spilled ~160 registers; as out-of-line functions each instantiation is allocated on its own.
-template <int LW, bool XRES, bool F1, bool GRAD>
-__device__ __attribute__((noinline)) void pl_loader_outlined(const PlArgs& a, char* smem, int lane, int lw, int G, int J) {
-    pl_loader<LW, XRES, F1, GRAD>(a, smem, lane, lw, G, J);
 }
 
 // HEAD / POOL are compile-time: the kernel sits at the 168-register step (three waves per SIMD), and the head's partial sums or the pool's
@@ -437,12 +432,7 @@ __global__ __launch_bounds__(NT) void conv3x3_pl_kernel(const PlArgs a) {
     if (wv >= NWAVE) {
         // ================= loader waves (pl_loader<LW, ...>: the slot geometry of a wave is compile-time) ===========================
         if constexpr (F1) {
-            switch (wv - NWAVE) {
-                case 0: pl_loader_outlined<0, XRES, F1, GRAD>(a, smem, lane, lw, G, J); break;
-                case 1: pl_loader_outlined<1, XRES, F1, GRAD>(a, smem, lane, lw, G, J); break;
-                case 2: pl_loader_outlined<2, XRES, F1, GRAD>(a, smem, lane, lw, G, J); break;
-                default: pl_loader_outlined<3, XRES, F1, GRAD>(a, smem, lane, lw, G, J); break;
-            }
+            pl_loader<0, XRES, F1, GRAD>(a, smem, lane, lw, G, J, wv - NWAVE);
         } else {
             switch (wv - NWAVE) {
                 case 0: pl_loader<0, XRES, F1, GRAD>(a, smem, lane, lw, G, J); break;
