@@ -475,6 +475,9 @@ __global__ __launch_bounds__(NT) void conv3x3_pl_kernel(const PlArgs a) {
         // ---- matrix section: identical arithmetic (and accumulation order) to conv3x3_kernel<F16F8> -----------------------------
         const char* ldsA = st + LDS_IN + (cur.mh * 32 + l31) * 16;            // + ((tap*4 + g)*64 + m*32)*16
         const char* ldsB = st + ((2 * wv) * IW + l31) * 16;                   // + g*PLANE + ((q+dy)*IW + dx)*16
+#if WSU_PROBE == 5
+        u32x4 sa0[2], sa1[2], sb0[2], sb1[2], sah[2], sbh[2];
+#endif
         auto cross = [&](auto tp_c) __attribute__((always_inline)) {
             constexpr int tp = decltype(tp_c)::value;
             constexpr int t0 = 2 * tp, t1 = (2 * tp + 1 < 9) ? 2 * tp + 1 : 2 * tp;
@@ -482,6 +485,11 @@ __global__ __launch_bounds__(NT) void conv3x3_pl_kernel(const PlArgs a) {
             const int aoff = ((hh ? t1 : t0) * 4 + 2) * 64 * 16;
             const int boff = 2 * PLANE + (hh ? ((t1 / 3) * IW + t1 % 3) : ((t0 / 3) * IW + t0 % 3)) * 16;
             u32x4 a0[2], a1[2], b0[2], b1[2];
+#if WSU_PROBE == 5                                                      // timing probe 5 (make probes): LDS fragments are read for the first group of a step only
+            if (tp == 0) {
+#else
+            {
+#endif
 _Pragma("unroll")
             for (int m = 0; m < MH; ++m) {
                 a0[m] = *reinterpret_cast<const u32x4*>(ldsA + aoff + m * 32 * 16);
@@ -492,6 +500,12 @@ _Pragma("unroll")
                 b0[q] = *reinterpret_cast<const u32x4*>(ldsB + boff + q * IW * 16);
                 b1[q] = *reinterpret_cast<const u32x4*>(ldsB + boff + PLANE + q * IW * 16);
             }
+#if WSU_PROBE == 5
+            for (int m = 0; m < 2; ++m) { sa0[m] = a0[m]; sa1[m] = a1[m]; sb0[m] = b0[m]; sb1[m] = b1[m]; }
+            } else { for (int m = 0; m < 2; ++m) { a0[m] = sa0[m]; a1[m] = sa1[m]; b0[m] = sb0[m]; b1[m] = sb1[m]; } }
+#else
+            }
+#endif
             if (single && hh) {
                 const u32x4 z = mk_u4(0, 0, 0, 0);
 _Pragma("unroll")
@@ -506,10 +520,21 @@ _Pragma("unroll")
         auto main_term = [&](auto tap_c) __attribute__((always_inline)) {
             constexpr int tap = decltype(tap_c)::value, dy = tap / 3, dx = tap % 3;
             u32x4 ah[2], bh[2];
+#if WSU_PROBE == 5
+            if (tap == 0) {
+#else
+            {
+#endif
 _Pragma("unroll")
             for (int m = 0; m < MH; ++m) ah[m] = *reinterpret_cast<const u32x4*>(ldsA + ((tap * 4 + hh) * 64 + m * 32) * 16);
 _Pragma("unroll")
             for (int q = 0; q < 2; ++q) bh[q] = *reinterpret_cast<const u32x4*>(ldsB + hh * PLANE + ((q + dy) * IW + dx) * 16);
+#if WSU_PROBE == 5
+            for (int m = 0; m < 2; ++m) { sah[m] = ah[m]; sbh[m] = bh[m]; }
+            } else { for (int m = 0; m < 2; ++m) { ah[m] = sah[m]; bh[m] = sbh[m]; } }
+#else
+            }
+#endif
 _Pragma("unroll")
             for (int m = 0; m < MH; ++m)
 _Pragma("unroll")
