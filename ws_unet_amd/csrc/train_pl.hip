@@ -206,6 +206,9 @@ __global__ __launch_bounds__(256) void pool_bwd_pl_kernel(const char* __restrict
 // ---- 1x1 head + sigmoid backward (autograd of unet.py:186-188): dz = dout * out * (1 - out);  g[c] = (sum_o w[o][c] dz[o]) * (x[c] > 0);
 // dW[o][c] = sum_px dz[o] x[c];  db[o] = sum_px dz[o].  Thread = (pixel lane, 8-channel group); per-block partials, fixed-order reduction. --------
 constexpr int HEADP_MAXCO = 4;
+// NCO = output planes compiled in (1: the reference's single plane -- 48 registers of weights / weight-gradient sums fewer than the 4-plane
+// form, which sat at 144 registers = 3 waves per SIMD for a streaming kernel; 4: 2..4 planes)
+template <int NCO>
 __global__ __launch_bounds__(256) void head_bwd_pl_kernel(const char* __restrict__ x, const float* __restrict__ wgt, const float* __restrict__ out,
                                                           const float* __restrict__ dout, char* __restrict__ g, float* __restrict__ part,
                                                           int n, int hw_, int c, int cout) {
@@ -214,9 +217,9 @@ __global__ __launch_bounds__(256) void head_bwd_pl_kernel(const char* __restrict
     const int cg = threadIdx.x / ppb, pl = threadIdx.x % ppb;
     const size_t hw = (size_t)hw_;
     const long long npix = (long long)n * hw;
-    float wv[HEADP_MAXCO][8], aw[HEADP_MAXCO][8], ab[HEADP_MAXCO];
+    float wv[NCO][8], aw[NCO][8], ab[NCO];
 #pragma unroll
-    for (int o = 0; o < HEADP_MAXCO; ++o) {
+    for (int o = 0; o < NCO; ++o) {
         ab[o] = 0.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) { wv[o][e] = o < cout ? wgt[(size_t)o * c + cg * 8 + e] : 0.f; aw[o][e] = 0.f; }
@@ -228,7 +231,7 @@ __global__ __launch_bounds__(256) void head_bwd_pl_kernel(const char* __restrict
 #pragma unroll
         for (int e = 0; e < 8; ++e) gv[e] = 0.f;
 #pragma unroll
-        for (int o = 0; o < HEADP_MAXCO; ++o)
+        for (int o = 0; o < NCO; ++o)
             if (o < cout) {
                 const size_t oi = ((size_t)img * cout + o) * hw + pix;
                 const float ov = out[oi];
@@ -396,7 +399,8 @@ int wsu_conv1x1_sigmoid_pl_bwd(const void* x, const float* w, const float* out, 
     const long long npix = (long long)n * h * wd;
     const int ppb = 256 / (c / 8);
     const int nblk = (int)((npix + ppb - 1) / ppb < SUM_BLOCKS ? (npix + ppb - 1) / ppb : SUM_BLOCKS);
-    hipLaunchKernelGGL(head_bwd_pl_kernel, dim3(nblk), dim3(256), 0, s, (const char*)x, w, out, dout, (char*)g, workspace, n, h * wd, c, cout);
+    if (cout == 1) hipLaunchKernelGGL(head_bwd_pl_kernel<1>, dim3(nblk), dim3(256), 0, s, (const char*)x, w, out, dout, (char*)g, workspace, n, h * wd, c, cout);
+    else hipLaunchKernelGGL(head_bwd_pl_kernel<HEADP_MAXCO>, dim3(nblk), dim3(256), 0, s, (const char*)x, w, out, dout, (char*)g, workspace, n, h * wd, c, cout);
     int rc = wsu_check_launch("head_bwd_pl_kernel");
     if (rc) return rc;
     hipLaunchKernelGGL(head_bwd_pl_reduce_kernel, dim3((cout * (c + 1) + 63) / 64), dim3(64), 0, s, workspace, dw, db, nblk, c, cout);
