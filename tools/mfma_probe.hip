@@ -16,7 +16,8 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
 // KIND 0: bf16 32x32x16; 1: block-scaled fp8(e4m3) 32x32x64; 2: two bf16 + one fp8 per step (hi*hi in bf16, both cross terms in one fp8);
-// 3: bf16 16x16x32; 4: block-scaled fp6(e2m3) 32x32x64
+// 3: bf16 16x16x32; 4: block-scaled fp6(e2m3) 32x32x64; 5: block-scaled fp8 16x16x128; 6 / 7: the 9 f16 : 5 fp8 instruction mix of
+// conv3x3_pl in the 32x32 / 16x16 shapes (round 3: is a change of MFMA shape worth a rewrite of the matrix section?)
 template <int KIND>
 __global__ __launch_bounds__(512) void probe(const uint32_t* __restrict__ src, float* __restrict__ out, int iters) {
     const int lane = threadIdx.x & 63;
@@ -67,6 +68,31 @@ __global__ __launch_bounds__(512) void probe(const uint32_t* __restrict__ src, f
             d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, d1, 0, 0, 0);
             d2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, d2, 0, 0, 0);
             d3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, d3, 0, 0, 0);
+        } else if constexpr (KIND == 5) {                                  // block-scaled fp8 in the 16x16 shape
+            d0 = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8, b8, d0, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+            d1 = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8, b8, d1, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+            d2 = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8, b8, d2, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+            d3 = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8, b8, d3, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+        } else if constexpr (KIND == 6) {                                  // the f16f8 mix of conv3x3_pl per 18 taps of one 32x32 tile: 18 f16 + 10 fp8 (32x32 shapes)
+            _Pragma("unroll") for (int t = 0; t < 9; ++t) {
+                c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, ah, c1, 0, 0, 0);
+            }
+            _Pragma("unroll") for (int t = 0; t < 5; ++t) {
+                c0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, c0, 0, 0, 0, 0x7f767f76, 0, 0x7f767f76);
+                c1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, c1, 0, 0, 0, 0x7f767f76, 0, 0x7f767f76);
+            }
+        } else if constexpr (KIND == 7) {                                  // the same work in the 16x16 shapes: 36 x 16x16x32 (K = 2 taps) + 20 x 16x16x128 per 2 x 4 tiles
+            _Pragma("unroll") for (int t = 0; t < 9; ++t) {
+                d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, d0, 0, 0, 0); d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, ah, d1, 0, 0, 0);
+                d2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, d2, 0, 0, 0); d3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, ah, d3, 0, 0, 0);
+            }
+            _Pragma("unroll") for (int t = 0; t < 5; ++t) {
+                d0 = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8, b8, d0, 0, 0, 0, 0x7f767f76, 0, 0x7f767f76);
+                d1 = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8, b8, d1, 0, 0, 0, 0x7f767f76, 0, 0x7f767f76);
+                d2 = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8, b8, d2, 0, 0, 0, 0x7f767f76, 0, 0x7f767f76);
+                d3 = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8, b8, d3, 0, 0, 0, 0x7f767f76, 0, 0x7f767f76);
+            }
         } else {
             c0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, c0, 2, 2, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
             c1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, c1, 2, 2, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
@@ -108,6 +134,10 @@ int main(int argc, char** argv) {
         {"mix 8 bf16 + 4 fp8 (x3-equivalent of 12 bf16)", probe<2>, 16 * 32768.0 + 8 * 131072.0, 32},
         {"bf16 16x16x32", probe<3>, 8 * 16384.0, 4},
         {"fp6(e2m3) scaled 32x32x64", probe<4>, 8 * 131072.0, 8},
+        {"fp8(e4m3) scaled 16x16x128", probe<5>, 8 * 65536.0, 8},
+        // the conv3x3_pl matrix mix (9 f16 : 5 fp8 instructions per chunk and tile), 38 units of 32 cycles per iteration in both shapes
+        {"conv3x3_pl mix, 32x32 shapes (18 f16 + 10 fp8)", probe<6>, 2 * (18 * 32768.0 + 10 * 131072.0), 2 * 38},
+        {"conv3x3_pl mix, 16x16 shapes (36 f16 + 20 fp8)", probe<7>, 2 * (36 * 16384.0 + 20 * 65536.0), 2 * 38},
     };
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (auto& c : cases) {

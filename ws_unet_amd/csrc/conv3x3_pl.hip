@@ -36,11 +36,12 @@ constexpr int NWAVE = 8, NLOAD = 4, NT = (NWAVE + NLOAD) * 64;      // 8 matrix 
 constexpr int IN_SEG = (NPIX + 63) / 64;                  // 10 wave-instructions per plane (the last one 36 lanes wide)
 constexpr int HBM_PLANES = 3;                             // stored planes per chunk: f16 ch 0-7 | f16 ch 8-15 | e4m3 residuals; LDS plane 3 is derived
 constexpr int IN_SLOTS = HBM_PLANES * IN_SEG;             // 30
-// The DMA of a step is issued by two dedicated LOADER waves (waves 8, 9: 38 pieces each), the matrix waves never touch the vector-memory
-// pipe inside the loop.  Measured on the way (profiles/r02/conv3x3_pl_stamps.md): a piece costs its issuing wave ~150 cycles in the
-// queue, so (v1) all eight waves issuing their pieces after the barrier idled the matrix pipe for 2-3 k cycles per step, (v2/v4)
+// The DMA of a step is issued by FOUR dedicated loader waves (waves 8-11, one per SIMD: 16-17 pieces each), the matrix waves never touch the
+// vector-memory pipe inside the loop.  Measured on the way (profiles/r02/conv3x3_pl_stamps.md): a piece costs its issuing wave ~150 cycles
+// in the queue, so (v1) all eight waves issuing their pieces after the barrier idled the matrix pipe for 2-3 k cycles per step, (v2/v4)
 // threading the pieces through the matrix section stalled the in-order waves just as long, (v3) giving them to one wave per SIMD let its
-// partner run alone (68 % pipe time).  A wave that only loads costs 168 instead of 256 registers per matrix wave -- nothing else.
+// partner run alone (68 % pipe time), (v5) two loader waves were the critical path.  A wave that only loads costs 168 instead of 256
+// registers per matrix wave -- nothing else.  Round 3 made the loaders' instruction stream lean (below, "loader side").
 constexpr int IN_PER_WAVE = (IN_SLOTS + NLOAD - 1) / NLOAD;   // 8 (slots 30, 31 do not exist)
 constexpr int W_SLOTS = LDS_W / 1024;                     // 36
 constexpr int W_PER_WAVE = W_SLOTS / NLOAD;               // 9
@@ -72,8 +73,6 @@ struct PlArgs {
     int msplit;                                           // 1: work items are half-blocks of 32 output channels (kernel variant MSPLIT); ncb = 2 * cout / 64
 };
 
-__device__ __attribute__((aligned(16))) unsigned g_zero16[4];   // source of the zero-padding DMA pieces of the GRAD variant
-
 struct Tile { int n, y0, x0, cb, mh; };                   // mh: the 32-channel half of block cb this item computes (kernel variant MSPLIT), else 0
 
 // Diagnostic stamps (only in the -DWSU_PL_STAMPS build): per workgroup the accumulated shader cycles of each phase of the chunk loop and
@@ -103,7 +102,6 @@ __device__ __forceinline__ Tile tile_of(const PlArgs& a, int t) {
 //   * weight pieces: one descriptor for the packed weights, offset = chunk base (scalar) + lane * 16.
 // Per step and wave that leaves ~3 instructions per piece, two of them scalar.
 typedef __attribute__((address_space(3))) void lds_void;
-typedef __attribute__((address_space(1))) const void glb_void;
 
 template <int LW> struct LoaderGeo {
     static constexpr int slot(int k) { return LW + NLOAD * k; }
@@ -382,8 +380,8 @@ __device__ __forceinline__ void pl_loader(const PlArgs& a, char* smem, int lane,
 // 9 f16 + 3 fp8 instructions = 15 instead of 19 matrix units per chunk, 30 instead of 40 input DMA pieces) -- `x_residual = 0`, see wsu.h.
 // GRAD: the data gradient of the conv (K7p, autograd of unet.py:141-189): the same pipeline over the pre-activation gradient with the
 // transposed / flipped weights (wsu_conv3x3_pack_dgrad) -- zero padding, the gradient's e4m3 scalings, no bias / ReLU, the ReLU mask of
-// the producing layer applied from a bit image that the loader waves build in LDS from that layer's stored f16 planes.  The reflect
-// adjoint's border ring is added by the caller (train_pl.hip).
+// the producing layer applied from a bit image in LDS: the loader waves bring the layer's 1-bit relu_mask planes in by LDS-DMA (round 3) or,
+// without them, build it from that layer's stored f16 planes.  The reflect adjoint's border ring is added by the caller (train_pl.hip).
 // MSPLIT (round 3, small grids): a work item is HALF a tile's output channels (32 of the 64: m-half = item & 1 -- each matrix wave keeps 2
 // instead of 4 accumulator tiles), so a layer with fewer tiles than CUs (e31 / e32 of unet_2 at batch 1: 128 tiles) occupies twice as many
 // CUs with half the matrix work per step each; the input tile and the whole 64-channel weight slice are fetched as before.
