@@ -341,7 +341,7 @@ def latency_b1_leg(dev, mode, size=512, reps=40, warmup=8):
             "per_layer": [{k: r[k] for k in ("layer", "ms", "tiles", "steps_per_tile", "cu_occupied", "tile_waves", "tflops", "hbm_GBps") if k in r} for r in pl["layers"]]}
 
 
-def train_step_leg(dev, batch, size, steps=5, warmup=3, train_mode=None):
+def train_step_leg(dev, batch, size, steps=5, warmup=3, train_mode=None, train_products=None):
     """BASELINE.json configs[2]: unet_2 fwd + L1WS + bwd + AdamW on synthetic cover/stego pairs resident in HBM."""
     import numpy as np
     import torch
@@ -351,6 +351,8 @@ def train_step_leg(dev, batch, size, steps=5, warmup=3, train_mode=None):
     m = get_model("unet_2", in_channels=1, out_channels=1, channel=[0], drop_rate=None, mode="f16f8p")
     if train_mode:
         m.train_mode = train_mode
+    if train_products:
+        m.train_products = train_products
     m.load_state_dict({k: torch.from_numpy(v) for k, v in formula.formula_state_dict(2, "default").items()})
     m = m.to(dev)
     cov = formula.synthetic_images(batch, size, size, seed=5)
@@ -374,7 +376,10 @@ def train_step_leg(dev, batch, size, steps=5, warmup=3, train_mode=None):
     top = sorted(ks.items(), key=lambda kv: -kv[1]["total_ms"])[:3]
     flop = TRAIN_FLOP_PER_IMAGE_512 * (size / 512.0) ** 2 * batch
     res = {"workload": f"unet_2 fwd + L1WS + bwd + AdamW, batch={batch} synthetic {size}x{size} cover/stego pairs (BASELINE.json configs[2])",
-           "arithmetic": (f"train_mode={m.train_mode}: f16f8 arithmetic on planar activations and gradients (3 bytes per element), fp32 accumulation" if m.train_mode == "f16f8p"
+           "arithmetic": (f"train_mode={m.train_mode} train_products={m.train_products}: planar activations and gradients (3 bytes per element), fp32 accumulation; "
+                          "forward in the f16f8 arithmetic of the predict path; 3x3 data / weight gradients multiply "
+                          + ("the f16 parts only (exact f16 products; include/wsu.h WSU_PRODUCTS_F16)" if m.train_products == "f16" else "f16 products + both fp8 residual cross terms")
+                          if m.train_mode == "f16f8p"
                           else f"train_mode={m.train_mode} fwd={m.train_fwd_mode} bwd={m.train_bwd_mode} (fp32 storage and accumulation)"),
            "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3, "images_per_s": batch * steps / dt,
            "tflops_algorithmic": flop * steps / dt / 1e12, "frac_of_mfma_peak": flop * steps / dt / PEAK["bf16x3"],
@@ -524,6 +529,9 @@ def main():
     if rank == 0 and world == 1 and not args.no_train_step:
         try:
             result["train_step"] = train_step_leg(dev, args.train_batch, args.size)
+            # the same step with the forward's f16f8 arithmetic in the backward matrix kernels too (train_products='f16f8', the round-2 arithmetic)
+            r2 = train_step_leg(dev, args.train_batch, args.size, steps=3, warmup=2, train_products="f16f8")
+            result["train_step_products_f16f8"] = {k: r2[k] for k in ("arithmetic", "steps", "warmup", "ms_per_step", "images_per_s", "tflops_algorithmic", "loss", "kernels_ms_per_step")}
         except Exception as e:                                       # the headline line must survive (e.g. a smaller card)
             result["train_step"] = {"error": f"{type(e).__name__}: {e}"}
 

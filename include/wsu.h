@@ -57,6 +57,18 @@ extern "C" {
 
 enum { WSU_MODE_F32 = 0, WSU_MODE_BF16X3 = 1, WSU_MODE_BF16 = 2, WSU_MODE_BF16X3S = 3, WSU_MODE_F16F8 = 4, WSU_MODE_F16F8X = 5 };
 
+/* `products` of the planar BACKWARD matrix kernels (wsu_conv3x3_pl_bwd_data, wsu_conv3x3_pl_bwd_weight) -- which terms of
+ * (f16 a + residual a)(f16 b + residual b) are multiplied:
+ *      WSU_PRODUCTS_F16F8 = 0  f16 a * f16 b on the f16 pipe + both residual cross terms on the block-scaled fp8 pipe (the forward's arithmetic,
+ *                              ~2^-16 per product; 19 matrix units per 9 of plain f16 in the data gradient, 4 per 2 in the weight gradient);
+ *      WSU_PRODUCTS_F16   = 1  f16 a * f16 b only (2^-11 per operand, unbiased rounding, fp32 accumulation): the residual planes are neither
+ *                              fetched nor multiplied.  A weight gradient sums 10^6..10^7 such products per element and a data gradient
+ *                              9 * cout of them, so the rounding noise averages out to a relative L2 of <= 2e-4 per weight gradient and
+ *                              ~1e-4 per data-gradient layer (tests/test_gpu_planar_train.py) -- below the 1e-3 that ReLU-mask flips from
+ *                              the FORWARD's own rounding put between any two arithmetics on these networks, and 8x finer than bf16
+ *                              autocast.  The forward pass and the stored formats do not change. */
+enum { WSU_PRODUCTS_F16F8 = 0, WSU_PRODUCTS_F16 = 1 };
+
 enum {
     WSU_OK = 0,
     WSU_ERR_ARG = -1,      /* bad argument (shape, mode, null pointer) */
@@ -161,18 +173,19 @@ int wsu_conv3x3_pack_ring(const float* w_oihw, void* w_packed, int cin, int cout
 int wsu_conv3x3_pl_bwd_data(const void* g, const void* w_packed_dgrad, const void* w_packed_ring, void* workspace, size_t workspace_bytes,
                             void* dx1, void* dx2, int csplit, const void* mask1, const void* mask2,
                             const unsigned char* mask1_bits, const unsigned char* mask2_bits,
-                            int n, int h, int w, int cin, int cout, int pad_zero, void* stream);
+                            int n, int h, int w, int cin, int cout, int pad_zero, int products, void* stream);
 /*      mask1_bits / mask2_bits (optional, each only together with its mask1 / mask2): the relu_mask planes of those activations; the
  *      persistent kernel then brings a tile's mask in by LDS-DMA (4 KB) instead of re-reading the activations' f16 planes (64 KB); the
- *      border fold still reads mask1 / mask2. */
+ *      border fold still reads mask1 / mask2.  products: WSU_PRODUCTS_F16F8 or WSU_PRODUCTS_F16 (above). */
 
 /* ---- K7p: weight / bias gradients on PLANAR operands (csrc/wgrad.hip wgrad_pl_kernel: the split-K MFMA GEMM over pixels of
  *      wsu_conv3x3_bwd_weight with planar staging -- one stored f16 granule + half a residual granule per (pixel, 8 channels), no split arithmetic).
  *      conv: g (cout channels, planar gradient), x1 / x2 (the layer's saved planar inputs, c1 / c2 channels), dw (cout, c1 + c2, 3, 3), db (cout) or
  *      NULL (sum of the decoded gradient values, fixed order).  Transposed conv: x (cin channels at h x w), dy (cout channels, planar gradient at
- *      2h x 2w), dw (cin, cout, 2, 2), db (cout) or NULL.  All channel counts multiples of 64; workspace >= wsu_wgrad_workspace_bytes.  Deterministic. */
+ *      2h x 2w), dw (cin, cout, 2, 2), db (cout) or NULL.  All channel counts multiples of 64; workspace >= wsu_wgrad_workspace_bytes.  Deterministic.
+ *      products (conv): WSU_PRODUCTS_F16F8 or WSU_PRODUCTS_F16 (above; db is then the sum of the gradient's f16 parts). */
 int wsu_conv3x3_pl_bwd_weight(const void* g, const void* x1, const void* x2, float* dw, float* db, float* workspace, size_t workspace_bytes,
-                              int n, int h, int w, int c1, int c2, int cout, void* stream);
+                              int n, int h, int w, int c1, int c2, int cout, int products, void* stream);
 int wsu_convt2x2_pl_bwd_weight(const void* x, const void* dy, float* dw, float* db, float* workspace, size_t workspace_bytes,
                                int n, int h, int w, int cin, int cout, void* stream);
 

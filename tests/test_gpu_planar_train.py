@@ -157,6 +157,80 @@ def test_conv3x3_pl_bwd_weight(n, h, w, c1, c2, cout):
     assert torch.equal(dw, dw2)                                        # fixed-order reduction
 
 
+def _h(t):
+    """what the f16 planes of a planar tensor hold for t"""
+    return t.half().float()
+
+
+@pytest.mark.parametrize("n,h,w,cin,csplit,cout,masked,pad_zero", [
+    (2, 16, 32, 64, 64, 64, False, True),
+    (1, 40, 72, 64, 64, 64, True, False),       # partial tiles, border ring
+    (2, 32, 64, 128, 64, 64, False, False),     # fused concat: two gradients
+    (1, 24, 40, 128, 128, 32, True, True),
+    (1, 3, 5, 64, 64, 64, True, False),
+    (1, 96, 160, 64, 64, 128, True, False),     # several tiles per workgroup, 8 chunks
+])
+def test_conv3x3_pl_bwd_data_f16_products(n, h, w, cin, csplit, cout, masked, pad_zero):
+    """products = 'f16' (wsu.h WSU_PRODUCTS_F16): the kernel multiplies the f16 parts of gradient and weights and nothing else -- equal, up to the
+    accumulation order and the store encoding, to the exact adjoint taken on f16-rounded operands; against the unrounded adjoint the operand
+    rounding shows as ~1e-4 relative L2."""
+    ops = _ops()
+    wgt = _rand((cout, cin, 3, 3), 1, (2.0 / (9 * cin)) ** 0.5)
+    g = _q(_rand((n, cout, h, w), 2), GRAD_LO)
+    act = torch.relu(_rand((n, cin, h, w), 3)) if masked else None
+    refs = []
+    for gg, ww in ((_h(g), _h(wgt)), (g, wgt)):
+        x = torch.zeros((n, cin, h, w), dtype=torch.float64, requires_grad=True)
+        F.conv2d(F.pad(x, (1, 1, 1, 1), mode="constant" if pad_zero else "reflect"), ww.double()).backward(gg.double())
+        refs.append(x.grad * (act > 0) if masked else x.grad)
+    wd = wgt.to(DEV)
+    wp = ops.pack_conv3x3(wd, ops.MODE_F16F8, dgrad=True)
+    wr = None if pad_zero else ops.pack_conv3x3_ring(wd)
+    m1 = planar_encode(act[:, :csplit]) if masked else None
+    m2 = planar_encode(act[:, csplit:]) if (masked and csplit < cin) else None
+    dx1, dx2 = ops.conv3x3_pl_bwd_data(planar_encode(g, GRAD_LO), wp, wr, cin, csplit, m1, m2, pad_zero=pad_zero, products="f16")
+    torch.cuda.synchronize()
+    got = planar_decode(dx1, GRAD_LO)
+    if dx2 is not None:
+        got = torch.cat([got, planar_decode(dx2, GRAD_LO)], dim=1)
+    assert rel_l2(got, refs[0]) < 2e-5, rel_l2(got, refs[0])
+    assert rel_l2(got, refs[1]) < 5e-4, rel_l2(got, refs[1])
+    if masked:
+        assert float(got[(act <= 0)].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("n,h,w,c1,c2,cout", [
+    (2, 16, 32, 64, 0, 64),
+    (1, 40, 72, 64, 0, 64),             # partial tiles
+    (2, 320, 128, 64, 0, 64),           # the ring wraps
+    (1, 200, 96, 128, 0, 128),
+    (1, 96, 160, 64, 64, 64),           # fused concat
+])
+def test_conv3x3_pl_bwd_weight_f16_products(n, h, w, c1, c2, cout):
+    """products = 'f16': dW from the f16 parts of gradient and activations (exact products, fp32 accumulation), db = the sum of the gradient's
+    f16 parts; deterministic.  On these random operands -- sums of zero-mean products, the worst case for rounding noise -- the operand rounding
+    costs ~2e-4 relative L2 against the unrounded gradient."""
+    ops = _ops()
+    cin = c1 + c2
+    x = _q(torch.relu(_rand((n, cin, h, w), 5)), 4096.0)
+    g = _q(_rand((n, cout, h, w), 6), GRAD_LO)
+    refs = []
+    for gg, xx in ((_h(g), _h(x)), (g, x)):
+        wgt = torch.zeros((cout, cin, 3, 3), dtype=torch.float64, requires_grad=True)
+        b = torch.zeros(cout, dtype=torch.float64, requires_grad=True)
+        F.conv2d(F.pad(xx.double(), (1, 1, 1, 1), mode="reflect"), wgt, b).backward(gg.double())
+        refs.append((wgt.grad, b.grad))
+    x1 = planar_encode(x[:, :c1])
+    x2 = planar_encode(x[:, c1:]) if c2 else None
+    dw, db = ops.conv3x3_pl_bwd_weight(planar_encode(g, GRAD_LO), x1, x2, products="f16")
+    torch.cuda.synchronize()
+    assert rel_l2(dw.cpu(), refs[0][0]) < 5e-6, rel_l2(dw.cpu(), refs[0][0])
+    assert rel_l2(db.cpu(), refs[0][1]) < 2e-6, rel_l2(db.cpu(), refs[0][1])
+    assert rel_l2(dw.cpu(), refs[1][0]) < 5e-4, rel_l2(dw.cpu(), refs[1][0])
+    dw2, db2 = ops.conv3x3_pl_bwd_weight(planar_encode(g, GRAD_LO), x1, x2, products="f16")
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)
+
+
 def test_planar_backward_kernels_race_screen():
     """Repeat launches of the pipelined backward kernels (weight-gradient ring: LDS-DMA three steps deep; data gradient: persistent kernel + ring
     launches) must be bitwise identical: a missing wait or barrier shows up as a launch-to-launch difference."""
@@ -259,14 +333,16 @@ def grad_golden():
     return np.load(os.path.join(os.path.dirname(__file__), "golden", "unet_grad.npz"))
 
 
+@pytest.mark.parametrize("products", ["f16f8", "f16"])
 @pytest.mark.parametrize("ns", [0, 1, 2])
-def test_unet_gradients_golden_planar(grad_golden, ns):
+def test_unet_gradients_golden_planar(grad_golden, ns, products):
     """train_mode 'f16f8p' end to end against the reference's autograd golden (tests/golden/make_golden.py: L1WS on 2x1x64x64 pairs):
     planar activations and gradients, the bands of test_gpu_backward.py::test_unet_gradients_golden for the split arithmetics."""
     ops = _ops()
     g = grad_golden
     model = gpu_model(ns, "he", "f16f8p")
     model.train_mode = "f16f8p"
+    model.train_products = products
     cov_u8 = formula.synthetic_images(2, 64, 64, seed=11)
     st_u8 = cov_u8.copy(); st_u8[0] = formula.lsbr_embed(cov_u8[0], 0.4, seed=5)
     covers = torch.from_numpy(cov_u8.astype(np.float32) / np.float32(255.))[:, None].to(DEV)
@@ -301,12 +377,14 @@ def test_unet_gradients_golden_planar(grad_golden, ns):
         assert torch.equal(p.grad, first[k]), k                        # deterministic
 
 
+@pytest.mark.parametrize("products", ["f16f8", "f16"])
 @pytest.mark.parametrize("n,size", [(2, 128), (1, 512), (1, 1024)])
-def test_planar_vs_fp32_storage_gradients_smooth_loss(n, size):
+def test_planar_vs_fp32_storage_gradients_smooth_loss(n, size, products):
     """The two training paths of one model under a smooth (L2) loss: same arithmetic class, different storage -- every parameter gradient agrees
     to a relative L2 of 2e-3 (ReLU-mask flips on rounding noise are the floor; test_gpu_backward_large.py).  At 512x512 every persistent
     workgroup of the data-gradient kernel walks several tiles and the weight-gradient ring several steps."""
     model = gpu_model(2, "he", "f16f8p")
+    model.train_products = products                 # f16 products in the backward matrix kernels: the same band (its rounding noise sits below the mask flips)
     x = torch.rand((n, 1, size, size), generator=torch.Generator().manual_seed(3)).to(DEV)
     tgt = torch.rand((n, 1, size, size), generator=torch.Generator().manual_seed(4)).to(DEV)
     res = {}

@@ -53,8 +53,8 @@ SIGNATURES = {
     "wsu_convt2x2_pl_fwd": (c_int, [_P, _P, _P, _P] + [c_int] * 5 + [_P, _P]),
     "wsu_conv3x3_pl_bwd_data_workspace_bytes": (c_size_t, [c_int] * 5),
     "wsu_conv3x3_pack_ring": (c_int, [_P, _P, c_int, c_int, _P]),
-    "wsu_conv3x3_pl_bwd_data": (c_int, [_P, _P, _P, _P, c_size_t, _P, _P, c_int, _P, _P, _P, _P] + [c_int] * 6 + [_P]),
-    "wsu_conv3x3_pl_bwd_weight": (c_int, [_P] * 6 + [c_size_t] + [c_int] * 6 + [_P]),
+    "wsu_conv3x3_pl_bwd_data": (c_int, [_P, _P, _P, _P, c_size_t, _P, _P, c_int, _P, _P, _P, _P] + [c_int] * 7 + [_P]),
+    "wsu_conv3x3_pl_bwd_weight": (c_int, [_P] * 6 + [c_size_t] + [c_int] * 7 + [_P]),
     "wsu_convt2x2_pl_bwd_weight": (c_int, [_P] * 5 + [c_size_t] + [c_int] * 5 + [_P]),
     "wsu_convt2x2_pl_pack_dgrad": (c_int, [_P, _P, c_int, c_int, _P]),
     "wsu_convt2x2_pl_bwd_data": (c_int, [_P] * 4 + [c_int] * 5 + [_P]),

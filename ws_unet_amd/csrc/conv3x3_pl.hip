@@ -71,6 +71,7 @@ struct PlArgs {
     // the tile's 8 granule planes x 512 bytes in by LDS-DMA instead of re-reading 2 bytes per element of the producing layer's f16 planes.
     unsigned char* relu_mask_out; const unsigned char* mbits; const unsigned char* mbits2;
     int msplit;                                           // 1: work items are half-blocks of 32 output channels (kernel variant MSPLIT); ncb = 2 * cout / 64
+    int honly;                                            // GRAD, 1: f16 products only (kernel variant HONLY; wsu.h "products" of the backward entry points)
 };
 
 struct Tile { int n, y0, x0, cb, mh; };                   // mh: the 32-channel half of block cb this item computes (kernel variant MSPLIT), else 0
@@ -136,7 +137,7 @@ __device__ __forceinline__ void plan_tile(const PlArgs& a, const Tile& t, int la
 
 // the DMA of one chunk step into stage `st`: this wave's 7-8 input pieces, then its 9 weight pieces
 typedef __attribute__((address_space(3))) char lds_char;
-template <int LW, bool XRES, bool WEIGHTS_ONLY>
+template <int LW, bool XRES, bool WEIGHTS_ONLY, bool HONLY = false>
 __device__ __forceinline__ void issue_dma(const PlArgs& a, int tn, int tcb, int c, lds_char* st, int lane, const unsigned (&voff)[IN_PER_WAVE], int lw_rt = LW) {
     const unsigned plane4 = (unsigned)(a.h * a.w) * 16u * HBM_PLANES;          // bytes of one chunk of one image (3 stored planes)
     const char* in_src = c < a.nch1 ? a.x1 + ((size_t)tn * a.nch1 + c) * plane4
@@ -162,10 +163,14 @@ __device__ __forceinline__ void issue_dma(const PlArgs& a, int tn, int tcb, int 
             }
         });
     }
-    WSU_STATIC_FOR(W_PER_WAVE, k, {
-        const int wslot = (WEIGHTS_ONLY ? lw_rt : LW) + NLOAD * k;               // compile-time unless the fused-first-layer loader (one copy, run-time wave index)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void*)(st + LDS_IN + wslot * 1024), 16, lane16, w_base + wslot * 1024, 0, 0);
-    });
+    // weight slot = tap * 4 + granule plane (f16 ci 0-7 | f16 ci 8-15 | e4m3 copies | e4m3 residuals), so loader wave LW carries granule
+    // plane LW of every tap: with f16 products only (HONLY) waves 2 and 3 have no weight pieces
+    if constexpr (!(HONLY && LW >= 2)) {
+        WSU_STATIC_FOR(W_PER_WAVE, k, {
+            const int wslot = (WEIGHTS_ONLY ? lw_rt : LW) + NLOAD * k;           // compile-time unless the fused-first-layer loader (one copy, run-time wave index)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void*)(st + LDS_IN + wslot * 1024), 16, lane16, w_base + wslot * 1024, 0, 0);
+        });
+    }
 }
 
 // value of lane ^ 1 by a DPP quad permutation (a VALU modifier: no LDS crossbar round trip like ds_bpermute)
@@ -187,7 +192,7 @@ __device__ __forceinline__ void swap32(uint32_t& upper_of, uint32_t& lower_of) {
 #endif
 
 // ================= loader wave LW: the whole DMA of step j+1 right after the barrier that opens step j ====================================
-template <int LW, bool XRES, bool F1, bool GRAD>
+template <int LW, bool XRES, bool F1, bool GRAD, bool HONLY = false>
 __device__ __forceinline__ void pl_loader(const PlArgs& a, char* smem, int lane, int lw, int G, int J, int lw_rt = LW) {
     // F1 (the loaders compute e11): ONE copy of this body with a run-time wave index -- its 27 image values + 16 accumulators per lane, inlined
     // four times beside the matrix waves' code, made the register allocator spill ~160 registers; the input-slot geometry is unused there
@@ -331,15 +336,17 @@ __device__ __forceinline__ void pl_loader(const PlArgs& a, char* smem, int lane,
     lds_char* smem3 = (lds_char*)smem;                                    // LDS address space from here on: no generic-pointer null checks per piece
     if (J > 0) {
         if constexpr (F1) f1_window(t); else plan_tile<LW, GRAD>(a, t, lane, voff);
-        issue_dma<LW, XRES, F1>(a, t.n, t.cb, 0, smem3, lane, voff, lw8);
+        issue_dma<LW, XRES, F1, HONLY>(a, t.n, t.cb, 0, smem3, lane, voff, lw8);
         f1_chunk(0, smem);
     }
     int c = 0, kt = 0;
     for (int j = 0; j < J; ++j) {
         STAMP(s0);
         static_assert(W_PER_WAVE == 9, "the vmcnt immediate below");
+        if constexpr (!HONLY) {                                           // (f16 products only: LDS plane 3 is not used, nothing to derive)
         asm volatile("s_waitcnt vmcnt(9)" ::: "memory");                  // this wave's INPUT pieces of step j have landed (everything older than its
         if (!(a.ablate & 8)) derive_x8(smem + (j & 1) * STAGE);           // 9 youngest operations: the weight pieces, or mask loads issued after them)
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // ... its weight pieces (and the mask granules) too
         if (mask_pending) { mask_commit(); mask_pending = false; }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                // ... and its derived / computed planes are written
@@ -355,7 +362,7 @@ __device__ __forceinline__ void pl_loader(const PlArgs& a, char* smem, int lane,
                 t = tile_of(a, lw + kt * G);
                 if constexpr (F1) f1_window(t); else plan_tile<LW, GRAD>(a, t, lane, voff);
             }
-            issue_dma<LW, XRES, F1>(a, t.n, t.cb, c, smem3 + ((j + 1) & 1) * STAGE, lane, voff, lw8);
+            issue_dma<LW, XRES, F1, HONLY>(a, t.n, t.cb, c, smem3 + ((j + 1) & 1) * STAGE, lane, voff, lw8);
             f1_chunk(c, smem + ((j + 1) & 1) * STAGE);
         }
         if (GRAD && first_chunk) mask_issue(tj);
@@ -385,7 +392,9 @@ __device__ __forceinline__ void pl_loader(const PlArgs& a, char* smem, int lane,
 // MSPLIT (round 3, small grids): a work item is HALF a tile's output channels (32 of the 64: m-half = item & 1 -- each matrix wave keeps 2
 // instead of 4 accumulator tiles), so a layer with fewer tiles than CUs (e31 / e32 of unet_2 at batch 1: 128 tiles) occupies twice as many
 // CUs with half the matrix work per step each; the input tile and the whole 64-channel weight slice are fetched as before.
-template <int HC, bool POOL, bool XRES = true, bool F1 = false, bool GRAD = false, bool MSPLIT = false>   // HC = head planes compiled in: 0 (no head), 1 (the reference's single output plane) or 4 (1..4)
+// HONLY (round 3, a training arithmetic of the data gradient: wsu.h "products"): f16 products only -- the 9 f16 instructions of a chunk, no
+// cross terms; the residual plane of the gradient, the e4m3 weight planes and the derived plane are neither fetched nor built (needs XRES = false).
+template <int HC, bool POOL, bool XRES = true, bool F1 = false, bool GRAD = false, bool MSPLIT = false, bool HONLY = false>   // HC = head planes compiled in: 0 (no head), 1 (the reference's single output plane) or 4 (1..4)
 __global__ __launch_bounds__(NT) void conv3x3_pl_kernel(const PlArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -430,13 +439,13 @@ __global__ __launch_bounds__(NT) void conv3x3_pl_kernel(const PlArgs a) {
     if (wv >= NWAVE) {
         // ================= loader waves (pl_loader<LW, ...>: the slot geometry of a wave is compile-time) ===========================
         if constexpr (F1) {
-            pl_loader<0, XRES, F1, GRAD>(a, smem, lane, lw, G, J, wv - NWAVE);
+            pl_loader<0, XRES, F1, GRAD, HONLY>(a, smem, lane, lw, G, J, wv - NWAVE);
         } else {
             switch (wv - NWAVE) {
-                case 0: pl_loader<0, XRES, F1, GRAD>(a, smem, lane, lw, G, J); break;
-                case 1: pl_loader<1, XRES, F1, GRAD>(a, smem, lane, lw, G, J); break;
-                case 2: pl_loader<2, XRES, F1, GRAD>(a, smem, lane, lw, G, J); break;
-                default: pl_loader<3, XRES, F1, GRAD>(a, smem, lane, lw, G, J); break;
+                case 0: pl_loader<0, XRES, F1, GRAD, HONLY>(a, smem, lane, lw, G, J); break;
+                case 1: pl_loader<1, XRES, F1, GRAD, HONLY>(a, smem, lane, lw, G, J); break;
+                case 2: pl_loader<2, XRES, F1, GRAD, HONLY>(a, smem, lane, lw, G, J); break;
+                default: pl_loader<3, XRES, F1, GRAD, HONLY>(a, smem, lane, lw, G, J); break;
             }
         }
         return;
@@ -541,7 +550,10 @@ _Pragma("unroll")
         // Measured neutral on this section (gpurun_out/ab_prio.log, time_pl*.log): raising the priority of waves 4-7 for its second half so
         // that SIMD partners reach the barrier together; fetching fragments one unit ahead of their matrix instructions behind scheduling
         // fences (two ahead needs 190 registers).
-        if constexpr (XRES) {
+        static_assert(!HONLY || !XRES, "HONLY reads neither residual plane");
+        if constexpr (HONLY) {
+            WSU_STATIC_FOR(9, tap, { main_term(std::integral_constant<int, tap>{}); });
+        } else if constexpr (XRES) {
             WSU_STATIC_FOR(5, tp, {
 #if WSU_PROBE != 3                                                      // timing probe 3 (make probes): no cross terms at all = plain f16, 9 units
                 cross(std::integral_constant<int, tp>{});
@@ -759,7 +771,7 @@ int pl_launch(PlArgs a, bool first, hipStream_t s, bool grad = false) {
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
             wsu_set_error("conv3x3_pl: cannot query the device"); return WSU_ERR_HIP;
         }
-        const void* fns[8] = {reinterpret_cast<const void*>(&conv3x3_pl_kernel<0, false, true, false, true>),reinterpret_cast<const void*>(&conv3x3_pl_kernel<0, false>), reinterpret_cast<const void*>(&conv3x3_pl_kernel<0, true>),
+        const void* fns[9] = {reinterpret_cast<const void*>(&conv3x3_pl_kernel<0, false, false, false, true, false, true>), reinterpret_cast<const void*>(&conv3x3_pl_kernel<0, false, true, false, true>),reinterpret_cast<const void*>(&conv3x3_pl_kernel<0, false>), reinterpret_cast<const void*>(&conv3x3_pl_kernel<0, true>),
                               reinterpret_cast<const void*>(&conv3x3_pl_kernel<1, false>), reinterpret_cast<const void*>(&conv3x3_pl_kernel<4, false>),
                               reinterpret_cast<const void*>(&conv3x3_pl_kernel<0, false, false>),
                               reinterpret_cast<const void*>(&conv3x3_pl_kernel<0, false, true, true>), reinterpret_cast<const void*>(&conv3x3_pl_kernel<0, true, true, true>)};
@@ -782,7 +794,8 @@ int pl_launch(PlArgs a, bool first, hipStream_t s, bool grad = false) {
     }
     const int grid = a.ntiles < ncu ? a.ntiles : ncu;
     const dim3 g(grid), b(NT);
-    if (grad) hipLaunchKernelGGL((conv3x3_pl_kernel<0, false, true, false, true>), g, b, LDS_TOTAL, s, a);
+    if (grad && a.honly) hipLaunchKernelGGL((conv3x3_pl_kernel<0, false, false, false, true, false, true>), g, b, LDS_TOTAL, s, a);
+    else if (grad) hipLaunchKernelGGL((conv3x3_pl_kernel<0, false, true, false, true>), g, b, LDS_TOTAL, s, a);
     else if (first) {
         if (a.ypool) hipLaunchKernelGGL((conv3x3_pl_kernel<0, true, true, true>), g, b, LDS_TOTAL, s, a);
         else hipLaunchKernelGGL((conv3x3_pl_kernel<0, false, true, true>), g, b, LDS_TOTAL, s, a);
@@ -842,7 +855,7 @@ int wsu_conv3x3_pl_fwd(const void* x1, const void* x2, const void* w_packed, con
     a.ntiles = (int)nt;
     a.img = nullptr; a.w1 = nullptr; a.b1 = nullptr;
     a.y2 = nullptr; a.nco1 = cout / 16; a.mask = nullptr; a.mask2 = nullptr; a.imgs_per_wset = 0; a.wset_bytes = 0;
-    a.relu_mask_out = relu_mask_out; a.mbits = nullptr; a.mbits2 = nullptr;
+    a.relu_mask_out = relu_mask_out; a.mbits = nullptr; a.mbits2 = nullptr; a.honly = 0;
     return pl_launch(a, false, static_cast<hipStream_t>(stream));
 }
 
@@ -869,7 +882,7 @@ int wsu_conv3x3_pl_fused_first_fwd(const float* img, const float* w1, const floa
     WSU_REQUIRE(nt > 0 && nt < 0x3FFFFFFFLL, "conv3x3_pl_fused_first: %lld tiles out of range", nt);
     a.ntiles = (int)nt;
     a.y2 = nullptr; a.nco1 = cout / 16; a.mask = nullptr; a.mask2 = nullptr; a.imgs_per_wset = 0; a.wset_bytes = 0;
-    a.relu_mask_out = nullptr; a.mbits = nullptr; a.mbits2 = nullptr;
+    a.relu_mask_out = nullptr; a.mbits = nullptr; a.mbits2 = nullptr; a.honly = 0;
     return pl_launch(a, true, static_cast<hipStream_t>(stream));
 }
 
@@ -892,8 +905,9 @@ int wsu_ring_fold_pl(const void* strips_out, void* dx1, void* dx2, const void* m
 int wsu_conv3x3_pl_bwd_data(const void* g, const void* w_packed_dgrad, const void* w_packed_ring, void* workspace, size_t workspace_bytes,
                             void* dx1, void* dx2, int csplit, const void* mask1, const void* mask2,
                             const unsigned char* mask1_bits, const unsigned char* mask2_bits,
-                            int n, int h, int w, int cin, int cout, int pad_zero, void* stream) {
+                            int n, int h, int w, int cin, int cout, int pad_zero, int products, void* stream) {
     WSU_REQUIRE(g && w_packed_dgrad && dx1, "conv3x3_pl_bwd_data: null pointer");
+    WSU_REQUIRE(products == WSU_PRODUCTS_F16F8 || products == WSU_PRODUCTS_F16, "conv3x3_pl_bwd_data: products must be WSU_PRODUCTS_F16F8 or WSU_PRODUCTS_F16");
     WSU_REQUIRE(n > 0 && h >= 2 && w >= 2, "conv3x3_pl_bwd_data: bad shape n=%d h=%d w=%d", n, h, w);
     WSU_REQUIRE(cout >= 32 && cout % 16 == 0, "conv3x3_pl_bwd_data: cout=%d must be a multiple of 16 (>= 32)", cout);
     WSU_REQUIRE(cin > 0 && cin % WSU_COB == 0 && cin <= 1024, "conv3x3_pl_bwd_data: cin=%d must be a multiple of %d (<= 1024)", cin, WSU_COB);
@@ -909,7 +923,7 @@ int wsu_conv3x3_pl_bwd_data(const void* g, const void* w_packed_dgrad, const voi
     a.head_w = nullptr; a.head_b = nullptr; a.head_out = nullptr; a.head_logit = nullptr; a.head_cout = 0;
     a.range_flag = nullptr; a.xres = 1; a.img = nullptr; a.w1 = nullptr; a.b1 = nullptr;
     a.imgs_per_wset = 0; a.wset_bytes = 0;
-    a.relu_mask_out = nullptr; a.mbits = mask1_bits; a.mbits2 = mask2_bits;
+    a.relu_mask_out = nullptr; a.mbits = mask1_bits; a.mbits2 = mask2_bits; a.honly = products == WSU_PRODUCTS_F16 ? 1 : 0;
     a.n = n; a.h = h; a.w = w; a.c1 = cout; a.c2 = 0; a.cout = cin;
     a.tiles_x = (w + TW - 1) / TW; a.tiles_y = (h + TH - 1) / TH; a.ncb = cin / WSU_COB;
     a.nch1 = cout / 16; a.nch = cout / 16; a.relu = 0;

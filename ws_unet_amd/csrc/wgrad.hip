@@ -440,7 +440,8 @@ struct WgPlArgs {
     float* part; float* bpart;
     int n, hu, wu, cu, cv1, cv2;
     int tiles_x, tiles_y, ntiles, nsplit, nmb, nnb, tiles_per_split;
-    int ablate;                     // timing-only experiments (WSU_WGRAD_ABLATE; results wrong when != 0): 1 = no matrix section, 2 = staging of the first tile only
+    int honly;                      // 1: f16 products only (wsu.h WSU_PRODUCTS_F16; ring kernel variant HONLY)
+    int ablate;                     // timing-only experiments (WSU_WGRAD_ABLATE; results wrong when != 0): 1 = no matrix section, 2 = staging of the first tile only, 4 = no derived copies (the ring kernel's variant HONLY = products F16 is the product form of "no cross terms")
 };
 
 template <int KIND>
@@ -752,9 +753,12 @@ constexpr unsigned WGR_OOB = 0xFFFFFFF0u;                             // beyond 
 //     and read zeros.  Only tiles that cross the image's right / bottom edge take a per-step select (wave-uniform branch).
 //   * V pieces: per-lane offset = unit (chunk, plane) + reflected column, recomputed when the walk enters a new tile column; the two rows of
 //     the pair differ by a scalar (+- one image row): one multiply-add per piece and step.
-template <int LW>
+// HONLY (products = WSU_PRODUCTS_F16): the residual pieces (kinds 1, 3) are not fetched, no e4m3 copies are derived; the LDS layout stays.
+template <int LW, bool HONLY>
 __device__ __forceinline__ void wgr_loader(const WgPlArgs& a, char* smem, int lane, int split, int mb, int nb, int t0, int t1) {
     using namespace wgr;
+    constexpr auto fetched = [](int p) constexpr { return !HONLY || (wgr_kind(p) & 1) == 0; };
+    constexpr int NDMA = [&]() constexpr { int c = 0; for (int k = 0; k < PER; ++k) c += fetched(LW + NLOAD * k) ? 1 : 0; return c; }();   // DMA instructions per step
     const int L = LW * 64 + lane;
     const char* vsrc; int cv, vch0;
     if (nb * 64 < a.cv1) { vsrc = a.v1; cv = a.cv1; vch0 = nb * 64; }
@@ -776,7 +780,7 @@ __device__ __forceinline__ void wgr_loader(const WgPlArgs& a, char* smem, int la
         constexpr int half = wgr_pidx(p) / wgr_pph(kd), pih = wgr_pidx(p) % wgr_pph(kd);
         const int sidx = pih * 64 + lane;
         const int pxl = sidx / upr, u = sidx - pxl * upr;              // pixel, 16-byte unit inside the half-row
-        if (pxl < npx) alive |= 1u << k;
+        if (pxl < npx && fetched(p)) alive |= 1u << k;
         const int g = half * upr + u;                                   // unit of the whole 64-channel row
         const int chunk = (kd & 1) ? g : g >> 1, plane = (kd & 1) ? 2 : (g & 1);        // f16: unit = 2 chunk + plane; residual: unit = chunk
         const int r = pxl / roww, c = pxl - r * roww;
@@ -818,8 +822,9 @@ __device__ __forceinline__ void wgr_loader(const WgPlArgs& a, char* smem, int la
         lds_char_w* vs = smem3 + V_BASE + (k_step % NV) * V_SLOT;
         WSU_STATIC_FOR(PER, k, {
             constexpr int p = LW + NLOAD * k, kd = wgr_kind(p);
-            // every piece has live lanes (static layout): a wave issues exactly PER DMA instructions per step -- the vmcnt arithmetic below
-            if constexpr (kd < 2) {                                     // (a prologue step fetches its tile's U too -- unused, it keeps the piece count constant)
+            // every piece has live lanes (static layout): a wave issues exactly NDMA instructions per step -- the vmcnt arithmetic below
+            if constexpr (!fetched(p)) {
+            } else if constexpr (kd < 2) {                                     // (a prologue step fetches its tile's U too -- unused, it keeps the piece count constant)
                 unsigned vo = uoff[k];
                 if (!u_full) {
                     const bool inside = (rc[k] >> 8) < ulim_y && (rc[k] & 255) < ulim_x;
@@ -845,7 +850,7 @@ __device__ __forceinline__ void wgr_loader(const WgPlArgs& a, char* smem, int la
         char* vs = smem + V_BASE + (k_step % NV) * V_SLOT;
         WSU_STATIC_FOR(PER, k, {
             constexpr int p = LW + NLOAD * k, kd = wgr_kind(p);
-            if constexpr (kd == 0 || kd == 2) {
+            if constexpr (!HONLY && (kd == 0 || kd == 2)) {
                 if (alive & (1u << k)) {
                     char* img = kd == 0 ? us : vs;
                     const u32x4 hgr = *reinterpret_cast<const u32x4*>(img + wgr_piece_off(p) + lane * 16);
@@ -864,6 +869,11 @@ __device__ __forceinline__ void wgr_loader(const WgPlArgs& a, char* smem, int la
         for (int k = 0; k < 2; ++k) {
             const int p = (L & 31) + 32 * k;
             const u32x4 hq = *reinterpret_cast<const u32x4*>(us + U_HI + (cg >> 2) * U_HH + p * HROW + (cg & 3) * 16);
+            if constexpr (HONLY) {                                          // the residual image was not fetched: sums of the f16 parts
+                bs[0] = wsu_add_f16_lo(bs[0], hq.x); bs[1] = wsu_add_f16_hi(bs[1], hq.x); bs[2] = wsu_add_f16_lo(bs[2], hq.y); bs[3] = wsu_add_f16_hi(bs[3], hq.y);
+                bs[4] = wsu_add_f16_lo(bs[4], hq.z); bs[5] = wsu_add_f16_hi(bs[5], hq.z); bs[6] = wsu_add_f16_lo(bs[6], hq.w); bs[7] = wsu_add_f16_hi(bs[7], hq.w);
+                continue;
+            }
             const u32x2 rr = *reinterpret_cast<const u32x2*>(us + U_L8 + (cg >> 2) * U_BH + p * BROW + (cg & 3) * 8);
             const int r0 = (int)rr.x, r1 = (int)rr.y;
             // sum += f16 part (v_fma_mix_f32 reads the half directly) + residual * 2^-14: three instructions per value
@@ -876,11 +886,11 @@ __device__ __forceinline__ void wgr_loader(const WgPlArgs& a, char* smem, int la
     // Every existing step k gets exactly one barrier k on both sides, plus two closing barriers: S + 2 barriers per wave (S >= 2).
     // DMA of step k + DEPTH goes out behind barrier k; `ahead` = steps issued beyond the one being waited for (PER pieces each stay in flight).
     auto wait_all_but = [&](int ahead) __attribute__((always_inline)) {
-        if (ahead >= 2)      asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
-        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+        if (ahead >= 2)      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NDMA) : "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NDMA) : "memory");
         else                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
-    static_assert(PER == 7 && DEPTH == 3, "the vmcnt immediates above");
+    static_assert(DEPTH == 3 && 2 * NDMA < 64, "the vmcnt immediates above");
     WgrWalk wi = wgr_walk_at(a, t0);                                    // the walk position of the next DMA issue
     WgrWalk wb = wi;                                                    // the step whose barrier comes next (for the bias pass)
     int issued = 0;                                                     // steps issued so far
@@ -919,6 +929,7 @@ __device__ __forceinline__ void wgr_loader(const WgPlArgs& a, char* smem, int la
 }
 
 
+template <bool HONLY>
 __global__ __launch_bounds__(wgr::NTD) void wgrad_ring_kernel(const WgPlArgs a) {
     using namespace wgr;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -936,10 +947,10 @@ __global__ __launch_bounds__(wgr::NTD) void wgrad_ring_kernel(const WgPlArgs a) 
     if (wv >= NMAT) {
         // ================= loader waves (wgr_loader<LW>: the piece kinds of a wave are compile-time) =======================================
         switch (wv - NMAT) {
-            case 0: wgr_loader<0>(a, smem, lane, split, mb, nb, t0, t1); break;
-            case 1: wgr_loader<1>(a, smem, lane, split, mb, nb, t0, t1); break;
-            case 2: wgr_loader<2>(a, smem, lane, split, mb, nb, t0, t1); break;
-            default: wgr_loader<3>(a, smem, lane, split, mb, nb, t0, t1); break;
+            case 0: wgr_loader<0, HONLY>(a, smem, lane, split, mb, nb, t0, t1); break;
+            case 1: wgr_loader<1, HONLY>(a, smem, lane, split, mb, nb, t0, t1); break;
+            case 2: wgr_loader<2, HONLY>(a, smem, lane, split, mb, nb, t0, t1); break;
+            default: wgr_loader<3, HONLY>(a, smem, lane, split, mb, nb, t0, t1); break;
         }
         return;
     }
@@ -963,7 +974,8 @@ __global__ __launch_bounds__(wgr::NTD) void wgrad_ring_kernel(const WgPlArgs a) 
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 const u32x4 ah0 = wgr_frag16(u_hi, r * TW + 8 * hh), ah1 = wgr_frag16(u_hi, r * TW + 16 + 8 * hh);
-                const u32x4 a8 = wgr_frag8(u_c8, r * TW + 16 * hh), al8 = wgr_frag8(u_l8, r * TW + 16 * hh);
+                u32x4 a8 = mk_u4(0, 0, 0, 0), al8 = a8;
+                if constexpr (!HONLY) { a8 = wgr_frag8(u_c8, r * TW + 16 * hh); al8 = wgr_frag8(u_l8, r * TW + 16 * hh); }
                 const int i = r + ky;                                   // window row 0..3: rows 0, 1 came with step k-1, rows 2, 3 with step k
                 const char* vs = smem + V_BASE + ((i < 2 ? k + NV - 1 : k) % NV) * V_SLOT;
                 const char* v_hi = vs + V_HI + wn * V_HH; const char* v_c8 = vs + V_C8 + wn * V_BH; const char* v_l8 = vs + V_L8 + wn * V_BH;
@@ -971,8 +983,10 @@ __global__ __launch_bounds__(wgr::NTD) void wgrad_ring_kernel(const WgPlArgs a) 
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
                     const int vrow = vrow0 + kx;
-                    const u32x4 bl8 = wgr_frag8(v_l8, vrow + 16 * hh), b8 = wgr_frag8(v_c8, vrow + 16 * hh);
-                    wsu_mfma_f8x2(a8, al8, bl8, b8, sc_a, sc_b, acc[kx]);
+                    if constexpr (!HONLY) {
+                        const u32x4 bl8 = wgr_frag8(v_l8, vrow + 16 * hh), b8 = wgr_frag8(v_c8, vrow + 16 * hh);
+                        wsu_mfma_f8x2(a8, al8, bl8, b8, sc_a, sc_b, acc[kx]);
+                    }
                     const u32x4 bh0 = wgr_frag16(v_hi, vrow + 8 * hh), bh1 = wgr_frag16(v_hi, vrow + 16 + 8 * hh);
                     wsu_mfma_f16(ah0, bh0, acc[kx]);
                     wsu_mfma_f16(ah1, bh1, acc[kx]);
@@ -1138,13 +1152,15 @@ int run_wgrad_pl(WgPlArgs a, float* dw, float* db, float* workspace, size_t work
     a.ablate = ablate;
     static int impl = -1;                                              // WSU_WGRAD_IMPL=reg: the register-staged kernel (A/B runs)
     if (impl < 0) { const char* e = getenv("WSU_WGRAD_IMPL"); impl = (e && e[0] == 'r') ? 0 : 1; }
+    if (a.honly && !(KIND == 0 && impl == 1)) { wsu_set_error("wgrad_pl: products = WSU_PRODUCTS_F16 is built into the ring kernel only"); return WSU_ERR_UNSUPPORTED; }
     if (KIND == 0 && impl == 1) {
         // one persistent-style workgroup per CU: the splits cover the tiles, fewer and longer than the register-staged kernel's
         static int ncu = 0;
         if (ncu == 0) {
             int dev = 0; hipDeviceProp_t prop;
             if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { wsu_set_error("wgrad_ring: cannot query the device"); return WSU_ERR_HIP; }
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_ring_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, wgr::LDS_TOTAL);
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_ring_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, wgr::LDS_TOTAL);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_ring_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, wgr::LDS_TOTAL);
             if (e != hipSuccess) { wsu_set_error("hipFuncSetAttribute(wgrad_ring): %s", hipGetErrorString(e)); return WSU_ERR_HIP; }
             ncu = prop.multiProcessorCount;
         }
@@ -1153,7 +1169,8 @@ int run_wgrad_pl(WgPlArgs a, float* dw, float* db, float* workspace, size_t work
         a.nsplit = ns;
         a.tiles_per_split = (a.ntiles + ns - 1) / ns;
         a.bpart = db ? workspace + (size_t)ns * slab / sizeof(float) : nullptr;
-        hipLaunchKernelGGL(wgrad_ring_kernel, dim3(ns * a.nmb * a.nnb), dim3(wgr::NTD), wgr::LDS_TOTAL, s, a);
+        if (a.honly) hipLaunchKernelGGL(wgrad_ring_kernel<true>, dim3(ns * a.nmb * a.nnb), dim3(wgr::NTD), wgr::LDS_TOTAL, s, a);
+        else hipLaunchKernelGGL(wgrad_ring_kernel<false>, dim3(ns * a.nmb * a.nnb), dim3(wgr::NTD), wgr::LDS_TOTAL, s, a);
         int rc = wsu_check_launch("wgrad_ring_kernel");
         if (rc) return rc;
         hipLaunchKernelGGL(wgrad_reduce_kernel<KIND>, dim3(512), dim3(256), 0, s, a.part, (const float*)a.bpart, dw, a.bpart ? db : (float*)nullptr, ns, a.nmb, a.nnb, nbias);
@@ -1181,14 +1198,16 @@ extern "C" {
 // 2h x 2w), dw (cin, cout, 2, 2), db (cout) or NULL (sum of dy, taken while staging).  Channel counts multiples of 64.  Workspace:
 // wsu_wgrad_workspace_bytes.  Deterministic.
 int wsu_conv3x3_pl_bwd_weight(const void* g, const void* x1, const void* x2, float* dw, float* db, float* workspace, size_t workspace_bytes,
-                              int n, int h, int w, int c1, int c2, int cout, void* stream) {
+                              int n, int h, int w, int c1, int c2, int cout, int products, void* stream) {
     WSU_REQUIRE(g && x1 && dw && workspace, "conv3x3_pl_bwd_weight: null pointer");
+    WSU_REQUIRE(products == WSU_PRODUCTS_F16F8 || products == WSU_PRODUCTS_F16, "conv3x3_pl_bwd_weight: products must be WSU_PRODUCTS_F16F8 or WSU_PRODUCTS_F16");
     WSU_REQUIRE(n > 0 && h >= 2 && w >= 2, "conv3x3_pl_bwd_weight: bad shape");
     WSU_REQUIRE(c1 > 0 && c1 % 64 == 0 && c2 >= 0 && c2 % 64 == 0 && (c2 == 0) == (x2 == nullptr), "conv3x3_pl_bwd_weight: c1=%d c2=%d must be multiples of 64", c1, c2);
     WSU_REQUIRE(cout > 0 && cout % 64 == 0, "conv3x3_pl_bwd_weight: cout=%d must be a multiple of 64", cout);
     WSU_REQUIRE((long long)h * w * 192 < 0xFFFFFFF0LL, "conv3x3_pl_bwd_weight: h*w too large (the 12 planes of a 64-channel block must stay below 4 GiB)");
     WgPlArgs a{};
     a.u = (const char*)g; a.v1 = (const char*)x1; a.v2 = (const char*)x2; a.n = n; a.hu = h; a.wu = w; a.cu = cout; a.cv1 = c1; a.cv2 = c2;
+    a.honly = products == WSU_PRODUCTS_F16 ? 1 : 0;
     return run_wgrad_pl<0>(a, dw, db, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
 }
 

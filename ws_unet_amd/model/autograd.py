@@ -110,17 +110,18 @@ def _backward_pl(model, t: Dict[str, torch.Tensor], x: torch.Tensor, dout: torch
     """Backward of train_mode 'f16f8p': every gradient tensor planar (f16 + e4m3 residual, pre-scaled by a power of two), data gradients through
     the persistent LDS-DMA conv kernel, weight gradients from planar operands; the same layer walk as the fp32-storage path below."""
     W = ops.MODE_F16F8
+    products = getattr(model, "train_products", "f16f8")      # which terms the backward matrix kernels multiply (wsu.h WSU_PRODUCTS_*)
     grads: Dict[str, torch.Tensor] = {}
     scale = ops.pow2_grad_scale(dout)
     dout = ops.scale_by(dout, scale[0:1])
 
     def conv_bwd(name, g, x1, x2, mask1, need_dx=True, mask1_bits=None):
         layer = getattr(model, name)
-        grads[name + ".weight"], grads[name + ".bias"] = ops.conv3x3_pl_bwd_weight(g, x1, x2)
+        grads[name + ".weight"], grads[name + ".bias"] = ops.conv3x3_pl_bwd_weight(g, x1, x2, products=products)
         if not need_dx:
             return None, None
         return ops.conv3x3_pl_bwd_data(g, model._packed(name, W, "dgrad"), model._packed(name, W, "ring"), layer.in_channels,
-                                       x1.shape[1] * 16, mask1, None, mask1_bits=mask1_bits)
+                                       x1.shape[1] * 16, mask1, None, mask1_bits=mask1_bits, products=products)
 
     g, grads["outconv.weight"], grads["outconv.bias"] = ops.conv1x1_sigmoid_pl_bwd(t["last"], model.outconv.weight, t["out"], dout)
     skip_g: Dict[int, torch.Tensor] = {}

@@ -106,6 +106,14 @@ class UNet(nn.Module):
         # input gradient is asked for); else split-bf16 on fp32 tensors (~2^-16 relative per product -- finer than the TF32 convs PyTorch
         # trains with by default on the reference's GPUs)
         self.train_mode = os.environ.get("WSU_TRAIN_MODE") or ("f32" if self.mode == "f32" else "f16f8p" if self.mode in ("f16f8p", "f16f8q") else "bf16x3")
+        # train_mode 'f16f8p': the terms the BACKWARD matrix kernels (3x3 data and weight gradients) multiply -- 'f16' (default: exact products of
+        # the operands' f16 parts, fp32 accumulation; include/wsu.h WSU_PRODUCTS_*) or 'f16f8' (+ both residual cross terms, the forward's
+        # arithmetic).  The forward -- loss, predictions, ReLU masks -- is the same.  Why 'f16' is enough (profiles/r03/
+        # train_products.md): a gradient element is a sum of 10^3 .. 10^7 products whose operand roundings (2^-12 relative, unbiased) average
+        # out -- <= 2e-4 relative L2 per kernel on zero-mean random operands, the worst case -- while the forward's own rounding already puts
+        # ~1e-3 between any two arithmetics through ReLU-mask flips; 300 AdamW steps track exact fp32 as closely as 'f16f8' does.
+        self.train_products = os.environ.get("WSU_TRAIN_PRODUCTS") or "f16"
+        ops.products_id(self.train_products)
         # matrix layers of the training FORWARD when train_mode is 'bf16x3': 'f16f8x' (default) or 'bf16x3'
         self.train_fwd_mode = os.environ.get("WSU_TRAIN_FWD_MODE") or "f16f8x"
         self.train_bwd_mode = os.environ.get("WSU_TRAIN_BWD_MODE") or "f16f8x"     # data-gradient 3x3 convs: 'f16f8x' or 'bf16x3'

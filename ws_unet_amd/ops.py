@@ -368,11 +368,20 @@ def pack_conv3x3_ring(w: torch.Tensor) -> torch.Tensor:
     return out
 
 
+PRODUCTS = {"f16f8": 0, "f16": 1}                     # wsu.h WSU_PRODUCTS_F16F8 / WSU_PRODUCTS_F16
+
+
+def products_id(name: str) -> int:
+    if name not in PRODUCTS:
+        raise ValueError(f"products must be one of {sorted(PRODUCTS)} (got {name!r})")
+    return PRODUCTS[name]
+
+
 def conv3x3_pl_bwd_data(g: torch.Tensor, w_packed_dgrad: torch.Tensor, w_packed_ring: Optional[torch.Tensor], cin: int, csplit: int,
                         mask1: Optional[torch.Tensor] = None, mask2: Optional[torch.Tensor] = None, pad_zero: bool = False,
-                        mask1_bits: Optional[torch.Tensor] = None, mask2_bits: Optional[torch.Tensor] = None):
+                        mask1_bits: Optional[torch.Tensor] = None, mask2_bits: Optional[torch.Tensor] = None, products: str = "f16f8"):
     """Data gradient of the 3x3 conv on planar tensors (wsu_conv3x3_pl_bwd_data).  g: planar gradient (N, Cout/16, 3, H, W, 4); returns
-    dx1 (csplit channels) and dx2 (cin - csplit channels, or None), planar gradients."""
+    dx1 (csplit channels) and dx2 (cin - csplit channels, or None), planar gradients.  products: 'f16f8' | 'f16' (wsu.h WSU_PRODUCTS_*)."""
     lib = _lib.load()
     _dev_check(g, w_packed_dgrad, w_packed_ring, mask1, mask2, mask1_bits, mask2_bits)
     assert g.dtype == torch.float32 and g.dim() == 6 and g.shape[2] == PLANAR_PLANES and g.is_contiguous()
@@ -384,16 +393,17 @@ def conv3x3_pl_bwd_data(g: torch.Tensor, w_packed_dgrad: torch.Tensor, w_packed_
     dx2 = torch.empty(planar_shape(n, cin - csplit, h, w), dtype=torch.float32, device=g.device) if csplit < cin else None
     nbytes = 0 if pad_zero else lib.wsu_conv3x3_pl_bwd_data_workspace_bytes(n, h, w, cin, cout)
     ws = workspace(nbytes, g.device) if nbytes else None
-    meta = {"flops": 2.0 * 9 * cin * cout * n * h * w, "bytes": float(n * h * w * (cin * 5 + cout * 3))}
+    meta = {"flops": 2.0 * 9 * cin * cout * n * h * w, "bytes": float(n * h * w * (cin * 5 + cout * (2 if products == "f16" else 3)))}
     check(_launch("conv3x3_pl_bwd_data", meta, lambda: lib.wsu_conv3x3_pl_bwd_data(
         g.data_ptr(), w_packed_dgrad.data_ptr(), _ptr(w_packed_ring), _ptr(ws), 0 if ws is None else ws.numel() * 4,
         dx1.data_ptr(), _ptr(dx2), csplit, _ptr(mask1), _ptr(mask2), _ptr(mask1_bits), _ptr(mask2_bits), n, h, w, cin, cout, int(pad_zero),
-        _stream())), "wsu_conv3x3_pl_bwd_data")
+        products_id(products), _stream())), "wsu_conv3x3_pl_bwd_data")
     return dx1, dx2
 
 
-def conv3x3_pl_bwd_weight(g: torch.Tensor, x1: torch.Tensor, x2: Optional[torch.Tensor], want_bias: bool = True):
-    """Weight / bias gradient of the 3x3 conv on planar operands (wsu_conv3x3_pl_bwd_weight): g planar gradient, x1 / x2 planar inputs."""
+def conv3x3_pl_bwd_weight(g: torch.Tensor, x1: torch.Tensor, x2: Optional[torch.Tensor], want_bias: bool = True, products: str = "f16f8"):
+    """Weight / bias gradient of the 3x3 conv on planar operands (wsu_conv3x3_pl_bwd_weight): g planar gradient, x1 / x2 planar inputs.
+    products: 'f16f8' | 'f16' (wsu.h WSU_PRODUCTS_*)."""
     lib = _lib.load()
     _dev_check(g, x1, x2)
     n, nco, _, h, w, _ = g.shape
@@ -402,10 +412,11 @@ def conv3x3_pl_bwd_weight(g: torch.Tensor, x1: torch.Tensor, x2: Optional[torch.
     dw = torch.empty((cout, c1 + c2, 3, 3), dtype=torch.float32, device=g.device)
     db = torch.empty(cout, dtype=torch.float32, device=g.device) if want_bias else None
     ws = workspace(lib.wsu_wgrad_workspace_bytes(cout, c1 + c2, 9), g.device)
-    meta = {"flops": 2.0 * 9 * (c1 + c2) * cout * n * h * w, "bytes": float(n * h * w * 3 * (cout * ((c1 + c2) // 64) + (c1 + c2) * (cout // 64)))}
+    meta = {"flops": 2.0 * 9 * (c1 + c2) * cout * n * h * w,
+            "bytes": float(n * h * w * (2 if products == "f16" else 3) * (cout * ((c1 + c2) // 64) + (c1 + c2) * (cout // 64)))}
     check(_launch("conv3x3_pl_bwd_weight", meta, lambda: lib.wsu_conv3x3_pl_bwd_weight(
         g.data_ptr(), x1.data_ptr(), _ptr(x2), dw.data_ptr(), _ptr(db), ws.data_ptr(), ws.numel() * 4,
-        n, h, w, c1, c2, cout, _stream())), "wsu_conv3x3_pl_bwd_weight")
+        n, h, w, c1, c2, cout, products_id(products), _stream())), "wsu_conv3x3_pl_bwd_weight")
     return dw, db
 
 
