@@ -57,7 +57,7 @@ extern "C" {
 
 enum { WSU_MODE_F32 = 0, WSU_MODE_BF16X3 = 1, WSU_MODE_BF16 = 2, WSU_MODE_BF16X3S = 3, WSU_MODE_F16F8 = 4, WSU_MODE_F16F8X = 5 };
 
-/* `products` of the planar BACKWARD matrix kernels (wsu_conv3x3_pl_bwd_data, wsu_conv3x3_pl_bwd_weight) -- which terms of
+/* `products` of the planar BACKWARD matrix kernels (wsu_conv3x3_pl_bwd_data / _bwd_weight, wsu_convt2x2_pl_bwd_data / _bwd_weight) -- which terms of
  * (f16 a + residual a)(f16 b + residual b) are multiplied:
  *      WSU_PRODUCTS_F16F8 = 0  f16 a * f16 b on the f16 pipe + both residual cross terms on the block-scaled fp8 pipe (the forward's arithmetic,
  *                              ~2^-16 per product; 19 matrix units per 9 of plain f16 in the data gradient, 4 per 2 in the weight gradient);
@@ -183,16 +183,17 @@ int wsu_conv3x3_pl_bwd_data(const void* g, const void* w_packed_dgrad, const voi
  *      conv: g (cout channels, planar gradient), x1 / x2 (the layer's saved planar inputs, c1 / c2 channels), dw (cout, c1 + c2, 3, 3), db (cout) or
  *      NULL (sum of the decoded gradient values, fixed order).  Transposed conv: x (cin channels at h x w), dy (cout channels, planar gradient at
  *      2h x 2w), dw (cin, cout, 2, 2), db (cout) or NULL.  All channel counts multiples of 64; workspace >= wsu_wgrad_workspace_bytes.  Deterministic.
- *      products (conv): WSU_PRODUCTS_F16F8 or WSU_PRODUCTS_F16 (above; db is then the sum of the gradient's f16 parts). */
+ *      products: WSU_PRODUCTS_F16F8 or WSU_PRODUCTS_F16 (above; db is then the sum of the gradient's f16 parts). */
 int wsu_conv3x3_pl_bwd_weight(const void* g, const void* x1, const void* x2, float* dw, float* db, float* workspace, size_t workspace_bytes,
                               int n, int h, int w, int c1, int c2, int cout, int products, void* stream);
 int wsu_convt2x2_pl_bwd_weight(const void* x, const void* dy, float* dw, float* db, float* workspace, size_t workspace_bytes,
-                               int n, int h, int w, int cin, int cout, void* stream);
+                               int n, int h, int w, int cin, int cout, int products, void* stream);
 
 /* ---- K7p: the other backward kernels of the planar training path (csrc/planar.hip, csrc/train_pl.hip; autograd of unet.py:137-189).
  *      wsu_convt2x2_pl_bwd_data: dx[n,i,j,ci] = sum dy[n,2i+a,2j+b,co] w[ci,co,a,b] times the ReLU mask of the layer below (mask: the planar
  *        ACTIVATION the transposed conv consumed, optional); dy (cout channels at 2h x 2w) and dx (cin at h x w) planar gradients; weights from
- *        wsu_convt2x2_pl_pack_dgrad (cin * cout * 16 bytes); cin a multiple of 64, cout of 16.
+ *        wsu_convt2x2_pl_pack_dgrad (cin * cout * 16 bytes); cin a multiple of 64, cout of 16; products as above (WSU_PRODUCTS_F16: only the
+ *        f16 planes of dy and of the weights travel, six LDS stages instead of three).
  *      wsu_maxpool2x2_pl_bwd: g = (skip_g + routing of dy_pool onto the first maximum of each 2x2 window) * (act > 0); act = the stored activation
  *        the pool consumed (the argmax is recomputed from it); skip_g optional; g may alias skip_g.
  *      wsu_conv1x1_sigmoid_pl_bwd: head backward (unet.py:186-188): x planar activation (c in {16..128}), w (cout <= 4, c), out / dout (N, cout, H, W)
@@ -202,7 +203,7 @@ int wsu_convt2x2_pl_bwd_weight(const void* x, const void* dy, float* dw, float* 
  *      All reductions are two-stage with a fixed order (deterministic). */
 int wsu_convt2x2_pl_pack_dgrad(const float* w_iohw, void* w_packed, int cin, int cout, void* stream);
 int wsu_convt2x2_pl_bwd_data(const void* dy, const void* w_packed_dgrad, void* dx, const void* mask,
-                             int n, int h, int w, int cin, int cout, void* stream);
+                             int n, int h, int w, int cin, int cout, int products, void* stream);
 int wsu_maxpool2x2_pl_bwd(const void* skip_g, const void* dy_pool, const void* act, void* g, int n, int h, int w, int c, void* stream);
 size_t wsu_head_pl_bwd_workspace_bytes(int c, int cout);
 int wsu_conv1x1_sigmoid_pl_bwd(const void* x, const float* w, const float* out, const float* dout, void* g, float* dw, float* db,

@@ -33,6 +33,11 @@ def _rand(shape, seed, scale=1.0):
     return torch.randn(shape, generator=g) * scale
 
 
+def _h(t):
+    """what the f16 planes of a planar tensor hold for t"""
+    return t.half().float()
+
+
 def _q(t, lo):
     """the values a planar tensor holds for t"""
     return planar_decode(planar_encode(t, lo), lo)
@@ -157,11 +162,6 @@ def test_conv3x3_pl_bwd_weight(n, h, w, c1, c2, cout):
     assert torch.equal(dw, dw2)                                        # fixed-order reduction
 
 
-def _h(t):
-    """what the f16 planes of a planar tensor hold for t"""
-    return t.half().float()
-
-
 @pytest.mark.parametrize("n,h,w,cin,csplit,cout,masked,pad_zero", [
     (2, 16, 32, 64, 64, 64, False, True),
     (1, 40, 72, 64, 64, 64, True, False),       # partial tiles, border ring
@@ -250,35 +250,62 @@ def test_planar_backward_kernels_race_screen():
         assert torch.equal(dx.view(torch.int32), dx0.view(torch.int32))
 
 
-@pytest.mark.parametrize("n,h,w,cin,cout", [(2, 8, 32, 64, 64), (1, 13, 40, 128, 64), (2, 5, 7, 64, 128)])
-def test_convt2x2_pl_bwd_weight(n, h, w, cin, cout):
+@pytest.mark.parametrize("products", ["f16f8", "f16"])
+@pytest.mark.parametrize("n,h,w,cin,cout", [
+    (2, 8, 32, 64, 64), (1, 13, 40, 128, 64), (2, 5, 7, 64, 128), (3, 64, 96, 64, 64),
+    (1, 100, 64, 256, 128),             # 8 (mb, nb) workgroups per split: 64 splits of 1-2 tiles (the register prefetch runs), the last ones empty
+])
+def test_convt2x2_pl_bwd_weight(n, h, w, cin, cout, products):
+    """products 'f16': exact products of the f16 parts (reference on f16-rounded operands: 5e-6), ~2e-4 from the unrounded gradient on
+    these zero-mean random operands; db = the sum of dy's f16 parts."""
     ops = _ops()
     x = _q(torch.relu(_rand((n, cin, h, w), 7)), 4096.0)
     dy = _q(_rand((n, cout, 2 * h, 2 * w), 8), GRAD_LO)
-    wgt = torch.zeros((cin, cout, 2, 2), requires_grad=True)
-    b = torch.zeros(cout, requires_grad=True)
-    F.conv_transpose2d(x, wgt, b, stride=2).backward(dy)
-    dw, db = ops.convt2x2_pl_bwd_weight(planar_encode(x), planar_encode(dy, GRAD_LO))
+    refs = []
+    for xx, dd in ((x, dy), (_h(x), _h(dy))):
+        wgt = torch.zeros((cin, cout, 2, 2), dtype=torch.float64, requires_grad=True)
+        b = torch.zeros(cout, dtype=torch.float64, requires_grad=True)
+        F.conv_transpose2d(xx.double(), wgt, b, stride=2).backward(dd.double())
+        refs.append((wgt.grad, b.grad))
+    dw, db = ops.convt2x2_pl_bwd_weight(planar_encode(x), planar_encode(dy, GRAD_LO), products=products)
     torch.cuda.synchronize()
-    assert rel_l2(dw.cpu(), wgt.grad) < REL_L2, rel_l2(dw.cpu(), wgt.grad)
-    assert rel_l2(db.cpu(), b.grad) < 2e-6, rel_l2(db.cpu(), b.grad)       # partial tiles: clamped copies of edge pixels are not summed
+    if products == "f16":
+        assert rel_l2(dw.cpu(), refs[1][0]) < 5e-6, rel_l2(dw.cpu(), refs[1][0])
+        assert rel_l2(db.cpu(), refs[1][1]) < 2e-6, rel_l2(db.cpu(), refs[1][1])
+        assert rel_l2(dw.cpu(), refs[0][0]) < 5e-4, rel_l2(dw.cpu(), refs[0][0])
+    else:
+        assert rel_l2(dw.cpu(), refs[0][0]) < REL_L2, rel_l2(dw.cpu(), refs[0][0])
+        assert rel_l2(db.cpu(), refs[0][1]) < 2e-6, rel_l2(db.cpu(), refs[0][1])   # partial tiles: clamped copies of edge pixels are not summed
 
 
-@pytest.mark.parametrize("n,h,w,cin,cout,masked", [(2, 8, 32, 64, 64, True), (1, 13, 40, 128, 64, True), (2, 5, 7, 64, 32, False), (1, 4, 64, 256, 128, True)])
-def test_convt2x2_pl_bwd_data(n, h, w, cin, cout, masked):
+@pytest.mark.parametrize("products", ["f16f8", "f16"])
+@pytest.mark.parametrize("n,h,w,cin,cout,masked", [
+    (2, 8, 32, 64, 64, True), (1, 13, 40, 128, 64, True), (2, 5, 7, 64, 32, False), (1, 4, 64, 256, 128, True),
+    (5, 64, 128, 64, 32, True),         # 320 tiles of 2 steps: workgroups walk 1-2 tiles, the six-stage ring of products 'f16' fills and drains
+    (3, 60, 100, 64, 112, False),       # 7 steps per tile (the ring wraps inside a tile), partial tiles
+])
+def test_convt2x2_pl_bwd_data(n, h, w, cin, cout, masked, products):
+    """products 'f16': only the f16 planes of dy and of the weights are fetched and multiplied (reference on f16-rounded operands: 2e-5, the
+    store encoding), six LDS stages instead of three."""
     ops = _ops()
     wgt = _rand((cin, cout, 2, 2), 9, (1.0 / cin) ** 0.5)
     dy = _q(_rand((n, cout, 2 * h, 2 * w), 10), GRAD_LO)
     act = torch.relu(_rand((n, cin, h, w), 11))
-    x = torch.zeros((n, cin, h, w), requires_grad=True)
-    F.conv_transpose2d(x, wgt, stride=2).backward(dy)
-    ref = x.grad * (act > 0) if masked else x.grad
+    refs = []
+    for ww, dd in ((wgt, dy), (_h(wgt), _h(dy))):
+        x = torch.zeros((n, cin, h, w), dtype=torch.float64, requires_grad=True)
+        F.conv_transpose2d(x, ww.double(), stride=2).backward(dd.double())
+        refs.append(x.grad * (act > 0) if masked else x.grad)
     wp = ops.pack_convt2x2_pl_dgrad(wgt.to(DEV))
-    dx = ops.convt2x2_pl_bwd_data(planar_encode(dy, GRAD_LO), wp, cin, planar_encode(act) if masked else None)
+    dx = ops.convt2x2_pl_bwd_data(planar_encode(dy, GRAD_LO), wp, cin, planar_encode(act) if masked else None, products=products)
     torch.cuda.synchronize()
     got = planar_decode(dx, GRAD_LO)
-    assert rel_l2(got, ref) < REL_L2, rel_l2(got, ref)
-    assert float((got - ref).abs().max()) < 2e-3 * float(ref.abs().max())
+    if products == "f16":
+        assert rel_l2(got, refs[1]) < 2e-5, rel_l2(got, refs[1])
+        assert rel_l2(got, refs[0]) < 5e-4, rel_l2(got, refs[0])
+    else:
+        assert rel_l2(got, refs[0]) < REL_L2, rel_l2(got, refs[0])
+        assert float((got - refs[0]).abs().max()) < 2e-3 * float(refs[0].abs().max())
 
 
 @pytest.mark.parametrize("with_skip", [True, False])

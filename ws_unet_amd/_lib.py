@@ -55,9 +55,9 @@ SIGNATURES = {
     "wsu_conv3x3_pack_ring": (c_int, [_P, _P, c_int, c_int, _P]),
     "wsu_conv3x3_pl_bwd_data": (c_int, [_P, _P, _P, _P, c_size_t, _P, _P, c_int, _P, _P, _P, _P] + [c_int] * 7 + [_P]),
     "wsu_conv3x3_pl_bwd_weight": (c_int, [_P] * 6 + [c_size_t] + [c_int] * 7 + [_P]),
-    "wsu_convt2x2_pl_bwd_weight": (c_int, [_P] * 5 + [c_size_t] + [c_int] * 5 + [_P]),
+    "wsu_convt2x2_pl_bwd_weight": (c_int, [_P] * 5 + [c_size_t] + [c_int] * 6 + [_P]),
     "wsu_convt2x2_pl_pack_dgrad": (c_int, [_P, _P, c_int, c_int, _P]),
-    "wsu_convt2x2_pl_bwd_data": (c_int, [_P] * 4 + [c_int] * 5 + [_P]),
+    "wsu_convt2x2_pl_bwd_data": (c_int, [_P] * 4 + [c_int] * 6 + [_P]),
     "wsu_maxpool2x2_pl_bwd": (c_int, [_P] * 4 + [c_int] * 4 + [_P]),
     "wsu_head_pl_bwd_workspace_bytes": (c_size_t, [c_int, c_int]),
     "wsu_conv1x1_sigmoid_pl_bwd": (c_int, [_P] * 8 + [c_size_t] + [c_int] * 5 + [_P]),

@@ -259,8 +259,8 @@ __global__ __launch_bounds__(ct::NT) void convt2x2_pl_kernel(const CtpArgs a) {
 // K7p.  Data gradient of the transposed conv (autograd of unet.py:177,183):  dx[n, i, j, ci] = sum_{a,b,co} dy[n, 2i+a, 2j+b, co] * w[ci, co, a, b],
 // times the ReLU mask of the layer below.  GEMM M = 64 ci, N = 4 x 32 input-resolution pixels, K = 4 sub-positions x Cout; persistent
 // workgroup per CU: 8 matrix waves (32 ci x one tile row each) + 8 loader waves (the kernel is DMA-issue / HBM bound: 40 pieces per chunk).
-// The dy tile (8 x 64 output pixels) arrives DE-INTERLEAVED -- each DMA lane fetches pixel (2 (y0 + r) + a, 2 (x0 + c) + b), so the LDS image is
-// [plane][sub-position][128 px][16 B] and every B-operand read is a contiguous 512 bytes.  Weights [sub][plane][64 ci][16 B] per chunk from
+// The dy tile (8 x 64 output pixels) arrives row by row -- LDS image [plane][row parity a][tile row r][64 output px][16 B] -- and the B-operand
+// read of sub-position (a, b) takes every other granule of a row (ctb_loader explains why the de-interleaving moved from the DMA to the read).  Weights [sub][plane][64 ci][16 B] per chunk from
 // wsu_convt2x2_pl_pack_dgrad.  Gradient encodings in and out (wsu_device.h).
 // =====================================================================================================================================
 namespace ctb {
@@ -291,14 +291,32 @@ __device__ __forceinline__ CtTile ctb_tile_of(const CtbPlArgs& a, int t) {
     return r;
 }
 
-// Loader wave LW (0..7) of the transposed conv's data gradient: slot = LW + 8 k -> k = 0..2 are the wave's three input pieces (plane k of ONE
-// (sub-position, 64-pixel segment) pair: sub = (LW >> 1) & 3, seg = LW & 1 -- so a lane has ONE pixel offset per tile), k = 3, 4 its two
-// weight pieces.  Descriptors + scalar plane offsets as in ct_issue_dma.
-template <int LW>
+// Loader wave LW (0..7) of the transposed conv's data gradient: its input pieces are the planes of ONE output row of the tile -- row parity
+// a = (LW >> 2) & 1, tile row r = LW & 3 -- 64 CONSECUTIVE output pixels per piece (both column parities; so a lane has one pixel offset per
+// tile), then its weight pieces.  Descriptors + scalar plane offsets as in ct_issue_dma.
+// (Round 2 / early round 3 de-interleaved while fetching -- a piece = every other pixel of a row, the LDS image [plane][sub][128 px] -- so every
+// DMA instruction used 16 of each 32 bytes it touched and the L2 -> CU path carried the rows twice: 3.2 - 3.4 TB/s of HBM traffic whatever the
+// pipeline depth.  Now the LDS image is [plane][a][r][64 output px] and the B-operand reads take the stride of 2 granules instead.)
+// HONLY (products = WSU_PRODUCTS_F16, round 3): only the f16 planes of dy and of the weights travel -- 16 + 8 KB instead of 32 + 16 KB per step,
+// so SIX stages fit and the DMA runs five steps ahead (80 KB of dy in flight per CU instead of 48: the kernel is HBM-latency bound).
+template <bool HONLY> struct CtbGeo {
+    static constexpr int NPL = HONLY ? 2 : 3;                          // dy planes fetched
+    static constexpr int IN1 = (HONLY ? 2 : 4) * 4 * ctb::NPIX * 16;   // [plane][a 2][r 4][64 output px][16 B]
+    static constexpr int W1L = HONLY ? ctb::W1 / 2 : ctb::W1;          // HONLY: [sub 4][plane 2][64 ci][16 B]
+    static constexpr int STAGE = IN1 + W1L;
+    static constexpr int NSTAGE = HONLY ? 6 : 3;
+    static constexpr int LDS_TOTAL = NSTAGE * STAGE;
+    static constexpr int PER = HONLY ? 3 : 5;                          // DMA instructions per loader wave and step
+};
+static_assert(CtbGeo<false>::STAGE == ctb::STAGE && CtbGeo<false>::LDS_TOTAL == ctb::LDS_TOTAL && CtbGeo<true>::LDS_TOTAL <= 160 * 1024 - 1024, "LDS budget");
+
+template <int LW, bool HONLY>
 __device__ __forceinline__ void ctb_loader(const CtbPlArgs& a, char* smem, int lane, int lw, int G, int J) {
     using namespace ctb;
-    static_assert(PER == 5 && IN_SLOTS == 24 && NLOAD == 8, "the slot arithmetic and the vmcnt immediate below");   // every piece has live lanes: PER DMA instructions per wave and step
-    constexpr int sub = (LW >> 1) & 3, seg = LW & 1;
+    using GEO = CtbGeo<HONLY>;
+    static_assert(PER == 5 && IN_SLOTS == 24 && NLOAD == 8, "the slot arithmetic and the vmcnt immediates below");   // every piece has live lanes: GEO::PER DMA instructions per wave and step
+    constexpr int pa = (LW >> 2) & 1, pr = LW & 3;
+    constexpr int AHEAD = GEO::NSTAGE - 1;                              // the DMA of step j + AHEAD goes out behind barrier j
     lds_char* smem3 = (lds_char*)smem;
     const int oh = 2 * a.h, ow = 2 * a.w;
     const unsigned ohw16 = (unsigned)(oh * ow) * 16u;
@@ -306,50 +324,65 @@ __device__ __forceinline__ void ctb_loader(const CtbPlArgs& a, char* smem, int l
     int c = 0, kt = 0;
     unsigned pixoff = 0;
     auto plan = [&]() __attribute__((always_inline)) {
-        const int pix = seg * 64 + lane;
-        const int oy = min(2 * (t.y0 + pix / TW) + (sub >> 1), oh - 1), ox = min(2 * (t.x0 + pix % TW) + (sub & 1), ow - 1);
+        const int oy = min(2 * (t.y0 + pr) + pa, oh - 1), ox = min(2 * t.x0 + lane, ow - 1);
         pixoff = (unsigned)(oy * ow + ox) * 16u;
     };
     plan();
     const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(a.wp), 0, 0x7FFFFFF0, 0x00020000);
     const unsigned lane16 = (unsigned)lane * 16u;
     auto issue_next = [&](int j_issue) __attribute__((always_inline)) {
-        lds_char* st = smem3 + (j_issue % NSTAGE) * STAGE;
+        lds_char* st = smem3 + (j_issue % GEO::NSTAGE) * GEO::STAGE;
         const char* in_base = a.dy + ((size_t)t.n * a.nch + c) * 3 * ohw16;
         const auto rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(in_base), 0, (int)(3u * ohw16), 0x00020000);
         const int w_base = (t.cb * a.nch + c) * W1;
-        WSU_STATIC_FOR(3, plane, {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void*)(st + ((plane * 4 + sub) * NPIX + seg * 64) * 16), 16, pixoff, (int)(plane * ohw16), 0, 0);
+        WSU_STATIC_FOR(GEO::NPL, plane, {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void*)(st + (((plane * 2 + pa) * 4 + pr) * 64) * 16), 16, pixoff, (int)(plane * ohw16), 0, 0);
         });
-        WSU_STATIC_FOR(2, k, {
-            constexpr int piece = LW + NLOAD * k;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void*)(st + IN1 + piece * 1024), 16, lane16, w_base + piece * 1024, 0, 0);
-        });
+        if constexpr (HONLY) {                                          // packed piece (sub, plane) = sub * 4 + plane, planes 0 / 1 only: wave LW takes (LW >> 1, LW & 1)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void*)(st + GEO::IN1 + LW * 1024), 16, lane16, w_base + ((LW >> 1) * 4 + (LW & 1)) * 1024, 0, 0);
+        } else {
+            WSU_STATIC_FOR(2, k, {
+                constexpr int piece = LW + NLOAD * k;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void*)(st + GEO::IN1 + piece * 1024), 16, lane16, w_base + piece * 1024, 0, 0);
+            });
+        }
         if (++c == a.nch) { c = 0; ++kt; t = ctb_tile_of(a, lw + kt * G); plan(); }
     };
-    if (J > 0) issue_next(0);
-    if (J > 1) issue_next(1);
+    for (int k = 0; k < AHEAD && k < J; ++k) issue_next(k);
     for (int j = 0; j < J; ++j) {
-        if (j + 1 < J) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");   // my pieces of step j landed, step j+1's stay in flight
-        else           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        {   // LDS plane 3 = e4m3(g * 4) of the f16 granules this wave fetched
-            char* st = smem + (j % NSTAGE) * STAGE;
-            const int pix = seg * 64 + lane;
+        // my pieces of step j landed; those of the steps issued behind it (at most AHEAD - 1 of them) stay in flight
+        const int ahead = min(J - 1 - j, AHEAD - 1);
+        if constexpr (HONLY) {
+            static_assert(GEO::PER == 3 && AHEAD == 5, "vmcnt immediates");
+            if (ahead >= 4)      asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else if (ahead == 3) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+            else if (ahead == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            static_assert(HONLY || (GEO::PER == 5 && AHEAD == 2), "vmcnt immediates");
+            if (ahead >= 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            else            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        if constexpr (!HONLY) {   // LDS plane 3 = e4m3(g * 4) of the f16 granules this wave fetched
+            char* st = smem + (j % GEO::NSTAGE) * GEO::STAGE;
 #pragma unroll
             for (int plane = 0; plane < 2; ++plane) {
-                const u32x4 hgr = *reinterpret_cast<const u32x4*>(st + ((plane * 4 + sub) * NPIX + pix) * 16);
-                *reinterpret_cast<u32x2*>(st + ((3 * 4 + sub) * NPIX + pix) * 16 + plane * 8) = wsu_f16x8_to_fp8_grad(hgr);
+                const u32x4 hgr = *reinterpret_cast<const u32x4*>(st + ((((plane * 2 + pa) * 4 + pr) * 64) + lane) * 16);
+                *reinterpret_cast<u32x2*>(st + ((((3 * 2 + pa) * 4 + pr) * 64) + lane) * 16 + plane * 8) = wsu_f16x8_to_fp8_grad(hgr);
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (j + 2 < J) issue_next(j + 2);                               // its stage held step j-1: every matrix wave is past it
+        if (j + AHEAD < J) issue_next(j + AHEAD);                       // its stage held step j-1: every matrix wave is past it
     }
 }
 
+template <bool HONLY>
 __global__ __launch_bounds__(ctb::NT) void convt2x2_bwd_pl_kernel(const CtbPlArgs a) {
     using namespace ctb;
+    using GEO = CtbGeo<HONLY>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
@@ -360,14 +393,14 @@ __global__ __launch_bounds__(ctb::NT) void convt2x2_bwd_pl_kernel(const CtbPlArg
 
     if (wv >= NWAVE) {
         switch (wv - NWAVE) {
-            case 0: ctb_loader<0>(a, smem, lane, lw, G, J); break;
-            case 1: ctb_loader<1>(a, smem, lane, lw, G, J); break;
-            case 2: ctb_loader<2>(a, smem, lane, lw, G, J); break;
-            case 3: ctb_loader<3>(a, smem, lane, lw, G, J); break;
-            case 4: ctb_loader<4>(a, smem, lane, lw, G, J); break;
-            case 5: ctb_loader<5>(a, smem, lane, lw, G, J); break;
-            case 6: ctb_loader<6>(a, smem, lane, lw, G, J); break;
-            default: ctb_loader<7>(a, smem, lane, lw, G, J); break;
+            case 0: ctb_loader<0, HONLY>(a, smem, lane, lw, G, J); break;
+            case 1: ctb_loader<1, HONLY>(a, smem, lane, lw, G, J); break;
+            case 2: ctb_loader<2, HONLY>(a, smem, lane, lw, G, J); break;
+            case 3: ctb_loader<3, HONLY>(a, smem, lane, lw, G, J); break;
+            case 4: ctb_loader<4, HONLY>(a, smem, lane, lw, G, J); break;
+            case 5: ctb_loader<5, HONLY>(a, smem, lane, lw, G, J); break;
+            case 6: ctb_loader<6, HONLY>(a, smem, lane, lw, G, J); break;
+            default: ctb_loader<7, HONLY>(a, smem, lane, lw, G, J); break;
         }
         return;
     }
@@ -383,13 +416,14 @@ __global__ __launch_bounds__(ctb::NT) void convt2x2_bwd_pl_kernel(const CtbPlArg
     for (int j = 0; j < J; ++j) {
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        const char* st = smem + (j % NSTAGE) * STAGE;
+        const char* st = smem + (j % GEO::NSTAGE) * GEO::STAGE;
         if (c == 0) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         }
         const int irow = cur.y0 + row, icol = cur.x0 + l31;
-        if (c + 1 == a.nch && a.mask) {                                  // the tile's mask values travel during its last matrix section
+        if (c == 0 && a.mask) {                                          // the tile's mask values travel during ALL its matrix sections (fetched in the
+                                                                         // last one -- 4 to 6 MFMAs -- the epilogue sat out an HBM latency per tile)
             const int yy = min(irow, a.h - 1), xx = min(icol, a.w - 1);
 #pragma unroll
             for (int cp = 0; cp < 2; ++cp)
@@ -397,21 +431,31 @@ __global__ __launch_bounds__(ctb::NT) void convt2x2_bwd_pl_kernel(const CtbPlArg
                 for (int pl = 0; pl < 2; ++pl)
                     mk[cp][pl] = *reinterpret_cast<const u32x2*>(a.mask + ((((size_t)cur.n * nci + cur.cb * 4 + mh * 2 + cp) * 3 + pl) * hw + (size_t)yy * a.w + xx) * 16 + hh * 8);
         }
-        const char* ldsA = st + IN1 + (mh * 32 + l31) * 16;            // + ((sub * 4 + plane) * 64) * 16
-        const char* ldsB = st + (row * TW + l31) * 16;                  // + ((plane * 4 + sub) * NPIX) * 16
+        const char* ldsA = st + GEO::IN1 + (mh * 32 + l31) * 16;       // + ((sub * 4 + plane) * 64) * 16   (HONLY: (sub * 2 + plane))
+        const char* ldsB = st + (row * 64 + 2 * l31) * 16;              // + (((plane * 2 + a) * 4) * 64 + b) * 16, sub = 2 a + b
+        auto boff = [](int plane, int sub) constexpr { return (((plane * 2 + (sub >> 1)) * 4) * 64 + (sub & 1)) * 16; };
+        if constexpr (HONLY) {
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) {
+                const u32x4 ah = *reinterpret_cast<const u32x4*>(ldsA + ((s2 * 2 + hh) * 64) * 16);
+                const u32x4 bh = *reinterpret_cast<const u32x4*>(ldsB + boff(hh, s2));
+                wsu_mfma_f16(ah, bh, acc);
+            }
+        } else {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int s = 2 * t + hh;
             const u32x4 a0 = *reinterpret_cast<const u32x4*>(ldsA + ((s * 4 + 2) * 64) * 16), a1 = *reinterpret_cast<const u32x4*>(ldsA + ((s * 4 + 3) * 64) * 16);
-            const u32x4 b0 = *reinterpret_cast<const u32x4*>(ldsB + ((2 * 4 + s) * NPIX) * 16), b1 = *reinterpret_cast<const u32x4*>(ldsB + ((3 * 4 + s) * NPIX) * 16);
+            const u32x4 b0 = *reinterpret_cast<const u32x4*>(ldsB + boff(2, s)), b1 = *reinterpret_cast<const u32x4*>(ldsB + boff(3, s));
             wsu_mfma_f8x2(a0, a1, b0, b1, sc_a, sc_b, acc);
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int s2 = 2 * t + u;
                 const u32x4 ah = *reinterpret_cast<const u32x4*>(ldsA + ((s2 * 4 + hh) * 64) * 16);
-                const u32x4 bh = *reinterpret_cast<const u32x4*>(ldsB + ((hh * 4 + s2) * NPIX) * 16);
+                const u32x4 bh = *reinterpret_cast<const u32x4*>(ldsB + boff(hh, s2));
                 wsu_mfma_f16(ah, bh, acc);
             }
+        }
         }
         if (c + 1 == a.nch) {
             const bool ok = irow < a.h && icol < a.w;
@@ -586,8 +630,9 @@ int wsu_convt2x2_pl_pack_dgrad(const float* w_iohw, void* w_packed, int cin, int
 }
 
 int wsu_convt2x2_pl_bwd_data(const void* dy, const void* w_packed_dgrad, void* dx, const void* mask,
-                             int n, int h, int w, int cin, int cout, void* stream) {
+                             int n, int h, int w, int cin, int cout, int products, void* stream) {
     WSU_REQUIRE(dy && w_packed_dgrad && dx, "convt2x2_pl_bwd_data: null pointer");
+    WSU_REQUIRE(products == WSU_PRODUCTS_F16F8 || products == WSU_PRODUCTS_F16, "convt2x2_pl_bwd_data: products must be WSU_PRODUCTS_F16F8 or WSU_PRODUCTS_F16");
     WSU_REQUIRE(n > 0 && h > 0 && w > 0 && cin > 0 && cin % WSU_COB == 0 && cout > 0 && cout % 16 == 0, "convt2x2_pl_bwd_data: bad shape (cin %% 64, cout %% 16)");
     WSU_REQUIRE((long long)h * w * 192 < 0xFFFFFFF0LL, "convt2x2_pl_bwd_data: h*w too large (a plane triple of dy must stay below 4 GiB)");
     CtbPlArgs a;
@@ -603,12 +648,14 @@ int wsu_convt2x2_pl_bwd_data(const void* dy, const void* w_packed_dgrad, void* d
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
             wsu_set_error("convt2x2_pl_bwd_data: cannot query the device"); return WSU_ERR_HIP;
         }
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&convt2x2_bwd_pl_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, ctb::LDS_TOTAL);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&convt2x2_bwd_pl_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, CtbGeo<false>::LDS_TOTAL);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&convt2x2_bwd_pl_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, CtbGeo<true>::LDS_TOTAL);
         if (e != hipSuccess) { wsu_set_error("hipFuncSetAttribute(convt2x2_bwd_pl): %s", hipGetErrorString(e)); return WSU_ERR_HIP; }
         ncu = prop.multiProcessorCount;
     }
     const int grid = (int)(nt < ncu ? nt : ncu);
-    hipLaunchKernelGGL(convt2x2_bwd_pl_kernel, dim3(grid), dim3(ctb::NT), ctb::LDS_TOTAL, static_cast<hipStream_t>(stream), a);
+    if (products == WSU_PRODUCTS_F16) hipLaunchKernelGGL(convt2x2_bwd_pl_kernel<true>, dim3(grid), dim3(ctb::NT), CtbGeo<true>::LDS_TOTAL, static_cast<hipStream_t>(stream), a);
+    else hipLaunchKernelGGL(convt2x2_bwd_pl_kernel<false>, dim3(grid), dim3(ctb::NT), CtbGeo<false>::LDS_TOTAL, static_cast<hipStream_t>(stream), a);
     return wsu_check_launch("convt2x2_bwd_pl_kernel");
 }
 

@@ -160,10 +160,14 @@ __global__ __launch_bounds__(256) void pool_bwd_pl_kernel(const char* __restrict
     const size_t hw = (size_t)h * w, hwp = (size_t)hp * wp;
     const long long total = (long long)n * ncg * hwp;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        // lane pairs = the two 8-channel groups of one 16-channel chunk at the same pixel: together they read / write whole 16-byte residual
+        // granules (round 2 gave consecutive lanes consecutive pixels of ONE group: every residual access used 8 of 16 bytes, the other half
+        // went to a workgroup far away in the grid)
         long long t = i;
+        const int cgl = (int)(t & 1); t >>= 1;
         const int xp = (int)(t % wp); t /= wp;
         const int yp = (int)(t % hp); t /= hp;
-        const int cg = (int)(t % ncg); const int img = (int)(t / ncg);
+        const int cg = (int)(t % (ncg >> 1)) * 2 + cgl; const int img = (int)(t / (ncg >> 1));
         float d[8];
         pl_decode8(*reinterpret_cast<const u32x4*>(pl_h(dyp, img, c, cg, hwp, (size_t)yp * wp + xp)),
                    *reinterpret_cast<const u32x2*>(pl_r(dyp, img, c, cg, hwp, (size_t)yp * wp + xp)), WSU_F8_GLO_DIV, d);

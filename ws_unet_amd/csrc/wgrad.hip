@@ -152,8 +152,10 @@ constexpr int X3_ROW = 144;                       // bytes per pixel row: 64 bf1
 
 constexpr int F8_ROW = 96;                        // bytes per pixel row of an e4m3 image: 64 + 32 pad (conflict-free transposing reads)
 
-template <int KIND> struct GeoX3 {
-    static constexpr int NTAPS = Geo<KIND>::NTAPS, TH = Geo<KIND>::TH, VH = Geo<KIND>::VH, VW = Geo<KIND>::VW;
+// THX: tile rows (default: Geo's; the planar transposed-conv kernel with f16 products takes 2 -- its LDS images are small enough)
+template <int KIND, int THX = Geo<KIND>::TH> struct GeoX3 {
+    static_assert(KIND == 1 || THX == Geo<KIND>::TH, "only the transposed conv's tile height is a parameter");
+    static constexpr int NTAPS = Geo<KIND>::NTAPS, TH = THX, VH = KIND == 0 ? TH + 2 : 2 * TH, VW = Geo<KIND>::VW;
     static constexpr int U_PIX = TH * TW, V_PIX = VH * VW;
     static constexpr int U_BYTES = U_PIX * X3_ROW, V_BYTES = V_PIX * X3_ROW;      // per hi / lo image
     static constexpr int LDS = 2 * U_BYTES + 2 * V_BYTES;
@@ -444,15 +446,18 @@ struct WgPlArgs {
     int ablate;                     // timing-only experiments (WSU_WGRAD_ABLATE; results wrong when != 0): 1 = no matrix section, 2 = staging of the first tile only, 4 = no derived copies (the ring kernel's variant HONLY = products F16 is the product form of "no cross terms")
 };
 
-template <int KIND>
+// HONLY (products = WSU_PRODUCTS_F16): the residual halves are not loaded, no e4m3 images are written or multiplied; bias sums of the f16 parts.
+// THX (transposed conv only): input rows per tile -- one tile of TH = 1 is 8 MFMAs per wave between two workgroup barriers and a register
+// prefetch of 20 KB; with f16 products the LDS images of two rows still fit twice per CU.
+template <int KIND, bool HONLY = false, int THX = Geo<KIND>::TH>
 __global__ __launch_bounds__(NT, 2) void wgrad_pl_kernel(const WgPlArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    using G = GeoX3<KIND>;
+    using G = GeoX3<KIND, THX>;
     constexpr int NTAPS = G::NTAPS, TH = G::TH, VH = G::VH, VW = G::VW;
     char* u_hi = smem;
     char* u_lo = smem + G::U_BYTES;                        // e4m3 copy image, then (u_l8) the residual image
     char* u_l8 = u_lo + G::U8_BYTES;
-    char* v_hi = smem + G::U_BYTES + 2 * G::U8_BYTES;
+    char* v_hi = smem + G::U_BYTES + (HONLY ? 0 : 2 * G::U8_BYTES);   // HONLY: the e4m3 images do not exist (LDS = U_BYTES + V_BYTES)
     char* v_lo = v_hi + G::V_BYTES;
     char* v_l8 = v_lo + G::V8_BYTES;
     constexpr bool UGRAD = KIND == 0;                      // which operand is the gradient
@@ -512,7 +517,7 @@ __global__ __launch_bounds__(NT, 2) void wgrad_pl_kernel(const WgPlArgs a) {
         if (y0 + r < a.hu && x0 + c < a.wu) {
             const char* base = a.u + (((size_t)n * (a.cu >> 4) + mb * 4 + (cg >> 1)) * 3) * hwu * 16 + ((size_t)(y0 + r) * a.wu + x0 + c) * 16;
             it.h = *reinterpret_cast<const u32x4*>(base + (cg & 1) * hwu * 16);
-            it.r = *reinterpret_cast<const u32x2*>(base + 2 * hwu * 16 + (cg & 1) * 8);
+            if constexpr (!HONLY) it.r = *reinterpret_cast<const u32x2*>(base + 2 * hwu * 16 + (cg & 1) * 8);
         }
         return it;
     };
@@ -524,7 +529,7 @@ __global__ __launch_bounds__(NT, 2) void wgrad_pl_kernel(const WgPlArgs a) {
         const char* base = vsrc + (((size_t)n * (cv >> 4) + (vch0 >> 4) + (cg >> 1)) * 3) * hwv * 16 + ((size_t)yy * wv + xx) * 16;
         Item it;
         it.h = *reinterpret_cast<const u32x4*>(base + (cg & 1) * hwv * 16);
-        it.r = *reinterpret_cast<const u32x2*>(base + 2 * hwv * 16 + (cg & 1) * 8);
+        if constexpr (HONLY) it.r = mk_u2(0, 0); else it.r = *reinterpret_cast<const u32x2*>(base + 2 * hwv * 16 + (cg & 1) * 8);
         return it;
     };
     auto v_valid = [&](int y0, int x0, int p) __attribute__((always_inline)) {    // KIND 1: the window pixel lies inside the image (clamped copies do not count)
@@ -532,11 +537,18 @@ __global__ __launch_bounds__(NT, 2) void wgrad_pl_kernel(const WgPlArgs a) {
     };
     auto put = [&](char* hi, char* c8, char* l8, int p, int cg, const Item& it, bool grad) __attribute__((always_inline)) {
         *reinterpret_cast<u32x4*>(hi + p * X3_ROW + cg * 16) = it.h;
-        *reinterpret_cast<u32x2*>(c8 + p * F8_ROW + cg * 8) = grad ? wsu_f16x8_to_fp8_grad(it.h) : wsu_f16x8_to_fp8(it.h);
-        *reinterpret_cast<u32x2*>(l8 + p * F8_ROW + cg * 8) = it.r;
+        if constexpr (!HONLY) {
+            *reinterpret_cast<u32x2*>(c8 + p * F8_ROW + cg * 8) = grad ? wsu_f16x8_to_fp8_grad(it.h) : wsu_f16x8_to_fp8(it.h);
+            *reinterpret_cast<u32x2*>(l8 + p * F8_ROW + cg * 8) = it.r;
+        }
     };
     auto bias_add = [&](float (&s)[8], const Item& it) __attribute__((always_inline)) {
         const f16x8 hv8 = __builtin_bit_cast(f16x8, it.h);
+        if constexpr (HONLY) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s[e] += (float)hv8[e];
+            return;
+        }
         const int r0 = (int)it.r.x, r1 = (int)it.r.y;
         s[0] += (float)hv8[0] + __builtin_amdgcn_cvt_f32_fp8(r0, 0) * WSU_F8_GLO_DIV;
         s[1] += (float)hv8[1] + __builtin_amdgcn_cvt_f32_fp8(r0, 1) * WSU_F8_GLO_DIV;
@@ -585,7 +597,7 @@ __global__ __launch_bounds__(NT, 2) void wgrad_pl_kernel(const WgPlArgs a) {
                 const int pn = spx + 32 * k;
                 if (pn < VN_PIX) {
                     const int rn = pn / VW, c = pn % VW;
-                    const int slot = (VN_ROW0 + rn + rot) & (VH - 1);
+                    const int slot = ROLL ? ((VN_ROW0 + rn + rot) & (VH - 1)) : rn;   // (the rolling window's VH is a power of two; the transposed conv's need not be)
                     if (KIND == 1 && bias_on && v_valid(y0, x0, pn)) bias_add(bs, pv[k]);
                     put(v_hi, v_lo, v_l8, slot * VW + c, scg, pv[k], !UGRAD);
                 }
@@ -613,15 +625,18 @@ __global__ __launch_bounds__(NT, 2) void wgrad_pl_kernel(const WgPlArgs a) {
             const int sc_a = hh ? SUL : SU8, sc_b = hh ? SV8 : SVL;
 #pragma unroll 1
             for (int r = 0; r < TH; ++r) {
-                const u32x4 a8 = f8_frag(u_lo, r * TW + 16 * hh, 1, colA8), al8 = f8_frag(u_l8, r * TW + 16 * hh, 1, colA8);
+                u32x4 a8 = mk_u4(0, 0, 0, 0), al8 = a8;
+                if constexpr (!HONLY) { a8 = f8_frag(u_lo, r * TW + 16 * hh, 1, colA8); al8 = f8_frag(u_l8, r * TW + 16 * hh, 1, colA8); }
                 const u32x4 ah0 = x3_frag(u_hi, r * TW + 8 * hh, 1, colA), ah1 = x3_frag(u_hi, r * TW + 16 + 8 * hh, 1, colA);
 #pragma unroll
                 for (int t = 0; t < NTAPS; ++t) {
                     int vrow, vstep;
                     if (KIND == 0) { vrow = ((r + t / 3 + rot) & (VH - 1)) * VW + t % 3; vstep = 1; }
                     else           { vrow = (2 * r + (t >> 1)) * VW + (t & 1); vstep = 2; }
-                    const u32x4 bl8 = f8_frag(v_l8, vrow + vstep * 16 * hh, vstep, colB8), b8 = f8_frag(v_lo, vrow + vstep * 16 * hh, vstep, colB8);
-                    wsu_mfma_f8x2(a8, al8, bl8, b8, sc_a, sc_b, acc[t]);
+                    if constexpr (!HONLY) {
+                        const u32x4 bl8 = f8_frag(v_l8, vrow + vstep * 16 * hh, vstep, colB8), b8 = f8_frag(v_lo, vrow + vstep * 16 * hh, vstep, colB8);
+                        wsu_mfma_f8x2(a8, al8, bl8, b8, sc_a, sc_b, acc[t]);
+                    }
                     const u32x4 bh0 = x3_frag(v_hi, vrow + vstep * 8 * hh, vstep, colB), bh1 = x3_frag(v_hi, vrow + vstep * (16 + 8 * hh), vstep, colB);
                     wsu_mfma_f16(ah0, bh0, acc[t]);
                     wsu_mfma_f16(ah1, bh1, acc[t]);
@@ -1127,10 +1142,13 @@ int run_wgrad(WgArgs a, float* dw, float* db, float* workspace, size_t workspace
     return wsu_check_launch("wgrad_reduce_kernel");
 }
 
+constexpr int CT_TH_F16 = 3;                                           // tile rows of wgrad_pl_kernel<1, HONLY>
+
 template <int KIND>
 int run_wgrad_pl(WgPlArgs a, float* dw, float* db, float* workspace, size_t workspace_bytes, hipStream_t s) {
     using G = Geo<KIND>;
-    a.tiles_x = (a.wu + TW - 1) / TW; a.tiles_y = (a.hu + G::TH - 1) / G::TH;
+    const int th = (KIND == 1 && a.honly) ? CT_TH_F16 : G::TH;
+    a.tiles_x = (a.wu + TW - 1) / TW; a.tiles_y = (a.hu + th - 1) / th;
     a.ntiles = a.n * a.tiles_x * a.tiles_y;
     a.nmb = a.cu / 64; a.nnb = (a.cv1 + a.cv2) / 64;
     int nsplit = (512 + a.nmb * a.nnb - 1) / (a.nmb * a.nnb);
@@ -1152,7 +1170,6 @@ int run_wgrad_pl(WgPlArgs a, float* dw, float* db, float* workspace, size_t work
     a.ablate = ablate;
     static int impl = -1;                                              // WSU_WGRAD_IMPL=reg: the register-staged kernel (A/B runs)
     if (impl < 0) { const char* e = getenv("WSU_WGRAD_IMPL"); impl = (e && e[0] == 'r') ? 0 : 1; }
-    if (a.honly && !(KIND == 0 && impl == 1)) { wsu_set_error("wgrad_pl: products = WSU_PRODUCTS_F16 is built into the ring kernel only"); return WSU_ERR_UNSUPPORTED; }
     if (KIND == 0 && impl == 1) {
         // one persistent-style workgroup per CU: the splits cover the tiles, fewer and longer than the register-staged kernel's
         static int ncu = 0;
@@ -1176,13 +1193,18 @@ int run_wgrad_pl(WgPlArgs a, float* dw, float* db, float* workspace, size_t work
         hipLaunchKernelGGL(wgrad_reduce_kernel<KIND>, dim3(512), dim3(256), 0, s, a.part, (const float*)a.bpart, dw, a.bpart ? db : (float*)nullptr, ns, a.nmb, a.nnb, nbias);
         return wsu_check_launch("wgrad_reduce_kernel");
     }
+    constexpr int THP = KIND == 1 ? CT_TH_F16 : G::TH;                 // the f16-products instantiation: tile rows, LDS (no e4m3 images)
+    using GP = GeoX3<KIND, THP>;
+    constexpr int LDS_H = GP::U_BYTES + GP::V_BYTES;
     static bool attr = false;
     if (!attr) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_pl_kernel<KIND>), hipFuncAttributeMaxDynamicSharedMemorySize, GeoX3<KIND>::LDS_F8);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_pl_kernel<KIND, true, THP>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_H);
         if (e != hipSuccess) { wsu_set_error("hipFuncSetAttribute(wgrad_pl): %s", hipGetErrorString(e)); return WSU_ERR_HIP; }
         attr = true;
     }
-    hipLaunchKernelGGL(wgrad_pl_kernel<KIND>, dim3(nsplit * a.nmb * a.nnb), dim3(NT), GeoX3<KIND>::LDS_F8, s, a);
+    if (a.honly) hipLaunchKernelGGL((wgrad_pl_kernel<KIND, true, THP>), dim3(nsplit * a.nmb * a.nnb), dim3(NT), LDS_H, s, a);
+    else hipLaunchKernelGGL(wgrad_pl_kernel<KIND>, dim3(nsplit * a.nmb * a.nnb), dim3(NT), GeoX3<KIND>::LDS_F8, s, a);
     int rc = wsu_check_launch("wgrad_pl_kernel");
     if (rc) return rc;
     hipLaunchKernelGGL(wgrad_reduce_kernel<KIND>, dim3(512), dim3(256), 0, s, a.part, (const float*)a.bpart, dw, a.bpart ? db : (float*)nullptr, nsplit, a.nmb, a.nnb, nbias);
@@ -1212,12 +1234,14 @@ int wsu_conv3x3_pl_bwd_weight(const void* g, const void* x1, const void* x2, flo
 }
 
 int wsu_convt2x2_pl_bwd_weight(const void* x, const void* dy, float* dw, float* db, float* workspace, size_t workspace_bytes,
-                               int n, int h, int w, int cin, int cout, void* stream) {
+                               int n, int h, int w, int cin, int cout, int products, void* stream) {
     WSU_REQUIRE(x && dy && dw && workspace, "convt2x2_pl_bwd_weight: null pointer");
+    WSU_REQUIRE(products == WSU_PRODUCTS_F16F8 || products == WSU_PRODUCTS_F16, "convt2x2_pl_bwd_weight: products must be WSU_PRODUCTS_F16F8 or WSU_PRODUCTS_F16");
     WSU_REQUIRE(n > 0 && h > 0 && w > 0, "convt2x2_pl_bwd_weight: bad shape");
     WSU_REQUIRE(cin > 0 && cin % 64 == 0 && cout > 0 && cout % 64 == 0, "convt2x2_pl_bwd_weight: cin=%d cout=%d must be multiples of 64", cin, cout);
     WgPlArgs a{};
     a.u = (const char*)x; a.v1 = (const char*)dy; a.v2 = nullptr; a.n = n; a.hu = h; a.wu = w; a.cu = cin; a.cv1 = cout; a.cv2 = 0;
+    a.honly = products == WSU_PRODUCTS_F16 ? 1 : 0;
     return run_wgrad_pl<1>(a, dw, db, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
 }
 

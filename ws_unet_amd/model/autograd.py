@@ -132,8 +132,8 @@ def _backward_pl(model, t: Dict[str, torch.Tensor], x: torch.Tensor, dout: torch
         dxu, skip_g[depth] = conv_bwd(c1, g, xu, skip, None)              # neither half is masked here: the upconv output has no ReLU, the skip's
         below = t["x" + (dec_names(depth + 1)[2] if depth < model.nsteps else ENC[model.nsteps][1])]    # mask meets the pool routing below
         lu = getattr(model, up)
-        grads[up + ".weight"], grads[up + ".bias"] = ops.convt2x2_pl_bwd_weight(below, dxu)
-        g = ops.convt2x2_pl_bwd_data(dxu, model._packed(up, W, "convt_dgrad_pl"), lu.in_channels, below)
+        grads[up + ".weight"], grads[up + ".bias"] = ops.convt2x2_pl_bwd_weight(below, dxu, products=products)
+        g = ops.convt2x2_pl_bwd_data(dxu, model._packed(up, W, "convt_dgrad_pl"), lu.in_channels, below, products=products)
     for lvl in range(model.nsteps, -1, -1):
         a, b = ENC[lvl]
         if lvl < model.nsteps:

@@ -420,7 +420,7 @@ def conv3x3_pl_bwd_weight(g: torch.Tensor, x1: torch.Tensor, x2: Optional[torch.
     return dw, db
 
 
-def convt2x2_pl_bwd_weight(x: torch.Tensor, dy: torch.Tensor, want_bias: bool = True):
+def convt2x2_pl_bwd_weight(x: torch.Tensor, dy: torch.Tensor, want_bias: bool = True, products: str = "f16f8"):
     """Weight / bias gradient of the transposed conv on planar operands: x planar input (N, Cin/16, 3, h, w, 4), dy planar gradient at (2h, 2w)."""
     lib = _lib.load()
     _dev_check(x, dy)
@@ -432,7 +432,7 @@ def convt2x2_pl_bwd_weight(x: torch.Tensor, dy: torch.Tensor, want_bias: bool = 
     ws = workspace(lib.wsu_wgrad_workspace_bytes(cin, cout, 4), x.device)
     meta = {"flops": 2.0 * 4 * cin * cout * n * h * w, "bytes": float(n * h * w * 3 * (cin * (cout // 64) + 4 * cout * (cin // 64)))}
     check(_launch("convt2x2_pl_bwd_weight", meta, lambda: lib.wsu_convt2x2_pl_bwd_weight(
-        x.data_ptr(), dy.data_ptr(), dw.data_ptr(), _ptr(db), ws.data_ptr(), ws.numel() * 4, n, h, w, cin, cout, _stream())), "wsu_convt2x2_pl_bwd_weight")
+        x.data_ptr(), dy.data_ptr(), dw.data_ptr(), _ptr(db), ws.data_ptr(), ws.numel() * 4, n, h, w, cin, cout, products_id(products), _stream())), "wsu_convt2x2_pl_bwd_weight")
     return dw, db
 
 
@@ -447,7 +447,7 @@ def pack_convt2x2_pl_dgrad(w: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def convt2x2_pl_bwd_data(dy: torch.Tensor, w_packed_dgrad: torch.Tensor, cin: int, mask: Optional[torch.Tensor]) -> torch.Tensor:
+def convt2x2_pl_bwd_data(dy: torch.Tensor, w_packed_dgrad: torch.Tensor, cin: int, mask: Optional[torch.Tensor], products: str = "f16f8") -> torch.Tensor:
     """dy: planar gradient (N, Cout/16, 3, 2h, 2w, 4) -> dx planar gradient with cin channels at (h, w), masked by (mask > 0)."""
     lib = _lib.load()
     _dev_check(dy, w_packed_dgrad, mask)
@@ -456,7 +456,7 @@ def convt2x2_pl_bwd_data(dy: torch.Tensor, w_packed_dgrad: torch.Tensor, cin: in
     dx = torch.empty(planar_shape(n, cin, h, w), dtype=torch.float32, device=dy.device)
     meta = {"flops": 2.0 * 4 * cin * cout * n * h * w, "bytes": float(n * h * w * (cout * 12 + cin * 5))}
     check(_launch("convt2x2_pl_bwd_data", meta, lambda: lib.wsu_convt2x2_pl_bwd_data(
-        dy.data_ptr(), w_packed_dgrad.data_ptr(), dx.data_ptr(), _ptr(mask), n, h, w, cin, cout, _stream())), "wsu_convt2x2_pl_bwd_data")
+        dy.data_ptr(), w_packed_dgrad.data_ptr(), dx.data_ptr(), _ptr(mask), n, h, w, cin, cout, products_id(products), _stream())), "wsu_convt2x2_pl_bwd_data")
     return dx
 
 
