@@ -273,13 +273,17 @@ __global__ __launch_bounds__(256) void head_bwd_pl_kernel(const char* __restrict
         }
     }
 }
-__global__ void head_bwd_pl_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ db, int nblocks, int c, int cout) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= cout * (c + 1)) return;
+// one WAVE per output: lane-strided partial sums + a butterfly -- a fixed order (deterministic); one thread per output walked the block
+// partials serially: 0.28 ms for 65 sums at batch 64
+__global__ __launch_bounds__(256) void head_bwd_pl_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ db, int nblocks, int c, int cout) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= cout * (c + 1)) return;                           // wave-uniform
     float s = 0.f;
-    for (int b = 0; b < nblocks; ++b) s += part[(size_t)b * cout * (c + 1) + i];
+    for (int b = lane; b < nblocks; b += 64) s += part[(size_t)b * cout * (c + 1) + i];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
     const int o = i / (c + 1), k = i % (c + 1);
-    if (k < c) dw[(size_t)o * c + k] = s; else db[o] = s;
+    if (lane == 0) { if (k < c) dw[(size_t)o * c + k] = s; else db[o] = s; }
 }
 
 // ---- per-channel sums of a planar gradient (bias gradient of the transposed conv) and the first layer's weight gradient (single input plane:
@@ -355,7 +359,7 @@ __global__ void first_split_kernel(const float* __restrict__ sums, float* __rest
     if (k < 9) dw[co * 9 + k] = sums[i]; else if (db) db[co] = sums[i];
 }
 
-constexpr int SUM_BLOCKS = 1024;
+constexpr int SUM_BLOCKS = 2048;                              // ~8 workgroups per CU: these kernels stream (2 - 3 loads in flight per thread), occupancy is their memory parallelism
 
 inline unsigned grid_for(long long total) { return (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192); }
 
@@ -407,7 +411,7 @@ int wsu_conv1x1_sigmoid_pl_bwd(const void* x, const float* w, const float* out, 
     else hipLaunchKernelGGL(head_bwd_pl_kernel<HEADP_MAXCO>, dim3(nblk), dim3(256), 0, s, (const char*)x, w, out, dout, (char*)g, workspace, n, h * wd, c, cout);
     int rc = wsu_check_launch("head_bwd_pl_kernel");
     if (rc) return rc;
-    hipLaunchKernelGGL(head_bwd_pl_reduce_kernel, dim3((cout * (c + 1) + 63) / 64), dim3(64), 0, s, workspace, dw, db, nblk, c, cout);
+    hipLaunchKernelGGL(head_bwd_pl_reduce_kernel, dim3((cout * (c + 1) + 3) / 4), dim3(256), 0, s, workspace, dw, db, nblk, c, cout);
     return wsu_check_launch("head_bwd_pl_reduce_kernel");
 }
 
