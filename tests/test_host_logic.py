@@ -347,3 +347,21 @@ def test_bench_self_launch_runs_two_ranks_on_cpu():
     src = (root / "bench.py").read_text()
     body = src[src.index("def self_launch"):src.index("def build_model")]
     assert "import torch" not in body and "visible_gpus" in body
+
+
+def test_train_products_setting(monkeypatch):
+    """`train_products` (include/wsu.h WSU_PRODUCTS_*): default 'f16', the environment overrides, an unknown name is refused when the model is
+    built -- not at the first backward."""
+    from ws_unet_amd import ops
+    from ws_unet_amd.model import get_model
+    assert ops.products_id("f16f8") == 0 and ops.products_id("f16") == 1
+    with pytest.raises(ValueError, match="products"):
+        ops.products_id("bf16")
+    monkeypatch.delenv("WSU_TRAIN_PRODUCTS", raising=False)
+    m = get_model("unet_0", in_channels=1, out_channels=1, channel=[0], drop_rate=None, mode="f16f8p")
+    assert m.train_mode == "f16f8p" and m.train_products == "f16"
+    monkeypatch.setenv("WSU_TRAIN_PRODUCTS", "f16f8")
+    assert get_model("unet_0", in_channels=1, out_channels=1, channel=[0], drop_rate=None, mode="f16f8p").train_products == "f16f8"
+    monkeypatch.setenv("WSU_TRAIN_PRODUCTS", "fp4")
+    with pytest.raises(ValueError, match="products"):
+        get_model("unet_0", in_channels=1, out_channels=1, channel=[0], drop_rate=None, mode="f16f8p")
