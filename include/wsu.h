@@ -66,7 +66,8 @@ enum { WSU_MODE_F32 = 0, WSU_MODE_BF16X3 = 1, WSU_MODE_BF16 = 2, WSU_MODE_BF16X3
  *                              9 * cout of them, so the rounding noise averages out to a relative L2 of <= 2e-4 per weight gradient and
  *                              ~1e-4 per data-gradient layer (tests/test_gpu_planar_train.py) -- below the 1e-3 that ReLU-mask flips from
  *                              the FORWARD's own rounding put between any two arithmetics on these networks, and 8x finer than bf16
- *                              autocast.  The forward pass and the stored formats do not change. */
+ *                              autocast.  The forward pass and the activations' format do not change; gradient tensors then hold f16
+ *                              values (their residual plane is not used, see the K7p notes below). */
 enum { WSU_PRODUCTS_F16F8 = 0, WSU_PRODUCTS_F16 = 1 };
 
 enum {
@@ -200,18 +201,22 @@ int wsu_convt2x2_pl_bwd_weight(const void* x, const void* dy, float* dw, float* 
  *        fp32 -> g (planar gradient w.r.t. the pre-activation of the layer that produced x), dw (cout, c), db (cout).
  *      wsu_colsum_pl: per-channel sums of a planar gradient (bias gradient of the transposed conv).
  *      wsu_conv3x3_first_pl_bwd_weight: first layer, single input plane: dw (c, 1, 3, 3), db (c) from the planar gradient g and img (N, 1, H, W).
- *      All reductions are two-stage with a fixed order (deterministic). */
+ *      All reductions are two-stage with a fixed order (deterministic).
+ *      products (every K7p entry point): with WSU_PRODUCTS_F16 a GRADIENT tensor carries no residual plane -- its producers (the data
+ *        gradients, the pool and head backward) write the two f16 planes only and its consumers read only those (plane 2 of such a tensor
+ *        is never touched: 2 instead of 3 bytes of traffic per gradient element); a gradient produced with one setting must be consumed
+ *        with the same.  Activations are always read whole (the pool's argmax compares the stored values). */
 int wsu_convt2x2_pl_pack_dgrad(const float* w_iohw, void* w_packed, int cin, int cout, void* stream);
 int wsu_convt2x2_pl_bwd_data(const void* dy, const void* w_packed_dgrad, void* dx, const void* mask,
                              int n, int h, int w, int cin, int cout, int products, void* stream);
-int wsu_maxpool2x2_pl_bwd(const void* skip_g, const void* dy_pool, const void* act, void* g, int n, int h, int w, int c, void* stream);
+int wsu_maxpool2x2_pl_bwd(const void* skip_g, const void* dy_pool, const void* act, void* g, int n, int h, int w, int c, int products, void* stream);
 size_t wsu_head_pl_bwd_workspace_bytes(int c, int cout);
 int wsu_conv1x1_sigmoid_pl_bwd(const void* x, const float* w, const float* out, const float* dout, void* g, float* dw, float* db,
-                               float* workspace, size_t workspace_bytes, int n, int h, int wd, int c, int cout, void* stream);
+                               float* workspace, size_t workspace_bytes, int n, int h, int wd, int c, int cout, int products, void* stream);
 size_t wsu_chansum_pl_workspace_bytes(int c);
-int wsu_colsum_pl(const void* g, float* db, float* workspace, size_t workspace_bytes, int n, int h, int w, int c, void* stream);
+int wsu_colsum_pl(const void* g, float* db, float* workspace, size_t workspace_bytes, int n, int h, int w, int c, int products, void* stream);
 int wsu_conv3x3_first_pl_bwd_weight(const void* g, const float* img, float* dw, float* db, float* workspace, size_t workspace_bytes,
-                                    int n, int h, int w, int c, void* stream);
+                                    int n, int h, int w, int c, int products, void* stream);
 
 /* ---- K3p / K0p: the other two kernels of the planar (F16F8P) inference path (csrc/planar.hip).
  *      wsu_convt2x2_pl_fwd: nn.ConvTranspose2d(k2, s2) + bias (unet.py:125,130,177,183), x: cin channels at (h, w) planar -> y: cout channels at

@@ -104,10 +104,11 @@ def planar_encode(x_nchw: torch.Tensor, lo_scale: float = 4096.0) -> torch.Tenso
 GRAD_LO = 16384.0          # residual scaling of planar gradients
 
 
-def planar_decode(t: torch.Tensor, lo_scale: float = 4096.0) -> torch.Tensor:
-    """planar 'F16F8P' storage -> fp32 NCHW on the CPU (f16 part + residual part)."""
+def planar_decode(t: torch.Tensor, lo_scale: float = 4096.0, f16_only: bool = False) -> torch.Tensor:
+    """planar 'F16F8P' storage -> fp32 NCHW on the CPU (f16 part + residual part).  f16_only: a gradient tensor written with products 'f16'
+    carries no residual plane (its plane 2 is uninitialised memory)."""
     raw = t.detach().contiguous().view(torch.uint8)                                        # (n, chunk, 3, h, w, 16)
     n, nch, _, h, w, _ = raw.shape
     hi = torch.stack([raw[:, :, 0], raw[:, :, 1]], dim=-2).contiguous().view(torch.float16).reshape(n, nch, h, w, 16).float()
-    lo = raw[:, :, 2].contiguous().view(torch.float8_e4m3fn).float() / lo_scale
+    lo = 0.0 if f16_only else raw[:, :, 2].contiguous().view(torch.float8_e4m3fn).float() / lo_scale
     return (hi + lo).permute(0, 1, 4, 2, 3).reshape(n, nch * 16, h, w).cpu()

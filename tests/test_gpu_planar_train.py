@@ -190,10 +190,13 @@ def test_conv3x3_pl_bwd_data_f16_products(n, h, w, cin, csplit, cout, masked, pa
     m2 = planar_encode(act[:, csplit:]) if (masked and csplit < cin) else None
     dx1, dx2 = ops.conv3x3_pl_bwd_data(planar_encode(g, GRAD_LO), wp, wr, cin, csplit, m1, m2, pad_zero=pad_zero, products="f16")
     torch.cuda.synchronize()
-    got = planar_decode(dx1, GRAD_LO)
+    got = planar_decode(dx1, GRAD_LO, f16_only=True)                    # products 'f16': the result is an f16 tensor (no residual plane is written)
     if dx2 is not None:
-        got = torch.cat([got, planar_decode(dx2, GRAD_LO)], dim=1)
-    assert rel_l2(got, refs[0]) < 2e-5, rel_l2(got, refs[0])
+        got = torch.cat([got, planar_decode(dx2, GRAD_LO, f16_only=True)], dim=1)
+    # = the exact adjoint of the f16 parts, rounded to f16 once (2^-12: 1.4e-4 relative L2) -- twice on the border ring of the reflect adjoint
+    assert rel_l2(got, refs[0]) < 3e-4, rel_l2(got, refs[0])
+    if pad_zero:
+        assert rel_l2(got, _h(refs[0].float())) < 5e-5, rel_l2(got, _h(refs[0].float()))  # up to last-place flips from the accumulation order
     assert rel_l2(got, refs[1]) < 5e-4, rel_l2(got, refs[1])
     if masked:
         assert float(got[(act <= 0)].abs().max()) == 0.0
@@ -231,23 +234,33 @@ def test_conv3x3_pl_bwd_weight_f16_products(n, h, w, c1, c2, cout):
     assert torch.equal(dw, dw2) and torch.equal(db, db2)
 
 
-def test_planar_backward_kernels_race_screen():
-    """Repeat launches of the pipelined backward kernels (weight-gradient ring: LDS-DMA three steps deep; data gradient: persistent kernel + ring
-    launches) must be bitwise identical: a missing wait or barrier shows up as a launch-to-launch difference."""
+@pytest.mark.parametrize("products", ["f16f8", "f16"])
+def test_planar_backward_kernels_race_screen(products):
+    """Repeat launches of the pipelined backward kernels (weight-gradient ring: LDS-DMA three steps deep; data gradient: persistent kernel -- two
+    stages, or four with the DMA three steps ahead and counted vmcnt waits for products 'f16' -- + ring launches; transposed-conv data gradient:
+    three / six stages) must be bitwise identical: a missing wait or barrier shows up as a launch-to-launch difference."""
     ops = _ops()
     n, h, w, c = 2, 320, 128, 64
+    live = slice(0, 2) if products == "f16" else slice(0, 3)           # products 'f16' writes no residual plane
     x = planar_encode(torch.relu(_rand((n, c, h, w), 21)))
     g = planar_encode(_rand((n, c, h, w), 22), GRAD_LO)
     wd = _rand((c, c, 3, 3), 23, 0.05).to(DEV)
     wp, wr = ops.pack_conv3x3(wd, ops.MODE_F16F8, dgrad=True), ops.pack_conv3x3_ring(wd)
-    dw0, db0 = ops.conv3x3_pl_bwd_weight(g, x, None)
-    dx0, _ = ops.conv3x3_pl_bwd_data(g, wp, wr, c, c, x, None)
-    dw0, db0, dx0 = dw0.clone(), db0.clone(), dx0.clone()
+    mbits = _mask_bits_ref(x)
+    wt = _rand((c, c, 2, 2), 24, 0.1).to(DEV)
+    wtp = ops.pack_convt2x2_pl_dgrad(wt)
+    xs = planar_encode(torch.relu(_rand((n, c, h // 2, w // 2), 25)))
+    dw0, db0 = ops.conv3x3_pl_bwd_weight(g, x, None, products=products)
+    dx0, _ = ops.conv3x3_pl_bwd_data(g, wp, wr, c, c, x, None, mask1_bits=mbits, products=products)
+    dt0 = ops.convt2x2_pl_bwd_data(g, wtp, c, xs, products=products)
+    dw0, db0, dx0, dt0 = dw0.clone(), db0.clone(), dx0[:, :, live].clone(), dt0[:, :, live].clone()
     for _ in range(15):
-        dw, db = ops.conv3x3_pl_bwd_weight(g, x, None)
-        dx, _ = ops.conv3x3_pl_bwd_data(g, wp, wr, c, c, x, None)
+        dw, db = ops.conv3x3_pl_bwd_weight(g, x, None, products=products)
+        dx, _ = ops.conv3x3_pl_bwd_data(g, wp, wr, c, c, x, None, mask1_bits=mbits, products=products)
+        dt = ops.convt2x2_pl_bwd_data(g, wtp, c, xs, products=products)
         assert torch.equal(dw, dw0) and torch.equal(db, db0)
-        assert torch.equal(dx.view(torch.int32), dx0.view(torch.int32))
+        assert torch.equal(dx[:, :, live].view(torch.int32), dx0.view(torch.int32))
+        assert torch.equal(dt[:, :, live].view(torch.int32), dt0.view(torch.int32))
 
 
 @pytest.mark.parametrize("products", ["f16f8", "f16"])
@@ -299,17 +312,18 @@ def test_convt2x2_pl_bwd_data(n, h, w, cin, cout, masked, products):
     wp = ops.pack_convt2x2_pl_dgrad(wgt.to(DEV))
     dx = ops.convt2x2_pl_bwd_data(planar_encode(dy, GRAD_LO), wp, cin, planar_encode(act) if masked else None, products=products)
     torch.cuda.synchronize()
-    got = planar_decode(dx, GRAD_LO)
+    got = planar_decode(dx, GRAD_LO, f16_only=products == "f16")
     if products == "f16":
-        assert rel_l2(got, refs[1]) < 2e-5, rel_l2(got, refs[1])
+        assert rel_l2(got, _h(refs[1].float())) < 5e-5, rel_l2(got, _h(refs[1].float()))
         assert rel_l2(got, refs[0]) < 5e-4, rel_l2(got, refs[0])
     else:
         assert rel_l2(got, refs[0]) < REL_L2, rel_l2(got, refs[0])
         assert float((got - refs[0]).abs().max()) < 2e-3 * float(refs[0].abs().max())
 
 
+@pytest.mark.parametrize("products", ["f16f8", "f16"])
 @pytest.mark.parametrize("with_skip", [True, False])
-def test_maxpool2x2_pl_bwd(with_skip):
+def test_maxpool2x2_pl_bwd(with_skip, products):
     ops = _ops()
     n, c, h, w = 2, 32, 12, 20
     act = _q(torch.relu(_rand((n, c, h, w), 12)), 4096.0)
@@ -319,16 +333,25 @@ def test_maxpool2x2_pl_bwd(with_skip):
     dyp = _q(_rand((n, c, h // 2, w // 2), 14), GRAD_LO)
     a = act.clone().requires_grad_(True)
     F.max_pool2d(a, 2).backward(dyp)
+    if products == "f16":               # gradient tensors are f16 tensors: their residual planes are neither read nor written
+        skip, dyp = _h(skip), _h(dyp)
+        a = act.clone().requires_grad_(True)
+        F.max_pool2d(a, 2).backward(dyp)
     ref = (a.grad + (skip if with_skip else 0)) * (act > 0)
-    g = ops.maxpool2x2_pl_bwd(planar_encode(skip, GRAD_LO) if with_skip else None, planar_encode(dyp, GRAD_LO), planar_encode(act))
+    g = ops.maxpool2x2_pl_bwd(planar_encode(skip, GRAD_LO) if with_skip else None, planar_encode(dyp, GRAD_LO), planar_encode(act), products=products)
     torch.cuda.synchronize()
-    got = planar_decode(g, GRAD_LO)
-    assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-7     # one re-encoding of an fp32 sum
+    got = planar_decode(g, GRAD_LO, f16_only=products == "f16")
+    if products == "f16":
+        assert torch.equal(got, _h(ref))                                # one f16 rounding of an exact fp32 sum
+    else:
+        assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-7     # one re-encoding of an fp32 sum
     assert float(got[0, :, 0:2, 0:2].abs().max()) == 0.0
 
 
-def test_head_and_first_layer_pl_bwd():
+@pytest.mark.parametrize("products", ["f16f8", "f16"])
+def test_head_and_first_layer_pl_bwd(products):
     ops = _ops()
+    f16 = products == "f16"
     n, c, h, w = 2, 64, 24, 40
     x = _q(torch.relu(_rand((n, c, h, w), 15)), 4096.0)
     wh = _rand((1, c, 1, 1), 16, 0.2).requires_grad_(True)
@@ -337,19 +360,19 @@ def test_head_and_first_layer_pl_bwd():
     out = torch.sigmoid(F.conv2d(xa, wh, bh))
     dout = _rand((n, 1, h, w), 17, 3.0)
     out.backward(dout)
-    g, dw, db = ops.conv1x1_sigmoid_pl_bwd(planar_encode(x), wh.detach().to(DEV), out.detach().to(DEV), dout.to(DEV))
+    g, dw, db = ops.conv1x1_sigmoid_pl_bwd(planar_encode(x), wh.detach().to(DEV), out.detach().to(DEV), dout.to(DEV), products=products)
     torch.cuda.synchronize()
     ref_g = xa.grad * (x > 0)
-    assert rel_l2(planar_decode(g, GRAD_LO), ref_g) < 3e-5
+    assert rel_l2(planar_decode(g, GRAD_LO, f16_only=f16), ref_g) < (3e-4 if f16 else 3e-5)      # f16: one 2^-12 rounding per value
     assert rel_l2(dw.cpu(), wh.grad) < 1e-5 and rel_l2(db.cpu(), bh.grad) < 1e-5
     # per-channel sums and the first layer's weight gradient from the same planar gradient
-    gq = planar_decode(g, GRAD_LO)
-    assert rel_l2(ops.colsum_pl(g).cpu(), gq.sum(dim=(0, 2, 3))) < 2e-6
+    gq = planar_decode(g, GRAD_LO, f16_only=f16)
+    assert rel_l2(ops.colsum_pl(g, products=products).cpu(), gq.sum(dim=(0, 2, 3))) < 2e-6
     img = torch.rand((n, 1, h, w), generator=torch.Generator().manual_seed(18))
     w1 = torch.zeros((c, 1, 3, 3), requires_grad=True)
     b1 = torch.zeros(c, requires_grad=True)
     F.conv2d(F.pad(img, (1, 1, 1, 1), mode="reflect"), w1, b1).backward(gq)
-    dw1, db1 = ops.conv3x3_first_pl_bwd_weight(g, img.to(DEV))
+    dw1, db1 = ops.conv3x3_first_pl_bwd_weight(g, img.to(DEV), products=products)
     torch.cuda.synchronize()
     assert rel_l2(dw1.cpu(), w1.grad) < 1e-5 and rel_l2(db1.cpu(), b1.grad) < 2e-6
 

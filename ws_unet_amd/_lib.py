@@ -58,12 +58,12 @@ SIGNATURES = {
     "wsu_convt2x2_pl_bwd_weight": (c_int, [_P] * 5 + [c_size_t] + [c_int] * 6 + [_P]),
     "wsu_convt2x2_pl_pack_dgrad": (c_int, [_P, _P, c_int, c_int, _P]),
     "wsu_convt2x2_pl_bwd_data": (c_int, [_P] * 4 + [c_int] * 6 + [_P]),
-    "wsu_maxpool2x2_pl_bwd": (c_int, [_P] * 4 + [c_int] * 4 + [_P]),
+    "wsu_maxpool2x2_pl_bwd": (c_int, [_P] * 4 + [c_int] * 5 + [_P]),
     "wsu_head_pl_bwd_workspace_bytes": (c_size_t, [c_int, c_int]),
-    "wsu_conv1x1_sigmoid_pl_bwd": (c_int, [_P] * 8 + [c_size_t] + [c_int] * 5 + [_P]),
+    "wsu_conv1x1_sigmoid_pl_bwd": (c_int, [_P] * 8 + [c_size_t] + [c_int] * 6 + [_P]),
     "wsu_chansum_pl_workspace_bytes": (c_size_t, [c_int]),
-    "wsu_colsum_pl": (c_int, [_P, _P, _P, c_size_t] + [c_int] * 4 + [_P]),
-    "wsu_conv3x3_first_pl_bwd_weight": (c_int, [_P] * 5 + [c_size_t] + [c_int] * 4 + [_P]),
+    "wsu_colsum_pl": (c_int, [_P, _P, _P, c_size_t] + [c_int] * 5 + [_P]),
+    "wsu_conv3x3_first_pl_bwd_weight": (c_int, [_P] * 5 + [c_size_t] + [c_int] * 5 + [_P]),
     "wsu_conv3x3_first_pl_fwd": (c_int, [_P, _P, _P, _P] + [c_int] * 6 + [_P, _P, _P]),
     "wsu_conv3x3_first_fwd": (c_int, [_P, _P, _P, _P] + [c_int] * 7 + [_P]),
     "wsu_maxpool2x2_fwd": (c_int, [_P, _P, _P] + [c_int] * 5 + [_P]),

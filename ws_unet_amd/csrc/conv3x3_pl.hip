@@ -32,6 +32,12 @@ constexpr int STAGE = LDS_IN + LDS_W;                     // 76032
 constexpr int LDS_EXTRA = 2 * STAGE;                      // bias [1024] | head_w [4][64] | head_b [4]
 constexpr int LDS_F1 = LDS_EXTRA + 1024 * 4 + 4 * 64 * 4 + 16;   // fused first layer: w1 tap-major [9][64] | b1 [64]
 constexpr int LDS_TOTAL = LDS_F1 + 9 * 64 * 4 + 64 * 4;
+// f16 products only (kernel variant HONLY): a stage holds 2 input planes + the 2 f16 weight planes of every tap = half the bytes, so FOUR stages
+// fit where two did and the DMA runs three steps ahead -- a step of 9 instead of 19 matrix units (1.2 us) no longer covers the DMA's latency
+constexpr int LDS_IN_H = 2 * PLANE;                       // 19584
+constexpr int STAGE_H = LDS_IN_H + 9 * 2 * WSU_COB * 16;  // 38016
+constexpr int NSTAGE_H = 4;
+static_assert(NSTAGE_H * STAGE_H <= 2 * STAGE, "the HONLY stages live in the two full stages' LDS");
 constexpr int NWAVE = 8, NLOAD = 4, NT = (NWAVE + NLOAD) * 64;      // 8 matrix waves + 4 loader waves (one per SIMD)
 constexpr int IN_SEG = (NPIX + 63) / 64;                  // 10 wave-instructions per plane (the last one 36 lanes wide)
 constexpr int HBM_PLANES = 3;                             // stored planes per chunk: f16 ch 0-7 | f16 ch 8-15 | e4m3 residuals; LDS plane 3 is derived
@@ -165,7 +171,13 @@ __device__ __forceinline__ void issue_dma(const PlArgs& a, int tn, int tcb, int 
     }
     // weight slot = tap * 4 + granule plane (f16 ci 0-7 | f16 ci 8-15 | e4m3 copies | e4m3 residuals), so loader wave LW carries granule
     // plane LW of every tap: with f16 products only (HONLY) waves 2 and 3 have no weight pieces
-    if constexpr (!(HONLY && LW >= 2)) {
+    if constexpr (HONLY) {
+        if constexpr (LW < 2) {                                                  // LDS: [tap][f16 plane LW][64 co][16 B] behind the two input planes
+            WSU_STATIC_FOR(W_PER_WAVE, k, {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void*)(st + LDS_IN_H + (k * 2 + LW) * 1024), 16, lane16, w_base + (LW + NLOAD * k) * 1024, 0, 0);
+            });
+        }
+    } else {
         WSU_STATIC_FOR(W_PER_WAVE, k, {
             const int wslot = (WEIGHTS_ONLY ? lw_rt : LW) + NLOAD * k;           // compile-time unless the fused-first-layer loader (one copy, run-time wave index)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void*)(st + LDS_IN + wslot * 1024), 16, lane16, w_base + wslot * 1024, 0, 0);
@@ -334,6 +346,56 @@ __device__ __forceinline__ void pl_loader(const PlArgs& a, char* smem, int lane,
         }
     };
     lds_char* smem3 = (lds_char*)smem;                                    // LDS address space from here on: no generic-pointer null checks per piece
+    if constexpr (HONLY) {
+        // ---- four stages, DMA three steps ahead.  Issue order of this wave: P_0 P_1 P_2 | barrier 0 | M_T0 P_3 | barrier 1 | P_4 | ... where P_s = the
+        // PER pieces of step s and M_T = the 4 mask pieces of the tile whose first step just opened (issued BEFORE that barrier's P, so they are
+        // older than every piece issued later).  `s_waitcnt vmcnt(n)` = "all but my n youngest operations have landed": before barrier j the
+        // wave needs P_j -- younger than it are the steps issued behind it and, during a tile's first three steps, its M -- and, before the
+        // barrier of a tile's LAST step, its M (the epilogue reads them): younger than M are only the steps from (first step + 3) on.
+        static_assert(!F1 && GRAD && !XRES, "HONLY is the data gradient's variant");
+        constexpr int NST = NSTAGE_H, AHEAD = NST - 1, PER = 5 + (LW < 2 ? W_PER_WAVE : 0);
+        static_assert((AHEAD - 1) * PER + 4 < 64 && IN_SLOTS == 30, "vmcnt immediates / 5 input pieces of planes 0, 1 per wave");
+        auto wait_vm = [&](int steps, bool plus_masks) __attribute__((always_inline)) {
+            switch (steps * 2 + (plus_masks ? 1 : 0)) {
+                case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+                case 1: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+                case 2: asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PER) : "memory"); break;
+                case 3: asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PER + 4) : "memory"); break;
+                case 4: asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * PER) : "memory"); break;
+                default: asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * PER + 4) : "memory"); break;
+            }
+        };
+        int ci = 0, kti = 0;                                               // chunk / tile counter of the next ISSUE (tile t, offsets voff)
+        auto issue_step = [&](int js) __attribute__((always_inline)) {
+            issue_dma<LW, false, false, true>(a, t.n, t.cb, ci, smem3 + (js % NST) * STAGE_H, lane, voff, LW);
+            if (++ci == a.nch && js + 1 < J) { ci = 0; ++kti; t = tile_of(a, lw + kti * G); plan_tile<LW, GRAD>(a, t, lane, voff); }
+        };
+        if (J > 0) plan_tile<LW, GRAD>(a, t, lane, voff);
+        for (int k = 0; k < AHEAD && k < J; ++k) issue_step(k);
+        Tile tb = tile_of(a, lw);                                          // tile / chunk of the step whose barrier comes next
+        int cb = 0, ktb = 0;
+        bool masks_dma = false;                                            // this tile's masks came by DMA (4 pieces in this wave's vmcnt order)
+        for (int j = 0; j < J; ++j) {
+            const int ya = min(J - 1 - j, AHEAD - 1);                      // steps issued behind step j so far
+            int steps = ya; bool plus = masks_dma && cb <= AHEAD - 1;
+            if (masks_dma && cb + 1 == a.nch) { steps = max(0, min(ya, cb + ya - AHEAD + 1)); plus = false; }
+            wait_vm(steps, plus);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (cb == 0) {
+                mask_issue(tb);
+                masks_dma = !mask_pending && ((tb.cb * 4 < a.nco1 ? a.mbits : a.mbits2) != nullptr);
+                if (mask_pending) {                                        // masks from the activations' f16 planes (no relu_mask planes given): registers,
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // drained on the spot -- the slow path; committed before the tile's second barrier
+                    mask_commit(); mask_pending = false;
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+            }
+            if (j + AHEAD < J) issue_step(j + AHEAD);                      // its stage held step j - 1: every matrix wave is past it
+            if (++cb == a.nch) { cb = 0; ++ktb; masks_dma = false; if (j + 1 < J) tb = tile_of(a, lw + ktb * G); }   // (the finished tile's M landed before its last barrier)
+        }
+        return;
+    }
     if (J > 0) {
         if constexpr (F1) f1_window(t); else plan_tile<LW, GRAD>(a, t, lane, voff);
         issue_dma<LW, XRES, F1, HONLY>(a, t.n, t.cb, 0, smem3, lane, voff, lw8);
@@ -469,7 +531,7 @@ __global__ __launch_bounds__(NT) void conv3x3_pl_kernel(const PlArgs a) {
         __builtin_amdgcn_s_barrier();                                         // the loaders' pieces landed; everyone left the other stage
         asm volatile("" ::: "memory");
         STAMP(s2);
-        char* st = smem + (j & 1) * STAGE;
+        char* st = HONLY ? smem + (j % NSTAGE_H) * STAGE_H : smem + (j & 1) * STAGE;
         STAMP(s3);
         if (c == 0) {
 #pragma unroll
@@ -480,7 +542,7 @@ __global__ __launch_bounds__(NT) void conv3x3_pl_kernel(const PlArgs a) {
                     for (int r = 0; r < 16; ++r) acc[m][q][r] = 0.f;
         }
         // ---- matrix section: identical arithmetic (and accumulation order) to conv3x3_kernel<F16F8> -----------------------------
-        const char* ldsA = st + LDS_IN + (cur.mh * 32 + l31) * 16;            // + ((tap*4 + g)*64 + m*32)*16
+        const char* ldsA = st + (HONLY ? LDS_IN_H : LDS_IN) + (cur.mh * 32 + l31) * 16;   // + ((tap*4 + g)*64 + m*32)*16   (HONLY: tap*2 + g)
         const char* ldsB = st + ((2 * wv) * IW + l31) * 16;                   // + g*PLANE + ((q+dy)*IW + dx)*16
 #if WSU_PROBE == 5
         u32x4 sa0[2], sa1[2], sb0[2], sb1[2], sah[2], sbh[2];
@@ -533,7 +595,7 @@ _Pragma("unroll")
             {
 #endif
 _Pragma("unroll")
-            for (int m = 0; m < MH; ++m) ah[m] = *reinterpret_cast<const u32x4*>(ldsA + ((tap * 4 + hh) * 64 + m * 32) * 16);
+            for (int m = 0; m < MH; ++m) ah[m] = *reinterpret_cast<const u32x4*>(ldsA + ((tap * (HONLY ? 2 : 4) + hh) * 64 + m * 32) * 16);
 _Pragma("unroll")
             for (int q = 0; q < 2; ++q) bh[q] = *reinterpret_cast<const u32x4*>(ldsB + hh * PLANE + ((q + dy) * IW + dx) * 16);
 #if WSU_PROBE == 5
@@ -671,7 +733,9 @@ _Pragma("unroll")
                         swap32(xlo, xlp); swap32(ylo, ylp);                     // lanes 0-31: xlp / ylp = the partner lane's residuals (ch 4-7 / 12-15)
                         if (ok) {
                             *reinterpret_cast<u32x4*>(base + off + hh * plane_bytes) = mk_u4(xh0, xh1, yh0, yh1);
-                            if (!hh) *reinterpret_cast<u32x4*>(base + off + 2 * plane_bytes) = mk_u4(xlo, xlp, ylo, ylp);
+                            if constexpr (!HONLY) {                                   // (HONLY = products F16: gradient tensors carry no residual plane)
+                                if (!hh) *reinterpret_cast<u32x4*>(base + off + 2 * plane_bytes) = mk_u4(xlo, xlp, ylo, ylp);
+                            }
                             if constexpr (!GRAD && !HEAD && !POOL) {            // the training forward's ReLU-mask byte of this lane's granule
                                 if (mdst) *mdst = (unsigned char)wsu_f16x8_pos_bits(mk_u4(xh0, xh1, yh0, yh1));
                             }
@@ -900,7 +964,7 @@ size_t wsu_conv3x3_pl_bwd_data_workspace_bytes(int n, int h, int w, int cin, int
 
 int wsu_ring_gather_pl(const void* g, void* strips, int n, int h, int w, int c, int L, void* stream);
 int wsu_ring_fold_pl(const void* strips_out, void* dx1, void* dx2, const void* mask1, const void* mask2,
-                     int n, int h, int w, int cin, int csplit, int L, void* stream);
+                     int n, int h, int w, int cin, int csplit, int L, int gres, void* stream);
 
 int wsu_conv3x3_pl_bwd_data(const void* g, const void* w_packed_dgrad, const void* w_packed_ring, void* workspace, size_t workspace_bytes,
                             void* dx1, void* dx2, int csplit, const void* mask1, const void* mask2,
@@ -949,7 +1013,7 @@ int wsu_conv3x3_pl_bwd_data(const void* g, const void* w_packed_dgrad, const voi
     r.ntiles = 4 * r.tiles_x * r.tiles_y * r.ncb;
     rc = pl_launch(r, false, s, true);
     if (rc) return rc;
-    return wsu_ring_fold_pl(strips_out, dx1, dx2, mask1, mask2, n, h, w, cin, csplit, L, stream);
+    return wsu_ring_fold_pl(strips_out, dx1, dx2, mask1, mask2, n, h, w, cin, csplit, L, a.honly ? 0 : 1, stream);
 }
 
 }  // extern "C"

@@ -18,7 +18,7 @@ __device__ __forceinline__ void swap32(uint32_t& upper_of, uint32_t& lower_of) {
 
 // X, Y = 4 + 4 values of one pixel (channels c0 + 4 hh .. and c0 + 8 + 4 hh ..; hh = lane >> 5): encode, gather whole 16-byte granules into
 // single lanes (conv3x3_pl.hip) and store the chunk's three planes (f16 | f16 | residuals): every instruction writes contiguous runs of 32 lanes x 16 B.
-__device__ __forceinline__ void store_chunk_px(const f32x4& X, const f32x4& Y, char* dst, size_t plane_bytes, int hh, bool ok, float div_lo = WSU_F8_XLO_DIV) {
+__device__ __forceinline__ void store_chunk_px(const f32x4& X, const f32x4& Y, char* dst, size_t plane_bytes, int hh, bool ok, float div_lo = WSU_F8_XLO_DIV, bool with_res = true) {
     uint32_t xh0, xh1, xlo, yh0, yh1, ylo;
     wsu_split4_f16r8(X, div_lo, xh0, xh1, xlo);
     wsu_split4_f16r8(Y, div_lo, yh0, yh1, ylo);
@@ -27,7 +27,7 @@ __device__ __forceinline__ void store_chunk_px(const f32x4& X, const f32x4& Y, c
     swap32(xlo, xlp); swap32(ylo, ylp);                                  // lanes 0-31 collect all 16 residuals of the chunk
     if (ok) {
         *reinterpret_cast<u32x4*>(dst + hh * plane_bytes) = mk_u4(xh0, xh1, yh0, yh1);
-        if (!hh) *reinterpret_cast<u32x4*>(dst + 2 * plane_bytes) = mk_u4(xlo, xlp, ylo, ylp);
+        if (with_res && !hh) *reinterpret_cast<u32x4*>(dst + 2 * plane_bytes) = mk_u4(xlo, xlp, ylo, ylp);
     }
 }
 
@@ -475,7 +475,7 @@ __global__ __launch_bounds__(ctb::NT) void convt2x2_bwd_pl_kernel(const CtbPlArg
                     }
                 }
                 char* dst = a.dx + ((((size_t)cur.n * nci + oc) * 3) * hw + (size_t)min(irow, a.h - 1) * a.w + min(icol, a.w - 1)) * 16;
-                store_chunk_px(X, Y, dst, hw * 16, hh, ok, WSU_F8_GLO_DIV);
+                store_chunk_px(X, Y, dst, hw * 16, hh, ok, WSU_F8_GLO_DIV, !HONLY);      // (products F16: gradient tensors carry no residual plane)
             }
             ++kt; c = 0;
             if (j + 1 < J) cur = ctb_tile_of(a, lw + kt * G);

@@ -71,7 +71,9 @@ __global__ __launch_bounds__(256) void ring_gather_pl_kernel(const char* __restr
 // so: the strips' conv outputs [4][nci][3][n][L + 2][16 B] (gradient encoding).  One thread per (image, ring pixel, 16-channel chunk).
 __global__ __launch_bounds__(256) void ring_fold_pl_kernel(const char* __restrict__ so, char* __restrict__ dx1, char* __restrict__ dx2,
                                                            const char* __restrict__ mask1, const char* __restrict__ mask2,
-                                                           int n, int h, int w, int nci, int nco1, int L) {
+                                                           int n, int h, int w, int nci, int nco1, int L, int gres) {
+    // gres = 0 (products F16): gradient tensors carry no residual plane -- it is neither read (dx, strips) nor written
+    const u32x4 zres = mk_u4(0, 0, 0, 0);
     const int nrows = (h - 2 != 1) ? 2 : 1, ncols = (w - 2 != 1) ? 2 : 1;
     const int rlo = min(1, h - 2), rhi = max(1, h - 2);
     const int per_img = nrows * w + ncols * (h - nrows);
@@ -97,7 +99,7 @@ __global__ __launch_bounds__(256) void ring_fold_pl_kernel(const char* __restric
         const size_t pix = (size_t)y * w + x;
         float v[16];
         pl_decode16(*reinterpret_cast<const u32x4*>(dx + pl_off(img, ncd, chd, 0, hw, pix)), *reinterpret_cast<const u32x4*>(dx + pl_off(img, ncd, chd, 1, hw, pix)),
-                    *reinterpret_cast<const u32x4*>(dx + pl_off(img, ncd, chd, 2, hw, pix)), WSU_F8_GLO_DIV, v);
+                    gres ? *reinterpret_cast<const u32x4*>(dx + pl_off(img, ncd, chd, 2, hw, pix)) : zres, WSU_F8_GLO_DIV, v);
         float add[16];
 #pragma unroll
         for (int e = 0; e < 16; ++e) add[e] = 0.f;
@@ -105,7 +107,7 @@ __global__ __launch_bounds__(256) void ring_fold_pl_kernel(const char* __restric
             const size_t p = (size_t)img * (L + 2) + col;
             float s[16];
             pl_decode16(*reinterpret_cast<const u32x4*>(so + pl_off(set, nci, ch, 0, shw, p)), *reinterpret_cast<const u32x4*>(so + pl_off(set, nci, ch, 1, shw, p)),
-                        *reinterpret_cast<const u32x4*>(so + pl_off(set, nci, ch, 2, shw, p)), WSU_F8_GLO_DIV, s);
+                        gres ? *reinterpret_cast<const u32x4*>(so + pl_off(set, nci, ch, 2, shw, p)) : zres, WSU_F8_GLO_DIV, s);
 #pragma unroll
             for (int e = 0; e < 16; ++e) add[e] += s[e];
         };
@@ -128,7 +130,7 @@ __global__ __launch_bounds__(256) void ring_fold_pl_kernel(const char* __restric
         pl_encode16(v, WSU_F8_GLO_DIV, h0, h1, lo);
         *reinterpret_cast<u32x4*>(dx + pl_off(img, ncd, chd, 0, hw, pix)) = h0;
         *reinterpret_cast<u32x4*>(dx + pl_off(img, ncd, chd, 1, hw, pix)) = h1;
-        *reinterpret_cast<u32x4*>(dx + pl_off(img, ncd, chd, 2, hw, pix)) = lo;
+        if (gres) *reinterpret_cast<u32x4*>(dx + pl_off(img, ncd, chd, 2, hw, pix)) = lo;
     }
 }
 
@@ -155,7 +157,9 @@ __device__ __forceinline__ const char* pl_r(const char* t, int n, int c, int cg,
 // stored activation the pool consumed.  One thread per (pooled pixel, 8-channel group); the argmax is recomputed from the stored values in the
 // window order (0,0) (0,1) (1,0) (1,1) of nn.MaxPool2d.
 __global__ __launch_bounds__(256) void pool_bwd_pl_kernel(const char* __restrict__ skip_g, const char* __restrict__ dyp, const char* __restrict__ act,
-                                                          char* __restrict__ g, int n, int h, int w, int c) {
+                                                          char* __restrict__ g, int n, int h, int w, int c, int gres) {
+    // gres = 0 (products F16): the gradients' residual planes (skip_g, dyp, g) are neither read nor written; the activation is read whole
+    const u32x2 zres = mk_u2(0, 0);
     const int hp = h >> 1, wp = w >> 1, ncg = c >> 3;
     const size_t hw = (size_t)h * w, hwp = (size_t)hp * wp;
     const long long total = (long long)n * ncg * hwp;
@@ -170,7 +174,7 @@ __global__ __launch_bounds__(256) void pool_bwd_pl_kernel(const char* __restrict
         const int cg = (int)(t % (ncg >> 1)) * 2 + cgl; const int img = (int)(t / (ncg >> 1));
         float d[8];
         pl_decode8(*reinterpret_cast<const u32x4*>(pl_h(dyp, img, c, cg, hwp, (size_t)yp * wp + xp)),
-                   *reinterpret_cast<const u32x2*>(pl_r(dyp, img, c, cg, hwp, (size_t)yp * wp + xp)), WSU_F8_GLO_DIV, d);
+                   gres ? *reinterpret_cast<const u32x2*>(pl_r(dyp, img, c, cg, hwp, (size_t)yp * wp + xp)) : zres, WSU_F8_GLO_DIV, d);
         float av[4][8];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -189,7 +193,7 @@ __global__ __launch_bounds__(256) void pool_bwd_pl_kernel(const char* __restrict
         for (int k = 0; k < 4; ++k) {
             const size_t pix = (size_t)(2 * yp + (k >> 1)) * w + 2 * xp + (k & 1);
             float v[8];
-            if (skip_g) pl_decode8(*reinterpret_cast<const u32x4*>(pl_h(skip_g, img, c, cg, hw, pix)), *reinterpret_cast<const u32x2*>(pl_r(skip_g, img, c, cg, hw, pix)), WSU_F8_GLO_DIV, v);
+            if (skip_g) pl_decode8(*reinterpret_cast<const u32x4*>(pl_h(skip_g, img, c, cg, hw, pix)), gres ? *reinterpret_cast<const u32x2*>(pl_r(skip_g, img, c, cg, hw, pix)) : zres, WSU_F8_GLO_DIV, v);
             else {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = 0.f;
@@ -202,7 +206,7 @@ __global__ __launch_bounds__(256) void pool_bwd_pl_kernel(const char* __restrict
             u32x4 hq; u32x2 rq;
             pl_encode8(v, WSU_F8_GLO_DIV, hq, rq);
             *reinterpret_cast<u32x4*>(const_cast<char*>(pl_h(g, img, c, cg, hw, pix))) = hq;
-            *reinterpret_cast<u32x2*>(const_cast<char*>(pl_r(g, img, c, cg, hw, pix))) = rq;
+            if (gres) *reinterpret_cast<u32x2*>(const_cast<char*>(pl_r(g, img, c, cg, hw, pix))) = rq;
         }
     }
 }
@@ -215,7 +219,7 @@ constexpr int HEADP_MAXCO = 4;
 template <int NCO>
 __global__ __launch_bounds__(256) void head_bwd_pl_kernel(const char* __restrict__ x, const float* __restrict__ wgt, const float* __restrict__ out,
                                                           const float* __restrict__ dout, char* __restrict__ g, float* __restrict__ part,
-                                                          int n, int hw_, int c, int cout) {
+                                                          int n, int hw_, int c, int cout, int gres) {
     const int ncg = c >> 3;                                   // 8 for the reference's 64 channels
     const int ppb = 256 / ncg;                                // pixels per block pass
     const int cg = threadIdx.x / ppb, pl = threadIdx.x % ppb;
@@ -249,7 +253,7 @@ __global__ __launch_bounds__(256) void head_bwd_pl_kernel(const char* __restrict
         u32x4 hq; u32x2 rq;
         pl_encode8(gv, WSU_F8_GLO_DIV, hq, rq);
         *reinterpret_cast<u32x4*>(const_cast<char*>(pl_h(g, img, c, cg, hw, pix))) = hq;
-        *reinterpret_cast<u32x2*>(const_cast<char*>(pl_r(g, img, c, cg, hw, pix))) = rq;
+        if (gres) *reinterpret_cast<u32x2*>(const_cast<char*>(pl_r(g, img, c, cg, hw, pix))) = rq;      // (products F16: no residual plane)
     }
     // block partial: part[block][o][c + 1]
     __shared__ float red[256 * 9];
@@ -291,7 +295,7 @@ __global__ __launch_bounds__(256) void head_bwd_pl_reduce_kernel(const float* __
 // block partials [block][c][NV], reduced in block order. ----------------------------------------------------------------------------------------
 template <bool FIRST>
 __global__ __launch_bounds__(256) void chansum_pl_kernel(const char* __restrict__ g, const float* __restrict__ img, float* __restrict__ part,
-                                                         int n, int h, int w, int c) {
+                                                         int n, int h, int w, int c, int gres) {
     constexpr int NV = FIRST ? 10 : 1;                        // 9 taps + bias | the plain sum
     const int ncg = c >> 3, ppb = 256 / ncg;
     const int cg = threadIdx.x / ppb, pl = threadIdx.x % ppb;
@@ -305,7 +309,7 @@ __global__ __launch_bounds__(256) void chansum_pl_kernel(const char* __restrict_
     for (long long p = (long long)blockIdx.x * ppb + pl; p < npix; p += (long long)gridDim.x * ppb) {
         const int im = (int)(p / hw); const size_t pix = (size_t)(p % hw);
         float gv[8];
-        pl_decode8(*reinterpret_cast<const u32x4*>(pl_h(g, im, c, cg, hw, pix)), *reinterpret_cast<const u32x2*>(pl_r(g, im, c, cg, hw, pix)), WSU_F8_GLO_DIV, gv);
+        pl_decode8(*reinterpret_cast<const u32x4*>(pl_h(g, im, c, cg, hw, pix)), gres ? *reinterpret_cast<const u32x2*>(pl_r(g, im, c, cg, hw, pix)) : mk_u2(0, 0), WSU_F8_GLO_DIV, gv);
         if constexpr (FIRST) {
             const int y = (int)(pix / w), x = (int)(pix % w);
             const float* src = img + (size_t)im * hw;
@@ -372,11 +376,11 @@ extern "C" int wsu_ring_gather_pl(const void* g, void* strips, int n, int h, int
     return wsu_check_launch("ring_gather_pl_kernel");
 }
 extern "C" int wsu_ring_fold_pl(const void* strips_out, void* dx1, void* dx2, const void* mask1, const void* mask2,
-                                int n, int h, int w, int cin, int csplit, int L, void* stream) {
+                                int n, int h, int w, int cin, int csplit, int L, int gres, void* stream) {
     const int nrows = (h - 2 != 1) ? 2 : 1, ncols = (w - 2 != 1) ? 2 : 1;
     const long long total = (long long)n * (nrows * w + ncols * (h - nrows)) * (cin / 16);
     hipLaunchKernelGGL(ring_fold_pl_kernel, dim3(grid_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream), (const char*)strips_out, (char*)dx1, (char*)dx2,
-                       (const char*)mask1, (const char*)mask2, n, h, w, cin / 16, csplit / 16, L);
+                       (const char*)mask1, (const char*)mask2, n, h, w, cin / 16, csplit / 16, L, gres);
     return wsu_check_launch("ring_fold_pl_kernel");
 }
 
@@ -384,12 +388,13 @@ extern "C" {
 
 // K7p: g = (skip_g + max-pool routing of dy_pool) * (act > 0) on planar tensors (layout: wsu.h): skip_g (optional), g at (h, w); dy_pool at (h/2, w/2);
 // act = the stored activation the pool consumed (c channels, multiple of 16; h, w even).  g may alias skip_g.
-int wsu_maxpool2x2_pl_bwd(const void* skip_g, const void* dy_pool, const void* act, void* g, int n, int h, int w, int c, void* stream) {
+int wsu_maxpool2x2_pl_bwd(const void* skip_g, const void* dy_pool, const void* act, void* g, int n, int h, int w, int c, int products, void* stream) {
     WSU_REQUIRE(dy_pool && act && g, "maxpool2x2_pl_bwd: null pointer");
+    WSU_REQUIRE(products == WSU_PRODUCTS_F16F8 || products == WSU_PRODUCTS_F16, "maxpool2x2_pl_bwd: products must be WSU_PRODUCTS_F16F8 or WSU_PRODUCTS_F16");
     WSU_REQUIRE(n > 0 && h > 0 && w > 0 && h % 2 == 0 && w % 2 == 0 && c > 0 && c % 16 == 0, "maxpool2x2_pl_bwd: bad shape");
     const long long total = (long long)n * (c / 8) * (h / 2) * (w / 2);
     hipLaunchKernelGGL(pool_bwd_pl_kernel, dim3(grid_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       (const char*)skip_g, (const char*)dy_pool, (const char*)act, (char*)g, n, h, w, c);
+                       (const char*)skip_g, (const char*)dy_pool, (const char*)act, (char*)g, n, h, w, c, products == WSU_PRODUCTS_F16 ? 0 : 1);
     return wsu_check_launch("pool_bwd_pl_kernel");
 }
 
@@ -399,16 +404,18 @@ size_t wsu_head_pl_bwd_workspace_bytes(int c, int cout) { return (size_t)SUM_BLO
 // (N, cout, H, W) fp32 (dout pre-scaled like every planar gradient), cout <= 4 -> g (planar gradient w.r.t. the PRE-activation of the layer that produced x:
 // its ReLU mask is applied), dw (cout, c), db (cout).
 int wsu_conv1x1_sigmoid_pl_bwd(const void* x, const float* w, const float* out, const float* dout, void* g, float* dw, float* db,
-                               float* workspace, size_t workspace_bytes, int n, int h, int wd, int c, int cout, void* stream) {
+                               float* workspace, size_t workspace_bytes, int n, int h, int wd, int c, int cout, int products, void* stream) {
     WSU_REQUIRE(x && w && out && dout && g && dw && db && workspace, "conv1x1_sigmoid_pl_bwd: null pointer");
+    WSU_REQUIRE(products == WSU_PRODUCTS_F16F8 || products == WSU_PRODUCTS_F16, "conv1x1_sigmoid_pl_bwd: products must be WSU_PRODUCTS_F16F8 or WSU_PRODUCTS_F16");
+    const int gres = products == WSU_PRODUCTS_F16 ? 0 : 1;
     WSU_REQUIRE(n > 0 && h > 0 && wd > 0 && c >= 16 && c <= 128 && (c & (c - 1)) == 0 && cout >= 1 && cout <= HEADP_MAXCO, "conv1x1_sigmoid_pl_bwd: bad shape c=%d cout=%d", c, cout);
     WSU_REQUIRE(workspace_bytes >= wsu_head_pl_bwd_workspace_bytes(c, cout), "conv1x1_sigmoid_pl_bwd: workspace too small");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const long long npix = (long long)n * h * wd;
     const int ppb = 256 / (c / 8);
     const int nblk = (int)((npix + ppb - 1) / ppb < SUM_BLOCKS ? (npix + ppb - 1) / ppb : SUM_BLOCKS);
-    if (cout == 1) hipLaunchKernelGGL(head_bwd_pl_kernel<1>, dim3(nblk), dim3(256), 0, s, (const char*)x, w, out, dout, (char*)g, workspace, n, h * wd, c, cout);
-    else hipLaunchKernelGGL(head_bwd_pl_kernel<HEADP_MAXCO>, dim3(nblk), dim3(256), 0, s, (const char*)x, w, out, dout, (char*)g, workspace, n, h * wd, c, cout);
+    if (cout == 1) hipLaunchKernelGGL(head_bwd_pl_kernel<1>, dim3(nblk), dim3(256), 0, s, (const char*)x, w, out, dout, (char*)g, workspace, n, h * wd, c, cout, gres);
+    else hipLaunchKernelGGL(head_bwd_pl_kernel<HEADP_MAXCO>, dim3(nblk), dim3(256), 0, s, (const char*)x, w, out, dout, (char*)g, workspace, n, h * wd, c, cout, gres);
     int rc = wsu_check_launch("head_bwd_pl_kernel");
     if (rc) return rc;
     hipLaunchKernelGGL(head_bwd_pl_reduce_kernel, dim3((cout * (c + 1) + 3) / 4), dim3(256), 0, s, workspace, dw, db, nblk, c, cout);
@@ -418,15 +425,16 @@ int wsu_conv1x1_sigmoid_pl_bwd(const void* x, const float* w, const float* out, 
 size_t wsu_chansum_pl_workspace_bytes(int c) { return (size_t)(SUM_BLOCKS + 1) * c * 10 * sizeof(float); }
 
 // K7p: db[c] = per-channel sum of a planar gradient (bias gradient of the transposed conv), c in {16, 32, 64, ..., 2048}
-int wsu_colsum_pl(const void* g, float* db, float* workspace, size_t workspace_bytes, int n, int h, int w, int c, void* stream) {
+int wsu_colsum_pl(const void* g, float* db, float* workspace, size_t workspace_bytes, int n, int h, int w, int c, int products, void* stream) {
     WSU_REQUIRE(g && db && workspace, "colsum_pl: null pointer");
+    WSU_REQUIRE(products == WSU_PRODUCTS_F16F8 || products == WSU_PRODUCTS_F16, "colsum_pl: products must be WSU_PRODUCTS_F16F8 or WSU_PRODUCTS_F16");
     WSU_REQUIRE(n > 0 && h > 0 && w > 0 && c >= 16 && c <= 2048 && c % 16 == 0 && 256 % (c / 8) == 0, "colsum_pl: bad shape (c=%d must be 16..2048 with 256 %% (c / 8) == 0)", c);
     WSU_REQUIRE(workspace_bytes >= wsu_chansum_pl_workspace_bytes(c), "colsum_pl: workspace too small");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const long long npix = (long long)n * h * w;
     const int ppb = 256 / (c / 8);
     const int nblk = (int)((npix + ppb - 1) / ppb < SUM_BLOCKS ? (npix + ppb - 1) / ppb : SUM_BLOCKS);
-    hipLaunchKernelGGL(chansum_pl_kernel<false>, dim3(nblk), dim3(256), 0, s, (const char*)g, (const float*)nullptr, workspace, n, h, w, c);
+    hipLaunchKernelGGL(chansum_pl_kernel<false>, dim3(nblk), dim3(256), 0, s, (const char*)g, (const float*)nullptr, workspace, n, h, w, c, products == WSU_PRODUCTS_F16 ? 0 : 1);
     int rc = wsu_check_launch("chansum_pl_kernel");
     if (rc) return rc;
     hipLaunchKernelGGL(block_sum_kernel, dim3((c + 3) / 4), dim3(256), 0, s, workspace, db, nblk, c);
@@ -435,8 +443,9 @@ int wsu_colsum_pl(const void* g, float* db, float* workspace, size_t workspace_b
 
 // K7p: weight / bias gradient of the first layer for a single input plane: g (planar gradient, c channels), img (N, 1, H, W) fp32 -> dw (c, 1, 3, 3), db (c) or NULL
 int wsu_conv3x3_first_pl_bwd_weight(const void* g, const float* img, float* dw, float* db, float* workspace, size_t workspace_bytes,
-                                    int n, int h, int w, int c, void* stream) {
+                                    int n, int h, int w, int c, int products, void* stream) {
     WSU_REQUIRE(g && img && dw && workspace, "conv3x3_first_pl_bwd_weight: null pointer");
+    WSU_REQUIRE(products == WSU_PRODUCTS_F16F8 || products == WSU_PRODUCTS_F16, "conv3x3_first_pl_bwd_weight: products must be WSU_PRODUCTS_F16F8 or WSU_PRODUCTS_F16");
     WSU_REQUIRE(n > 0 && h >= 2 && w >= 2 && c >= 16 && c <= 256 && c % 16 == 0 && 256 % (c / 8) == 0, "conv3x3_first_pl_bwd_weight: bad shape c=%d", c);
     WSU_REQUIRE(workspace_bytes >= wsu_chansum_pl_workspace_bytes(c), "conv3x3_first_pl_bwd_weight: workspace too small");
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -444,7 +453,7 @@ int wsu_conv3x3_first_pl_bwd_weight(const void* g, const float* img, float* dw, 
     const int ppb = 256 / (c / 8);
     const int nblk = (int)((npix + ppb - 1) / ppb < SUM_BLOCKS ? (npix + ppb - 1) / ppb : SUM_BLOCKS);
     float* sums = workspace + (size_t)SUM_BLOCKS * c * 10;
-    hipLaunchKernelGGL(chansum_pl_kernel<true>, dim3(nblk), dim3(256), 0, s, (const char*)g, img, workspace, n, h, w, c);
+    hipLaunchKernelGGL(chansum_pl_kernel<true>, dim3(nblk), dim3(256), 0, s, (const char*)g, img, workspace, n, h, w, c, products == WSU_PRODUCTS_F16 ? 0 : 1);
     int rc = wsu_check_launch("chansum_pl_kernel<first>");
     if (rc) return rc;
     hipLaunchKernelGGL(block_sum_kernel, dim3((c * 10 + 3) / 4), dim3(256), 0, s, workspace, sums, nblk, c * 10);

@@ -123,7 +123,7 @@ def _backward_pl(model, t: Dict[str, torch.Tensor], x: torch.Tensor, dout: torch
         return ops.conv3x3_pl_bwd_data(g, model._packed(name, W, "dgrad"), model._packed(name, W, "ring"), layer.in_channels,
                                        x1.shape[1] * 16, mask1, None, mask1_bits=mask1_bits, products=products)
 
-    g, grads["outconv.weight"], grads["outconv.bias"] = ops.conv1x1_sigmoid_pl_bwd(t["last"], model.outconv.weight, t["out"], dout)
+    g, grads["outconv.weight"], grads["outconv.bias"] = ops.conv1x1_sigmoid_pl_bwd(t["last"], model.outconv.weight, t["out"], dout, products=products)
     skip_g: Dict[int, torch.Tensor] = {}
     for depth in range(1, model.nsteps + 1):
         up, c1, c2 = dec_names(depth)
@@ -137,11 +137,11 @@ def _backward_pl(model, t: Dict[str, torch.Tensor], x: torch.Tensor, dout: torch
     for lvl in range(model.nsteps, -1, -1):
         a, b = ENC[lvl]
         if lvl < model.nsteps:
-            g = ops.maxpool2x2_pl_bwd(skip_g[lvl + 1], g, t["x" + b])
+            g = ops.maxpool2x2_pl_bwd(skip_g[lvl + 1], g, t["x" + b], products=products)
         xa = t["x" + a]
         g, _ = conv_bwd(b, g, xa, None, xa, mask1_bits=t.get("m_x" + a))
         if lvl == 0:
-            grads[a + ".weight"], grads[a + ".bias"] = ops.conv3x3_first_pl_bwd_weight(g, x)
+            grads[a + ".weight"], grads[a + ".bias"] = ops.conv3x3_first_pl_bwd_weight(g, x, products=products)
         else:
             g, _ = conv_bwd(a, g, t[f"xp{lvl}"], None, None)
     ops.scale_many_(list(grads.values()), scale[1:2])

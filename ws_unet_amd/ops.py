@@ -460,19 +460,21 @@ def convt2x2_pl_bwd_data(dy: torch.Tensor, w_packed_dgrad: torch.Tensor, cin: in
     return dx
 
 
-def maxpool2x2_pl_bwd(skip_g: Optional[torch.Tensor], dy_pool: torch.Tensor, act: torch.Tensor) -> torch.Tensor:
-    """(skip_g + routed dy_pool) * (act > 0) on planar tensors; writes into skip_g when given."""
+def maxpool2x2_pl_bwd(skip_g: Optional[torch.Tensor], dy_pool: torch.Tensor, act: torch.Tensor, products: str = "f16f8") -> torch.Tensor:
+    """(skip_g + routed dy_pool) * (act > 0) on planar tensors; writes into skip_g when given.  products 'f16': the gradient tensors carry no
+    residual plane (wsu.h, K7p notes)."""
     lib = _lib.load()
     _dev_check(skip_g, dy_pool, act)
     n, nch, _, h, w, _ = act.shape
     g = skip_g if skip_g is not None else torch.empty_like(act)
-    meta = {"bytes": float(n * nch * 16 * h * w * (9 if skip_g is not None else 6.75))}
+    gb = 2 if products == "f16" else 3                     # bytes per gradient element
+    meta = {"bytes": float(n * nch * 16 * h * w * (3 + gb + gb / 4 + (gb if skip_g is not None else 0)))}
     check(_launch("maxpool2x2_pl_bwd", meta, lambda: lib.wsu_maxpool2x2_pl_bwd(
-        _ptr(skip_g), dy_pool.data_ptr(), act.data_ptr(), g.data_ptr(), n, h, w, nch * 16, _stream())), "wsu_maxpool2x2_pl_bwd")
+        _ptr(skip_g), dy_pool.data_ptr(), act.data_ptr(), g.data_ptr(), n, h, w, nch * 16, products_id(products), _stream())), "wsu_maxpool2x2_pl_bwd")
     return g
 
 
-def conv1x1_sigmoid_pl_bwd(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, dout: torch.Tensor):
+def conv1x1_sigmoid_pl_bwd(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, dout: torch.Tensor, products: str = "f16f8"):
     """Head backward on a planar input: returns g (planar gradient), dw (cout, C, 1, 1), db (cout)."""
     lib = _lib.load()
     w2 = w.detach().reshape(w.shape[0], -1).contiguous()
@@ -483,14 +485,14 @@ def conv1x1_sigmoid_pl_bwd(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, 
     dw = torch.empty((cout, c, 1, 1), dtype=torch.float32, device=x.device)
     db = torch.empty(cout, dtype=torch.float32, device=x.device)
     ws = workspace(lib.wsu_head_pl_bwd_workspace_bytes(c, cout), x.device)
-    meta = {"bytes": float(n * h * wd * (c * 6 + cout * 8))}
+    meta = {"bytes": float(n * h * wd * (c * (5 if products == "f16" else 6) + cout * 8))}
     check(_launch("conv1x1_sigmoid_pl_bwd", meta, lambda: lib.wsu_conv1x1_sigmoid_pl_bwd(
         x.data_ptr(), w2.data_ptr(), out.data_ptr(), dout.data_ptr(), g.data_ptr(), dw.data_ptr(), db.data_ptr(),
-        ws.data_ptr(), ws.numel() * 4, n, h, wd, c, cout, _stream())), "wsu_conv1x1_sigmoid_pl_bwd")
+        ws.data_ptr(), ws.numel() * 4, n, h, wd, c, cout, products_id(products), _stream())), "wsu_conv1x1_sigmoid_pl_bwd")
     return g, dw, db
 
 
-def colsum_pl(g: torch.Tensor) -> torch.Tensor:
+def colsum_pl(g: torch.Tensor, products: str = "f16f8") -> torch.Tensor:
     """Per-channel sums of a planar gradient."""
     lib = _lib.load()
     _dev_check(g)
@@ -499,11 +501,11 @@ def colsum_pl(g: torch.Tensor) -> torch.Tensor:
     db = torch.empty(c, dtype=torch.float32, device=g.device)
     ws = workspace(lib.wsu_chansum_pl_workspace_bytes(c), g.device)
     check(_launch("colsum_pl", {"bytes": float(n * c * h * w * 3)}, lambda: lib.wsu_colsum_pl(
-        g.data_ptr(), db.data_ptr(), ws.data_ptr(), ws.numel() * 4, n, h, w, c, _stream())), "wsu_colsum_pl")
+        g.data_ptr(), db.data_ptr(), ws.data_ptr(), ws.numel() * 4, n, h, w, c, products_id(products), _stream())), "wsu_colsum_pl")
     return db
 
 
-def conv3x3_first_pl_bwd_weight(g: torch.Tensor, x_nchw: torch.Tensor, want_bias: bool = True):
+def conv3x3_first_pl_bwd_weight(g: torch.Tensor, x_nchw: torch.Tensor, want_bias: bool = True, products: str = "f16f8"):
     """First-layer weight / bias gradient from a planar gradient; single input plane."""
     lib = _lib.load()
     _dev_check(g, x_nchw)
@@ -514,8 +516,8 @@ def conv3x3_first_pl_bwd_weight(g: torch.Tensor, x_nchw: torch.Tensor, want_bias
     dw = torch.empty((c, 1, 3, 3), dtype=torch.float32, device=g.device)
     db = torch.empty(c, dtype=torch.float32, device=g.device) if want_bias else None
     ws = workspace(lib.wsu_chansum_pl_workspace_bytes(c), g.device)
-    check(_launch("conv3x3_first_pl_bwd_weight", {"bytes": float(n * h * w * (c * 3 + 4))}, lambda: lib.wsu_conv3x3_first_pl_bwd_weight(
-        g.data_ptr(), x_nchw.data_ptr(), dw.data_ptr(), _ptr(db), ws.data_ptr(), ws.numel() * 4, n, h, w, c, _stream())),
+    check(_launch("conv3x3_first_pl_bwd_weight", {"bytes": float(n * h * w * (c * (2 if products == "f16" else 3) + 4))}, lambda: lib.wsu_conv3x3_first_pl_bwd_weight(
+        g.data_ptr(), x_nchw.data_ptr(), dw.data_ptr(), _ptr(db), ws.data_ptr(), ws.numel() * 4, n, h, w, c, products_id(products), _stream())),
         "wsu_conv3x3_first_pl_bwd_weight")
     return dw, db
 
