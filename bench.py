@@ -376,9 +376,10 @@ def train_step_leg(dev, batch, size, steps=5, warmup=3, train_mode=None, train_p
     top = sorted(ks.items(), key=lambda kv: -kv[1]["total_ms"])[:3]
     flop = TRAIN_FLOP_PER_IMAGE_512 * (size / 512.0) ** 2 * batch
     res = {"workload": f"unet_2 fwd + L1WS + bwd + AdamW, batch={batch} synthetic {size}x{size} cover/stego pairs (BASELINE.json configs[2])",
-           "arithmetic": (f"train_mode={m.train_mode} train_products={m.train_products}: planar activations and gradients (3 bytes per element), fp32 accumulation; "
-                          "forward in the f16f8 arithmetic of the predict path; 3x3 data / weight gradients multiply "
-                          + ("the f16 parts only (exact f16 products; include/wsu.h WSU_PRODUCTS_F16)" if m.train_products == "f16" else "f16 products + both fp8 residual cross terms")
+           "arithmetic": (f"train_mode={m.train_mode} train_products={m.train_products}: planar activations (3 bytes per element), fp32 accumulation; "
+                          "forward in the f16f8 arithmetic of the predict path; the backward matrix kernels (3x3 and transposed-conv data / weight gradients) multiply "
+                          + ("the f16 parts only (exact f16 products; include/wsu.h WSU_PRODUCTS_F16) and gradient tensors hold f16 values (2 bytes per element)"
+                             if m.train_products == "f16" else "f16 products + both fp8 residual cross terms; gradient tensors f16 + e4m3 residual (3 bytes per element)")
                           if m.train_mode == "f16f8p"
                           else f"train_mode={m.train_mode} fwd={m.train_fwd_mode} bwd={m.train_bwd_mode} (fp32 storage and accumulation)"),
            "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3, "images_per_s": batch * steps / dt,
