@@ -113,23 +113,30 @@ def test_relu_mask_plane_of_the_forward_kernels(n, h, w, c1, c2, cout):
     assert torch.equal(fmask, _mask_bits_ref(f))
 
 
-@pytest.mark.parametrize("n,h,w,cin,csplit,cout", [(2, 32, 64, 64, 64, 64), (1, 37, 70, 128, 64, 64), (2, 18, 34, 64, 64, 128), (1, 96, 160, 128, 128, 64)])
-def test_conv3x3_pl_bwd_data_mask_bits_equal_activation_masks(n, h, w, cin, csplit, cout):
+@pytest.mark.parametrize("products", ["f16f8", "f16"])
+@pytest.mark.parametrize("n,h,w,cin,csplit,cout", [
+    (2, 32, 64, 64, 64, 64), (1, 37, 70, 128, 64, 64), (2, 18, 34, 64, 64, 128), (1, 96, 160, 128, 128, 64),
+    (3, 96, 160, 64, 64, 32), (3, 96, 160, 64, 64, 48), (2, 200, 96, 64, 64, 80),     # 2 / 3 / 5 steps per tile, several tiles per workgroup: with products
+])                                                                                     # 'f16' the mask pieces ride the counted vmcnt waits of the 4-stage ring
+def test_conv3x3_pl_bwd_data_mask_bits_equal_activation_masks(n, h, w, cin, csplit, cout, products):
     """The data gradient fed the 1-bit planes (LDS-DMA of 4 KB per tile) returns bitwise what it returns fed the activations themselves
     (16 granule loads per loader lane and tile): same masks, same arithmetic (reflect padding incl. the border fold; fused concat)."""
     ops = _ops()
+    live = slice(0, 2) if products == "f16" else slice(0, 3)
     wd = _rand((cout, cin, 3, 3), 41, (2.0 / (9 * cin)) ** 0.5).to(DEV)
     g = planar_encode(_rand((n, cout, h, w), 42), GRAD_LO)
     act = torch.relu(_rand((n, cin, h, w), 43))
     m1 = planar_encode(act[:, :csplit]); m2 = planar_encode(act[:, csplit:]) if csplit < cin else None
     wp, wr = ops.pack_conv3x3(wd, ops.MODE_F16F8, dgrad=True), ops.pack_conv3x3_ring(wd)
-    a1, a2 = ops.conv3x3_pl_bwd_data(g, wp, wr, cin, csplit, m1, m2)
-    b1, b2 = ops.conv3x3_pl_bwd_data(g, wp, wr, cin, csplit, m1, m2, mask1_bits=_mask_bits_ref(m1), mask2_bits=None if m2 is None else _mask_bits_ref(m2))
-    torch.cuda.synchronize()
-    assert torch.equal(a1.view(torch.int32), b1.view(torch.int32))
-    if a2 is not None:
-        assert torch.equal(a2.view(torch.int32), b2.view(torch.int32))
-    got = planar_decode(b1, GRAD_LO)
+    a1, a2 = ops.conv3x3_pl_bwd_data(g, wp, wr, cin, csplit, m1, m2, products=products)
+    mb1, mb2 = _mask_bits_ref(m1), None if m2 is None else _mask_bits_ref(m2)
+    for rep_ in range(3):                                                # (repeats: a missing wait on the mask pieces shows as a launch-to-launch difference)
+        b1, b2 = ops.conv3x3_pl_bwd_data(g, wp, wr, cin, csplit, m1, m2, mask1_bits=mb1, mask2_bits=mb2, products=products)
+        torch.cuda.synchronize()
+        assert torch.equal(a1[:, :, live].view(torch.int32), b1[:, :, live].view(torch.int32))
+        if a2 is not None:
+            assert torch.equal(a2[:, :, live].view(torch.int32), b2[:, :, live].view(torch.int32))
+    got = planar_decode(b1, GRAD_LO, f16_only=products == "f16")
     assert float(got[(act[:, :csplit] <= 0)].abs().max()) == 0.0 and float(got.abs().max()) > 0
 
 
