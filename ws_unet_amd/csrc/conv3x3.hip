@@ -31,9 +31,9 @@ constexpr int NPIX_IN = IW * IH;                         // 340
 constexpr int PLANE_IN = NPIX_IN * 16 + 96;              // 5536 B: planes 8 dwords apart mod 32 banks
 constexpr int LDS_IN = WSU_GRAN * PLANE_IN;              // 22144
 constexpr int LDS_W = 9 * WSU_GRAN * WSU_COB * 16;       // 36864
-constexpr int LDS_MAIN = LDS_IN + LDS_W;                 // 59008
+[[maybe_unused]] constexpr int LDS_MAIN = LDS_IN + LDS_W;                 // 59008
 constexpr int W_ITEMS = LDS_W / 16;                      // 2304 x 16 B
-constexpr int IN_ITEMS = NPIX_IN * WSU_GRAN;             // 1360 x 16 B (680 x 32 B for BF16X3)
+[[maybe_unused]] constexpr int IN_ITEMS = NPIX_IN * WSU_GRAN;             // 1360 x 16 B (680 x 32 B for BF16X3)
 // Workgroup shapes on the same 8x32-pixel x 64-channel tile:
 //   NW = 4: 256 threads, wave tile 64 co x 64 px (4 MFMA tiles), 2 waves/SIMD
 //   NW = 8: 512 threads, wave tile 32 co x 64 px (2 MFMA tiles), <= 128 VGPRs -> 4 waves/SIMD

@@ -212,7 +212,7 @@ __device__ __forceinline__ void pl_loader(const PlArgs& a, char* smem, int lane,
     float* s_w1 = reinterpret_cast<float*>(smem + LDS_F1);
     float* s_b1 = s_w1 + 9 * 64;
     unsigned char* s_mask = reinterpret_cast<unsigned char*>(smem + LDS_EXTRA);   // GRAD: [4 output chunks][2 f16 planes][512 px] bytes of 8 mask bits (the bias slot)
-    unsigned long long t_wait = 0, t_bar = 0, t_dma = 0, s0 = 0, s1 = 0, s2 = 0, s3 = 0, t0 = 0, rt0 = 0;
+    [[maybe_unused]] unsigned long long t_wait = 0, t_bar = 0, t_dma = 0, s0 = 0, s1 = 0, s2 = 0, s3 = 0, t0 = 0, rt0 = 0;     // stamps build only
     STAMP(t0);
 #ifdef WSU_PL_STAMPS
     rt0 = __builtin_amdgcn_s_memrealtime();
@@ -491,8 +491,8 @@ __global__ __launch_bounds__(NT) void conv3x3_pl_kernel(const PlArgs a) {
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     }
-    unsigned long long t_wait = 0, t_bar = 0, t_dma = 0, t_mma = 0, t_epi = 0, t0 = 0, rt0 = 0;
-    unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0;
+    [[maybe_unused]] unsigned long long t_wait = 0, t_bar = 0, t_dma = 0, t_mma = 0, t_epi = 0, t0 = 0, rt0 = 0;               // stamps build only
+    [[maybe_unused]] unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0;
     STAMP(t0);
 #ifdef WSU_PL_STAMPS
     rt0 = __builtin_amdgcn_s_memrealtime();
