@@ -270,3 +270,70 @@ def test_small_grid_split_equals_the_unsplit_kernel():
         assert rr.returncode == 0, rr.stderr[-2000:]
         outs.append(torch.load(out, weights_only=True)); os.remove(out)
     assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32))       # 8 tiles x 4 blocks = 32 items -> 64 half-items when split
+
+
+# ---- block-scaled fp4 cross terms (x_residual = 2, round 3) ---------------------------------------------------------------------------------
+def _fp4(v):
+    """round to the e2m1 grid {0, .5, 1, 1.5, 2, 3, 4, 6} (nearest even, saturating), as v_cvt_scalef32_pk_fp4_* does (tools/fp4_probe.hip)"""
+    a = v.abs()
+    e = torch.floor(torch.log2(a.clamp_min(1e-30))).clamp(0, 2)
+    step = torch.exp2(e - 1)
+    return torch.sign(v) * (torch.round(a / step) * step).clamp_max(6.0)
+
+
+def _q4_blocks(hpart, res2048, dim):
+    """hpart: the f16 parts, res2048: the residuals * 2^11, blocks of 16 along `dim` -> (fp4 copy, fp4 residual) at true scale / with the 2^-11 undone"""
+    shp = list(hpart.shape)
+    blk = shp[:dim] + [shp[dim] // 16, 16] + shp[dim + 1:]
+    hv, rv = hpart.reshape(blk), res2048.reshape(blk)
+    amax = hv.abs().amax(dim=dim + 1, keepdim=True)
+    # E = exponent field of the largest |f16| - 15 - 1 (zero / subnormal blocks: field 0)
+    ef = torch.where(amax >= 2.0 ** -14, torch.floor(torch.log2(amax.clamp_min(1e-30))) + 15, torch.zeros_like(amax))
+    sc = torch.exp2(ef - 16)
+    return (_fp4(hv / sc) * sc).reshape(shp), (_fp4(rv / sc) * sc / 2048.0).reshape(shp)
+
+
+def _conv3x3_q4_ref(x, w, b):
+    """the arithmetic of conv3x3_pl(..., x_residual=2) on the CPU, fp64 accumulation: x = what the planar tensor holds (f16 part + e4m3 residual)"""
+    xp = F.pad(x, (1, 1, 1, 1), mode="reflect")
+    xh = xp.half().float()
+    xr = ((xp - xh) * 4096).to(torch.float8_e4m3fn).float() / 4096                      # the stored residual
+    wh = w.half().float()
+    xc4, xr4 = _q4_blocks(xh, xr * 2048.0, 1)
+    wc4, wr4 = _q4_blocks(wh, (w - wh) * 2048.0, 1)
+    y = F.conv2d(xh.double(), wh.double(), b.double()) + F.conv2d(xc4.double(), wr4.double()) + F.conv2d(xr4.double(), wc4.double())
+    return y.float()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,h,w,c1,c2,cout,pool", [
+    (1, 16, 32, 64, 0, 64, False),            # one tile, 4 chunk steps
+    (2, 40, 72, 64, 0, 128, False),           # partial tiles, 2 output blocks
+    (2, 32, 64, 64, 64, 64, True),            # fused concat + pool
+    (1, 96, 160, 128, 0, 64, False),          # several tiles per workgroup would need > 256 tiles: 30 tiles x 8 steps
+    (5, 128, 128, 32, 0, 64, False),          # 320 tiles of 2 steps: workgroups walk two tiles, the three-slot input ring wraps across tiles
+    (1, 2, 2, 16, 0, 64, False),              # one chunk per tile (J = 1)
+])
+def test_conv3x3_pl_q4_matches_emulation(n, h, w, c1, c2, cout, pool):
+    """x_residual = 2: f16 products on the f16 pipe + both cross terms as block-scaled fp4 -- equal to the CPU emulation of exactly that arithmetic
+    (block exponents from the largest f16 part, fp4 rounding to nearest even) up to accumulation order and the store encoding; and within
+    2e-3 of the exact convolution relative to the output's scale (the cross terms now carry ~3 bits instead of e4m3's 4)."""
+    from ws_unet_amd import ops
+    cin = c1 + c2
+    g = torch.Generator().manual_seed(7)
+    x = planar_decode(planar_encode(torch.relu(torch.randn((n, cin, h, w), generator=g)) * torch.exp2(torch.randint(-3, 4, (n, cin, 1, 1), generator=g).float())))
+    wgt = torch.randn((cout, cin, 3, 3), generator=g) * (2.0 / (9 * cin)) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    ref = torch.relu(_conv3x3_q4_ref(x, wgt, b))
+    exact = torch.relu(F.conv2d(F.pad(x, (1, 1, 1, 1), mode="reflect").double(), wgt.double(), b.double())).float()
+    wp = ops.pack_conv3x3_f4(wgt.to(DEV))
+    x1 = planar_encode(x[:, :c1]).to(DEV)
+    x2 = planar_encode(x[:, c1:]).to(DEV) if c2 else None
+    out = ops.conv3x3_pl(x1, x2, wp, b.to(DEV), cout, pool=pool, x_residual=2)
+    torch.cuda.synchronize()
+    y = planar_decode(out[0] if pool else out)
+    scale = float(exact.abs().max())
+    assert float((y - ref).abs().max()) < 3e-5 * scale, float((y - ref).abs().max()) / scale
+    assert float((y - exact).abs().max()) < 2e-3 * scale, float((y - exact).abs().max()) / scale
+    if pool:
+        assert float((planar_decode(out[1]) - F.max_pool2d(y, 2)).abs().max()) == 0.0

@@ -39,15 +39,20 @@ def q_small(v, fmt):
     return torch.sign(v) * q.clamp_max(vmax)
 
 
+HW_RULE = False          # True: the scale rule a loader can afford -- 2^(floor(log2 amax) - 1) from the exponent field of the block's largest f16 (amax / scale in [2, 4))
+
+
 def block_scale(amax, fmt):
     """E8M0 scale 2^E with amax / 2^E <= the format's largest value (no saturation), as large a use of the range as a power of two allows"""
+    if HW_RULE:
+        return torch.exp2(torch.floor(torch.log2(amax.clamp_min(2.0 ** -14))) - 1)
     vmax = FORMATS[fmt][2]
     return torch.exp2(torch.ceil(torch.log2(amax.clamp_min(1e-30) / vmax)))
 
 
 def quant_pair(c, r, fmt, block_dims):
     """copy c and pre-scaled residual r share one scale per block (block = all of `block_dims` of a 16-channel chunk view)"""
-    amax = torch.maximum(c.abs().amax(dim=block_dims, keepdim=True), r.abs().amax(dim=block_dims, keepdim=True))
+    amax = c.abs().amax(dim=block_dims, keepdim=True) if HW_RULE else torch.maximum(c.abs().amax(dim=block_dims, keepdim=True), r.abs().amax(dim=block_dims, keepdim=True))
     s = block_scale(amax, fmt)
     return q_small(c / s, fmt) * s, q_small(r / s, fmt) * s
 
@@ -56,6 +61,8 @@ def split_x(x, fmt):
     """activations (N, C, H, W): returns f16 part, Q(copy), Q(residual) (true scale)"""
     h = q16(x)
     r = x - h
+    if HW_RULE and fmt != "e4m3":
+        r = (r * 4096).to(torch.float8_e4m3fn).to(torch.float32) / 4096          # the loader sees the STORED e4m3 residual
     if fmt == "e4m3":
         c8 = (h / 4).to(torch.float8_e4m3fn).to(torch.float32) * 4
         r8 = (r * 4096).to(torch.float8_e4m3fn).to(torch.float32) / 4096
@@ -137,11 +144,14 @@ def main():
     with torch.no_grad():
         ref = forward(x.double(), {k: v.double() for k, v in sd.items()}, None).float()
         print(f"unet_2 'he' weights, {batch} x {size} x {size}: output mean {ref.mean():.4f} std {ref.std():.4f}")
-        for fmt in ("e4m3", "e2m3", "e3m2", "e2m1"):
+        global HW_RULE
+        for fmt, hw in (("e4m3", False), ("e2m3", False), ("e3m2", False), ("e2m1", False), ("e2m1", True), ("e2m3", True)):
             t0 = time.time()
+            HW_RULE = hw
             y = forward(x, sd, fmt)
             d = (y - ref).abs()
-            print(f"  cross terms in {fmt:5s}{' (fixed scales, today)' if fmt == 'e4m3' else ' (block scales)     '}: MAE {d.mean().item():.3e}  max {d.max().item():.3e}   [{time.time() - t0:.0f} s]", flush=True)
+            what = " (fixed scales, today)" if fmt == "e4m3" else " (block scales, exponent-field rule, stored residuals)" if hw else " (block scales)"
+            print(f"  cross terms in {fmt:5s}{what}: MAE {d.mean().item():.3e}  max {d.max().item():.3e}   [{time.time() - t0:.0f} s]", flush=True)
 
 
 if __name__ == "__main__":

@@ -51,6 +51,8 @@ SIGNATURES = {
     "wsu_relu_mask_bytes": (c_size_t, [c_int] * 4),
     "wsu_conv3x3_pl_fused_first_fwd": (c_int, [_P] * 7 + [c_int] * 5 + [_P, _P]),
     "wsu_convt2x2_pl_fwd": (c_int, [_P, _P, _P, _P] + [c_int] * 5 + [_P, _P]),
+    "wsu_conv3x3_packed_f4_bytes": (c_size_t, [c_int] * 2),
+    "wsu_conv3x3_pack_f4": (c_int, [_P, _P, c_int, c_int, _P]),
     "wsu_conv3x3_pl_bwd_data_workspace_bytes": (c_size_t, [c_int] * 5),
     "wsu_conv3x3_pack_ring": (c_int, [_P, _P, c_int, c_int, _P]),
     "wsu_conv3x3_pl_bwd_data": (c_int, [_P, _P, _P, _P, c_size_t, _P, _P, c_int, _P, _P, _P, _P] + [c_int] * 7 + [_P]),

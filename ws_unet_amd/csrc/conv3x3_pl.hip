@@ -38,6 +38,19 @@ constexpr int LDS_IN_H = 2 * PLANE;                       // 19584
 constexpr int STAGE_H = LDS_IN_H + 9 * 2 * WSU_COB * 16;  // 38016
 constexpr int NSTAGE_H = 4;
 static_assert(NSTAGE_H * STAGE_H <= 2 * STAGE, "the HONLY stages live in the two full stages' LDS");
+// Q4 (round 3, kernel variant of the forward): the two cross terms as ONE block-scaled fp4 (e2m1) MFMA operand pair -- a 16-byte granule per
+// (pixel, chunk) = fp4(f16 part) x 16 | fp4(residual * 2^11) x 16 with one E8M0 scale byte, derived by the loader waves from the three stored
+// granules; weights from wsu_conv3x3_pack_f4 ([tap][f16 ci 0-7 | f16 ci 8-15 | fp4(residual * 2^11) x 16 | fp4(f16 part) x 16][64 co] + a scale
+// byte per (tap, co)).  5 fp4 instructions of 32 cycles instead of 64: 14 instead of 19 matrix units per chunk; 27 instead of 36 KB of weights per
+// step.  The derivation needs all three planes of a pixel in ONE lane and time to run: the input pieces are assigned by segment (a lane fetches
+// planes 0 / 1 of its pixels by LDS-DMA and their residual granules into registers) and travel TWO steps ahead into a ring of three input slots,
+// the weights one step ahead into two slots -- the loader converts step j+1's pixels while the matrix waves multiply step j.
+constexpr int Q4_IN_SLOT = 3 * PLANE + 640;                // f16 ch 0-7 | f16 ch 8-15 | Q | S (612 scale bytes) = 30016
+constexpr int Q4_W_GRAN = 9 * 3 * WSU_COB * 16;            // 27648
+constexpr int Q4_W_SLOT = Q4_W_GRAN + 1024;                // + [9][64] scale bytes, padded to a DMA piece: 28672 = the packed slice of a (block, chunk)
+constexpr int Q4_NIN = 3, Q4_NW = 2;
+constexpr int Q4_W_BASE = Q4_NIN * Q4_IN_SLOT;             // 90048
+static_assert(Q4_W_BASE + Q4_NW * Q4_W_SLOT <= 2 * STAGE && Q4_W_SLOT % 1024 == 0 && (Q4_W_SLOT / 1024) % 4 == 0, "Q4 rings live in the two stages' LDS; 28 weight pieces = 7 per loader wave");
 constexpr int NWAVE = 8, NLOAD = 4, NT = (NWAVE + NLOAD) * 64;      // 8 matrix waves + 4 loader waves (one per SIMD)
 constexpr int IN_SEG = (NPIX + 63) / 64;                  // 10 wave-instructions per plane (the last one 36 lanes wide)
 constexpr int HBM_PLANES = 3;                             // stored planes per chunk: f16 ch 0-7 | f16 ch 8-15 | e4m3 residuals; LDS plane 3 is derived
@@ -78,6 +91,7 @@ struct PlArgs {
     unsigned char* relu_mask_out; const unsigned char* mbits; const unsigned char* mbits2;
     int msplit;                                           // 1: work items are half-blocks of 32 output channels (kernel variant MSPLIT); ncb = 2 * cout / 64
     int honly;                                            // GRAD, 1: f16 products only (kernel variant HONLY; wsu.h "products" of the backward entry points)
+    int q4;                                               // forward, 1: block-scaled fp4 cross terms (kernel variant Q4; weights from wsu_conv3x3_pack_f4)
 };
 
 struct Tile { int n, y0, x0, cb, mh; };                   // mh: the 32-channel half of block cb this item computes (kernel variant MSPLIT), else 0
@@ -443,6 +457,102 @@ __device__ __forceinline__ void pl_loader(const PlArgs& a, char* smem, int lane,
 #endif
 }
 
+
+// ================= loader wave LW of the Q4 variant (see the Q4 notes at the top) ==========================================================
+#define WSU_VMCNT_CASE(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); break;
+__device__ __forceinline__ void wsu_wait_vmcnt(int n) {      // all but the n youngest vector-memory operations of this wave have completed
+    switch (n) {
+        WSU_VMCNT_CASE(0) WSU_VMCNT_CASE(1) WSU_VMCNT_CASE(2) WSU_VMCNT_CASE(3) WSU_VMCNT_CASE(4) WSU_VMCNT_CASE(5) WSU_VMCNT_CASE(6) WSU_VMCNT_CASE(7)
+        WSU_VMCNT_CASE(8) WSU_VMCNT_CASE(9) WSU_VMCNT_CASE(10) WSU_VMCNT_CASE(11) WSU_VMCNT_CASE(12) WSU_VMCNT_CASE(13) WSU_VMCNT_CASE(14) WSU_VMCNT_CASE(15)
+        WSU_VMCNT_CASE(16) WSU_VMCNT_CASE(17) WSU_VMCNT_CASE(18) WSU_VMCNT_CASE(19) WSU_VMCNT_CASE(20) WSU_VMCNT_CASE(21) WSU_VMCNT_CASE(22) WSU_VMCNT_CASE(23)
+        WSU_VMCNT_CASE(24) WSU_VMCNT_CASE(25) WSU_VMCNT_CASE(26) WSU_VMCNT_CASE(27) WSU_VMCNT_CASE(28) WSU_VMCNT_CASE(29) WSU_VMCNT_CASE(30) WSU_VMCNT_CASE(31)
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+
+template <int LW>
+__device__ __forceinline__ void pl_loader_q4(const PlArgs& a, char* smem, int lane, int lw, int G, int J) {
+    constexpr int NSEG = LW < 2 ? 3 : 2;                              // this wave's 64-pixel segments of the 612-pixel input tile: LW, LW + 4, LW + 8
+    constexpr int NW = Q4_W_SLOT / 1024 / NLOAD;                      // 7 weight pieces per step
+    constexpr int NIN = 3 * NSEG;                                     // vector-memory operations of an input issue: 2 DMA pieces + 1 register load per segment
+    lds_char* smem3 = (lds_char*)smem;
+    const unsigned hw16 = (unsigned)(a.h * a.w) * 16u;
+    unsigned voff[NSEG];                                              // per segment: this lane's pixel inside a plane (the issue cursor's tile)
+    auto plan = [&](const Tile& t) __attribute__((always_inline)) {
+        WSU_STATIC_FOR(NSEG, k, {
+            const int idx = min((LW + NLOAD * k) * 64 + lane, NPIX - 1);
+            const int r = idx / IW, c = idx - r * IW;
+            const int yy = wsu_reflect(t.y0 - 1 + r, a.h), xx = wsu_reflect(t.x0 - 1 + c, a.w);
+            voff[k] = (unsigned)(yy * a.w + xx) * 16u;
+        });
+    };
+    u32x4 rres[2][NSEG];                                              // the residual granules of the step being fetched / the step being converted
+    int issued = 0, mark_in[Q4_NIN] = {0, 0, 0}, mark_w[Q4_NW] = {0, 0};   // operation counts of this wave: total, and the total right after an issue
+    Tile ti = tile_of(a, lw); int ci = 0, kti = 0;                    // cursor of the input issue
+    int cbw = ti.cb, cw = 0, ktw = 0;                                 // cursor of the weight issue (block, chunk)
+    auto issue_in = [&](int s) __attribute__((always_inline)) {
+        const unsigned plane3 = hw16 * HBM_PLANES;
+        const char* in_src = ci < a.nch1 ? a.x1 + ((size_t)ti.n * a.nch1 + ci) * plane3 : a.x2 + ((size_t)ti.n * (a.nch - a.nch1) + (ci - a.nch1)) * plane3;
+        const auto rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(in_src), 0, (int)plane3, 0x00020000);
+        lds_char* slot = smem3 + (s % Q4_NIN) * Q4_IN_SLOT;
+        WSU_STATIC_FOR(NSEG, k, {
+            constexpr int seg = LW + NLOAD * k;
+            const bool live = seg < IN_SEG - 1 || lane < NPIX - (IN_SEG - 1) * 64;
+            if (live) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void*)(slot + seg * 1024), 16, voff[k], 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void*)(slot + PLANE + seg * 1024), 16, voff[k], (int)hw16, 0, 0);
+            }
+            rres[s & 1][k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)voff[k], (int)(2u * hw16), 0));
+        });
+        issued += NIN; mark_in[s % Q4_NIN] = issued;
+        if (++ci == a.nch && s + 1 < J) { ci = 0; ++kti; ti = tile_of(a, lw + kti * G); plan(ti); }
+    };
+    auto issue_w = [&](int s) __attribute__((always_inline)) {
+        const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(a.wp), 0, 0x7FFFFFF0, 0x00020000);
+        const int w_base = (cbw * a.nch + cw) * Q4_W_SLOT;
+        lds_char* slot = smem3 + Q4_W_BASE + (s % Q4_NW) * Q4_W_SLOT;
+        WSU_STATIC_FOR(NW, k, {
+            constexpr int piece = LW + NLOAD * k;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void*)(slot + piece * 1024), 16, (unsigned)lane * 16u, w_base + piece * 1024, 0, 0);
+        });
+        issued += NW; mark_w[s % Q4_NW] = issued;
+        if (++cw == a.nch && s + 1 < J) { cw = 0; ++ktw; cbw = tile_of(a, lw + ktw * G).cb; }
+    };
+    auto derive = [&](int s) __attribute__((always_inline)) {        // Q granule + scale byte of this lane's pixels of step s (planes 0 / 1 landed in LDS, residuals in registers)
+        char* slot = smem + (s % Q4_NIN) * Q4_IN_SLOT;
+        WSU_STATIC_FOR(NSEG, k, {
+            constexpr int seg = LW + NLOAD * k;
+            const int idx = seg * 64 + lane;
+            if (seg < IN_SEG - 1 || idx < NPIX) {
+                const u32x4 h0 = *reinterpret_cast<const u32x4*>(slot + idx * 16), h1 = *reinterpret_cast<const u32x4*>(slot + PLANE + idx * 16);
+                uint32_t sb;
+                const u32x4 q = wsu_q4_encode_x(h0, h1, rres[s & 1][k], &sb);
+                *reinterpret_cast<u32x4*>(slot + 2 * PLANE + idx * 16) = q;
+                *reinterpret_cast<unsigned char*>(slot + 3 * PLANE + idx) = (unsigned char)sb;
+            }
+        });
+    };
+    if (J <= 0) return;
+    plan(ti);
+    issue_w(0);
+    issue_in(0);
+    if (J > 1) issue_in(1);
+    wsu_wait_vmcnt(issued - mark_in[0]);                             // step 0's inputs (its weights are older)
+    derive(0);
+    for (int j = 0; j < J; ++j) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // this wave's Q / S of step j are written
+        __builtin_amdgcn_s_barrier();                                 // barrier j: step j is complete in LDS; every matrix wave has left step j - 1
+        asm volatile("" ::: "memory");
+        if (j + 1 >= J) break;
+        issue_w(j + 1);                                               // its slot held step j - 1
+        if (j + 2 < J) issue_in(j + 2);                               // its slot held step j - 1
+        wsu_wait_vmcnt(issued - mark_in[(j + 1) % Q4_NIN]);           // step j + 1's inputs, issued a whole step ago
+        derive(j + 1);
+        wsu_wait_vmcnt(issued - mark_w[(j + 1) % Q4_NW]);             // step j + 1's weights
+    }
+}
+
 // HEAD / POOL are compile-time: the kernel sits at the 168-register step (three waves per SIMD), and the head's partial sums or the pool's
 // exchange registers would otherwise be carried -- and spilled -- by the variants that do not use them.
 // XRES = false: the activations' residual plane is neither loaded nor multiplied (one cross term per product, the weights' residual:
@@ -456,7 +566,7 @@ __device__ __forceinline__ void pl_loader(const PlArgs& a, char* smem, int lane,
 // CUs with half the matrix work per step each; the input tile and the whole 64-channel weight slice are fetched as before.
 // HONLY (round 3, a training arithmetic of the data gradient: wsu.h "products"): f16 products only -- the 9 f16 instructions of a chunk, no
 // cross terms; the residual plane of the gradient, the e4m3 weight planes and the derived plane are neither fetched nor built (needs XRES = false).
-template <int HC, bool POOL, bool XRES = true, bool F1 = false, bool GRAD = false, bool MSPLIT = false, bool HONLY = false>   // HC = head planes compiled in: 0 (no head), 1 (the reference's single output plane) or 4 (1..4)
+template <int HC, bool POOL, bool XRES = true, bool F1 = false, bool GRAD = false, bool MSPLIT = false, bool HONLY = false, bool Q4 = false>   // HC = head planes compiled in: 0 (no head), 1 (the reference's single output plane) or 4 (1..4)
 __global__ __launch_bounds__(NT) void conv3x3_pl_kernel(const PlArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -500,7 +610,15 @@ __global__ __launch_bounds__(NT) void conv3x3_pl_kernel(const PlArgs a) {
 
     if (wv >= NWAVE) {
         // ================= loader waves (pl_loader<LW, ...>: the slot geometry of a wave is compile-time) ===========================
-        if constexpr (F1) {
+        if constexpr (Q4) {
+            static_assert(!Q4 || (XRES && !F1 && !GRAD && !HONLY), "Q4 is a variant of the forward");
+            switch (wv - NWAVE) {
+                case 0: pl_loader_q4<0>(a, smem, lane, lw, G, J); break;
+                case 1: pl_loader_q4<1>(a, smem, lane, lw, G, J); break;
+                case 2: pl_loader_q4<2>(a, smem, lane, lw, G, J); break;
+                default: pl_loader_q4<3>(a, smem, lane, lw, G, J); break;
+            }
+        } else if constexpr (F1) {
             pl_loader<0, XRES, F1, GRAD, HONLY>(a, smem, lane, lw, G, J, wv - NWAVE);
         } else {
             switch (wv - NWAVE) {
@@ -532,6 +650,8 @@ __global__ __launch_bounds__(NT) void conv3x3_pl_kernel(const PlArgs a) {
         asm volatile("" ::: "memory");
         STAMP(s2);
         char* st = HONLY ? smem + (j % NSTAGE_H) * STAGE_H : smem + (j & 1) * STAGE;
+        [[maybe_unused]] const char* q_in = smem + (j % Q4_NIN) * Q4_IN_SLOT;                 // Q4: this step's input slot / weight slot
+        [[maybe_unused]] const char* q_w = smem + Q4_W_BASE + (j % Q4_NW) * Q4_W_SLOT;
         STAMP(s3);
         if (c == 0) {
 #pragma unroll
@@ -542,8 +662,8 @@ __global__ __launch_bounds__(NT) void conv3x3_pl_kernel(const PlArgs a) {
                     for (int r = 0; r < 16; ++r) acc[m][q][r] = 0.f;
         }
         // ---- matrix section: identical arithmetic (and accumulation order) to conv3x3_kernel<F16F8> -----------------------------
-        const char* ldsA = st + (HONLY ? LDS_IN_H : LDS_IN) + (cur.mh * 32 + l31) * 16;   // + ((tap*4 + g)*64 + m*32)*16   (HONLY: tap*2 + g)
-        const char* ldsB = st + ((2 * wv) * IW + l31) * 16;                   // + g*PLANE + ((q+dy)*IW + dx)*16
+        const char* ldsA = Q4 ? q_w + (cur.mh * 32 + l31) * 16 : st + (HONLY ? LDS_IN_H : LDS_IN) + (cur.mh * 32 + l31) * 16;   // + ((tap*4 + g)*64 + m*32)*16   (HONLY: tap*2 + g; Q4: tap*3 + g)
+        const char* ldsB = (Q4 ? q_in : st) + ((2 * wv) * IW + l31) * 16;     // + g*PLANE + ((q+dy)*IW + dx)*16
 #if WSU_PROBE == 5
         u32x4 sa0[2], sa1[2], sb0[2], sb1[2], sah[2], sbh[2];
 #endif
@@ -595,7 +715,7 @@ _Pragma("unroll")
             {
 #endif
 _Pragma("unroll")
-            for (int m = 0; m < MH; ++m) ah[m] = *reinterpret_cast<const u32x4*>(ldsA + ((tap * (HONLY ? 2 : 4) + hh) * 64 + m * 32) * 16);
+            for (int m = 0; m < MH; ++m) ah[m] = *reinterpret_cast<const u32x4*>(ldsA + ((tap * (HONLY ? 2 : Q4 ? 3 : 4) + hh) * 64 + m * 32) * 16);
 _Pragma("unroll")
             for (int q = 0; q < 2; ++q) bh[q] = *reinterpret_cast<const u32x4*>(ldsB + hh * PLANE + ((q + dy) * IW + dx) * 16);
 #if WSU_PROBE == 5
@@ -612,8 +732,44 @@ _Pragma("unroll")
         // Measured neutral on this section (gpurun_out/ab_prio.log, time_pl*.log): raising the priority of waves 4-7 for its second half so
         // that SIMD partners reach the barrier together; fetching fragments one unit ahead of their matrix instructions behind scheduling
         // fences (two ahead needs 190 registers).
+        // Q4: both cross terms of a tap pair in one fp4 instruction -- lane half hh carries tap 2 tp + hh: weight granule plane 2 and the pixel's Q
+        // granule, each with its E8M0 scale byte (per (tap, co) / per pixel)
+        auto cross_q4 = [&](auto tp_c) __attribute__((always_inline)) {
+            constexpr int tp = decltype(tp_c)::value;
+            constexpr int t0 = 2 * tp, t1 = (2 * tp + 1 < 9) ? 2 * tp + 1 : 2 * tp;
+            constexpr bool single = 2 * tp + 1 >= 9;
+            const int tap = hh ? t1 : t0;
+            const int pixoff = (tap / 3) * IW + tap % 3;                        // (dy, dx) of this lane's tap
+            u32x4 a4[2], b4[2]; int sa[2], sb[2];
+_Pragma("unroll")
+            for (int m = 0; m < MH; ++m) {
+                a4[m] = *reinterpret_cast<const u32x4*>(ldsA + ((tap * 3 + 2) * 64 + m * 32) * 16);
+                sa[m] = *reinterpret_cast<const unsigned char*>(q_w + Q4_W_GRAN + tap * 64 + cur.mh * 32 + m * 32 + l31);
+            }
+_Pragma("unroll")
+            for (int q = 0; q < 2; ++q) {
+                b4[q] = *reinterpret_cast<const u32x4*>(ldsB + 2 * PLANE + (q * IW + pixoff) * 16);
+                sb[q] = *reinterpret_cast<const unsigned char*>(q_in + 3 * PLANE + (2 * wv + q) * IW + l31 + pixoff);
+            }
+            if (single && hh) {
+                const u32x4 z = mk_u4(0, 0, 0, 0);
+_Pragma("unroll")
+                for (int m = 0; m < MH; ++m) a4[m] = z;
+                b4[0] = z; b4[1] = z;
+            }
+_Pragma("unroll")
+            for (int m = 0; m < MH; ++m)
+_Pragma("unroll")
+                for (int q = 0; q < 2; ++q) wsu_mfma_q4(a4[m], b4[q], sa[m], sb[q], acc[m][q]);
+        };
         static_assert(!HONLY || !XRES, "HONLY reads neither residual plane");
-        if constexpr (HONLY) {
+        if constexpr (Q4) {
+            WSU_STATIC_FOR(5, tp, {
+                cross_q4(std::integral_constant<int, tp>{});
+                main_term(std::integral_constant<int, 2 * tp>{});
+                if constexpr (2 * tp + 1 < 9) main_term(std::integral_constant<int, 2 * tp + 1>{});
+            });
+        } else if constexpr (HONLY) {
             WSU_STATIC_FOR(9, tap, { main_term(std::integral_constant<int, tap>{}); });
         } else if constexpr (XRES) {
             WSU_STATIC_FOR(5, tp, {
@@ -824,6 +980,61 @@ _Pragma("unroll")
 #endif
 }
 
+// (explicit instantiations: referenced only from pl_launch, hipcc (ROCm 7.2) emitted the host stub of the first Q4 variant and left the other four
+// as undefined symbols -- without a diagnostic)
+template __global__ void conv3x3_pl_kernel<0, false, true, false, false, false, false, true>(const PlArgs);
+template __global__ void conv3x3_pl_kernel<0, true, true, false, false, false, false, true>(const PlArgs);
+template __global__ void conv3x3_pl_kernel<1, false, true, false, false, false, false, true>(const PlArgs);
+template __global__ void conv3x3_pl_kernel<4, false, true, false, false, false, false, true>(const PlArgs);
+template __global__ void conv3x3_pl_kernel<0, false, true, false, false, true, false, true>(const PlArgs);
+
+// one thread per (block, chunk, tap, co): 16 weights -> two f16 granules, the fp4 granule and the scale byte (layout: wsu_conv3x3_pack_f4 below)
+__global__ void pack_conv3x3_f4_kernel(const float* __restrict__ w, char* __restrict__ dst, int cin, int cout) {
+    const int nch = cin / 16;
+    const long long total = (long long)(cout / WSU_COB) * nch * 9 * WSU_COB;
+    for (long long d = (long long)blockIdx.x * blockDim.x + threadIdx.x; d < total; d += (long long)gridDim.x * blockDim.x) {
+        long long t = d;
+        const int co = (int)(t % WSU_COB); t /= WSU_COB;
+        const int tap = (int)(t % 9); t /= 9;
+        const int c = (int)(t % nch); const int cb = (int)(t / nch);
+        float v[16], r[16];
+        uint32_t h[8];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] = w[(((size_t)(cb * WSU_COB + co) * cin + c * 16 + e) * 3 + tap / 3) * 3 + tap % 3];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const _Float16 a = (_Float16)v[2 * e], b = (_Float16)v[2 * e + 1];              // round to nearest even, as every f16 part of the library
+            h[e] = (uint32_t)__builtin_bit_cast(unsigned short, a) | ((uint32_t)__builtin_bit_cast(unsigned short, b) << 16);
+            r[2 * e] = (v[2 * e] - (float)a) * 2048.f; r[2 * e + 1] = (v[2 * e + 1] - (float)b) * 2048.f;
+        }
+        const u32x4 h0 = mk_u4(h[0], h[1], h[2], h[3]), h1 = mk_u4(h[4], h[5], h[6], h[7]);
+        const int E = wsu_q4_block_exp(wsu_f16x16_max_abs_bits(h0, h1));
+        const float sc = wsu_pow2f(E);
+        uint32_t q[4] = {0, 0, 0, 0};
+        WSU_STATIC_FOR(8, e, { q[e >> 2] = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(q[e >> 2], r[2 * e], r[2 * e + 1], sc, e & 3); });   // nibbles 0-15: residuals, meet fp4(x)
+        q[2] = wsu_f16x8_to_fp4(h0, sc); q[3] = wsu_f16x8_to_fp4(h1, sc);                                                            // nibbles 16-31: copies, meet the residuals of x
+        char* slice = dst + ((size_t)cb * nch + c) * Q4_W_SLOT;
+        char* base = slice + (size_t)(tap * 3) * (WSU_COB * 16) + co * 16;
+        *reinterpret_cast<u32x4*>(base) = h0;
+        *reinterpret_cast<u32x4*>(base + WSU_COB * 16) = h1;
+        *reinterpret_cast<u32x4*>(base + 2 * WSU_COB * 16) = mk_u4(q[0], q[1], q[2], q[3]);
+        slice[Q4_W_GRAN + tap * 64 + co] = (char)(E + 127 - 11);
+        if (tap == 0 && co < 7) *reinterpret_cast<u32x4*>(slice + Q4_W_GRAN + 576 + co * 64) = mk_u4(0, 0, 0, 0), *reinterpret_cast<u32x4*>(slice + Q4_W_GRAN + 576 + co * 64 + 16) = mk_u4(0, 0, 0, 0),
+            *reinterpret_cast<u32x4*>(slice + Q4_W_GRAN + 576 + co * 64 + 32) = mk_u4(0, 0, 0, 0), *reinterpret_cast<u32x4*>(slice + Q4_W_GRAN + 576 + co * 64 + 48) = mk_u4(0, 0, 0, 0);   // the 448 pad bytes
+    }
+}
+
+// diagnostic (wsu_debug_q4_encode): the loaders' Q granule + scale byte of every pixel of one planar chunk, written to global memory
+__global__ void debug_q4_encode_kernel(const char* __restrict__ x, char* __restrict__ q, unsigned char* __restrict__ sbytes, int hw) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= hw) return;
+    const u32x4 h0 = *reinterpret_cast<const u32x4*>(x + (size_t)i * 16), h1 = *reinterpret_cast<const u32x4*>(x + ((size_t)hw + i) * 16),
+                r = *reinterpret_cast<const u32x4*>(x + (2 * (size_t)hw + i) * 16);
+    uint32_t sb;
+    *reinterpret_cast<u32x4*>(q + (size_t)i * 16) = wsu_q4_encode_x(h0, h1, r, &sb);
+    sbytes[i] = (unsigned char)sb;
+}
+
 // one place that knows the instantiations: attributes once, then the variant the arguments select
 int pl_launch(PlArgs a, bool first, hipStream_t s, bool grad = false) {
     static int ablate = -1;
@@ -839,6 +1050,13 @@ int pl_launch(PlArgs a, bool first, hipStream_t s, bool grad = false) {
                               reinterpret_cast<const void*>(&conv3x3_pl_kernel<1, false>), reinterpret_cast<const void*>(&conv3x3_pl_kernel<4, false>),
                               reinterpret_cast<const void*>(&conv3x3_pl_kernel<0, false, false>),
                               reinterpret_cast<const void*>(&conv3x3_pl_kernel<0, false, true, true>), reinterpret_cast<const void*>(&conv3x3_pl_kernel<0, true, true, true>)};
+        const void* q4fns[5] = {reinterpret_cast<const void*>(&conv3x3_pl_kernel<0, false, true, false, false, false, false, true>), reinterpret_cast<const void*>(&conv3x3_pl_kernel<0, true, true, false, false, false, false, true>),
+                                reinterpret_cast<const void*>(&conv3x3_pl_kernel<1, false, true, false, false, false, false, true>), reinterpret_cast<const void*>(&conv3x3_pl_kernel<4, false, true, false, false, false, false, true>),
+                                reinterpret_cast<const void*>(&conv3x3_pl_kernel<0, false, true, false, false, true, false, true>)};
+        for (const void* fn : q4fns) {
+            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
+            if (e != hipSuccess) { wsu_set_error("hipFuncSetAttribute(conv3x3_pl q4): %s", hipGetErrorString(e)); return WSU_ERR_HIP; }
+        }
         hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_pl_kernel<0, false, true, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
         if (e0 != hipSuccess) { wsu_set_error("hipFuncSetAttribute(conv3x3_pl): %s", hipGetErrorString(e0)); return WSU_ERR_HIP; }
         for (const void* fn : fns) {
@@ -853,11 +1071,19 @@ int pl_launch(PlArgs a, bool first, hipStream_t s, bool grad = false) {
     a.msplit = 0;
     if (msplit_on && !grad && !first && !a.head_w && !a.ypool && a.xres && 2 * (long long)a.ntiles <= ncu) {
         a.msplit = 1; a.ncb *= 2; a.ntiles *= 2;
-        hipLaunchKernelGGL((conv3x3_pl_kernel<0, false, true, false, false, true>), dim3(a.ntiles), dim3(NT), LDS_TOTAL, s, a);
+        if (a.q4) hipLaunchKernelGGL((conv3x3_pl_kernel<0, false, true, false, false, true, false, true>), dim3(a.ntiles), dim3(NT), LDS_TOTAL, s, a);
+        else hipLaunchKernelGGL((conv3x3_pl_kernel<0, false, true, false, false, true>), dim3(a.ntiles), dim3(NT), LDS_TOTAL, s, a);
         return wsu_check_launch("conv3x3_pl_kernel");
     }
     const int grid = a.ntiles < ncu ? a.ntiles : ncu;
     const dim3 g(grid), b(NT);
+    if (a.q4 && !grad && !first) {
+        if (a.head_w && a.head_cout == 1) hipLaunchKernelGGL((conv3x3_pl_kernel<1, false, true, false, false, false, false, true>), g, b, LDS_TOTAL, s, a);
+        else if (a.head_w) hipLaunchKernelGGL((conv3x3_pl_kernel<4, false, true, false, false, false, false, true>), g, b, LDS_TOTAL, s, a);
+        else if (a.ypool) hipLaunchKernelGGL((conv3x3_pl_kernel<0, true, true, false, false, false, false, true>), g, b, LDS_TOTAL, s, a);
+        else hipLaunchKernelGGL((conv3x3_pl_kernel<0, false, true, false, false, false, false, true>), g, b, LDS_TOTAL, s, a);
+        return wsu_check_launch("conv3x3_pl_kernel<q4>");
+    }
     if (grad && a.honly) hipLaunchKernelGGL((conv3x3_pl_kernel<0, false, false, false, true, false, true>), g, b, LDS_TOTAL, s, a);
     else if (grad) hipLaunchKernelGGL((conv3x3_pl_kernel<0, false, true, false, true>), g, b, LDS_TOTAL, s, a);
     else if (first) {
@@ -879,6 +1105,26 @@ extern "C" {
 int wsu_debug_read_pl_stamps(unsigned long long* host_dst, int nblocks) {
     if (nblocks > 256) nblocks = 256;
     return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_pl_stamps), (size_t)nblocks * 8 * sizeof(unsigned long long)) == hipSuccess ? 0 : -2;
+}
+
+// Weights of the Q4 variant (x_residual = 2): per (64-channel output block, 16-channel input chunk) one 28 KB slice =
+// [tap 9][plane 3][64 co][16 B] with planes f16 ci 0-7 | f16 ci 8-15 | fp4(residual * 2^11 / 2^E) ci 0-15, fp4(f16 part / 2^E) ci 0-15 (nibble i =
+// channel i), then [tap 9][64 co] scale bytes E + 127 - 11 (the 2^-11 of the residual's pre-scaling rides in the weight's scale), zero padded to 1 KB.
+size_t wsu_conv3x3_packed_f4_bytes(int cin, int cout) {
+    if (cin <= 0 || cout <= 0 || cin % 16 || cout % WSU_COB) return 0;
+    return (size_t)(cout / WSU_COB) * (cin / 16) * Q4_W_SLOT;
+}
+int wsu_conv3x3_pack_f4(const float* w_oihw, void* w_packed, int cin, int cout, void* stream) {
+    WSU_REQUIRE(w_oihw && w_packed, "conv3x3_pack_f4: null pointer");
+    WSU_REQUIRE(cin > 0 && cin % 16 == 0 && cout > 0 && cout % WSU_COB == 0, "conv3x3_pack_f4: cin=%d must be a multiple of 16, cout=%d of %d", cin, cout, WSU_COB);
+    hipLaunchKernelGGL(pack_conv3x3_f4_kernel, dim3(512), dim3(256), 0, static_cast<hipStream_t>(stream), w_oihw, (char*)w_packed, cin, cout);
+    return wsu_check_launch("pack_conv3x3_f4_kernel");
+}
+
+// diagnostic only (not part of include/wsu.h; tests/test_gpu_planar.py): Q granules (hw x 16 B) and scale bytes (hw) of ONE planar chunk (3 planes x hw x 16 B)
+int wsu_debug_q4_encode(const void* x_chunk, void* q, unsigned char* scale_bytes, int hw, void* stream) {
+    hipLaunchKernelGGL(debug_q4_encode_kernel, dim3((hw + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), (const char*)x_chunk, (char*)q, scale_bytes, hw);
+    return wsu_check_launch("debug_q4_encode_kernel");
 }
 
 size_t wsu_relu_mask_bytes(int n, int c, int h, int w) {
@@ -911,6 +1157,8 @@ int wsu_conv3x3_pl_fwd(const void* x1, const void* x2, const void* w_packed, con
     a.y = (char*)y; a.ypool = (char*)y_pool;
     a.head_w = head_w; a.head_b = head_b; a.head_out = head_out; a.head_logit = head_logit; a.head_cout = head_cout;
     a.range_flag = range_flag; a.xres = x_residual ? 1 : 0;
+    WSU_REQUIRE(x_residual >= 0 && x_residual <= 2, "conv3x3_pl: x_residual must be 0 (one e4m3 cross term), 1 (both) or 2 (block-scaled fp4 cross terms)");
+    WSU_REQUIRE(x_residual != 2 || !relu_mask_out, "conv3x3_pl: relu_mask_out is built into the e4m3 variants (x_residual = 1)");
     a.n = n; a.h = h; a.w = w; a.c1 = c1; a.c2 = c2; a.cout = cout;
     a.tiles_x = (w + TW - 1) / TW; a.tiles_y = (h + TH - 1) / TH; a.ncb = cout / WSU_COB;
     a.nch1 = c1 / 16; a.nch = (c1 + c2) / 16; a.relu = relu;
@@ -919,7 +1167,7 @@ int wsu_conv3x3_pl_fwd(const void* x1, const void* x2, const void* w_packed, con
     a.ntiles = (int)nt;
     a.img = nullptr; a.w1 = nullptr; a.b1 = nullptr;
     a.y2 = nullptr; a.nco1 = cout / 16; a.mask = nullptr; a.mask2 = nullptr; a.imgs_per_wset = 0; a.wset_bytes = 0;
-    a.relu_mask_out = relu_mask_out; a.mbits = nullptr; a.mbits2 = nullptr; a.honly = 0;
+    a.relu_mask_out = relu_mask_out; a.mbits = nullptr; a.mbits2 = nullptr; a.honly = 0; a.q4 = x_residual == 2 ? 1 : 0;
     return pl_launch(a, false, static_cast<hipStream_t>(stream));
 }
 
@@ -946,7 +1194,7 @@ int wsu_conv3x3_pl_fused_first_fwd(const float* img, const float* w1, const floa
     WSU_REQUIRE(nt > 0 && nt < 0x3FFFFFFFLL, "conv3x3_pl_fused_first: %lld tiles out of range", nt);
     a.ntiles = (int)nt;
     a.y2 = nullptr; a.nco1 = cout / 16; a.mask = nullptr; a.mask2 = nullptr; a.imgs_per_wset = 0; a.wset_bytes = 0;
-    a.relu_mask_out = nullptr; a.mbits = nullptr; a.mbits2 = nullptr; a.honly = 0;
+    a.relu_mask_out = nullptr; a.mbits = nullptr; a.mbits2 = nullptr; a.honly = 0; a.q4 = 0;
     return pl_launch(a, true, static_cast<hipStream_t>(stream));
 }
 
@@ -987,7 +1235,7 @@ int wsu_conv3x3_pl_bwd_data(const void* g, const void* w_packed_dgrad, const voi
     a.head_w = nullptr; a.head_b = nullptr; a.head_out = nullptr; a.head_logit = nullptr; a.head_cout = 0;
     a.range_flag = nullptr; a.xres = 1; a.img = nullptr; a.w1 = nullptr; a.b1 = nullptr;
     a.imgs_per_wset = 0; a.wset_bytes = 0;
-    a.relu_mask_out = nullptr; a.mbits = mask1_bits; a.mbits2 = mask2_bits; a.honly = products == WSU_PRODUCTS_F16 ? 1 : 0;
+    a.relu_mask_out = nullptr; a.mbits = mask1_bits; a.mbits2 = mask2_bits; a.honly = products == WSU_PRODUCTS_F16 ? 1 : 0; a.q4 = 0;
     a.n = n; a.h = h; a.w = w; a.c1 = cout; a.c2 = 0; a.cout = cin;
     a.tiles_x = (w + TW - 1) / TW; a.tiles_y = (h + TH - 1) / TH; a.ncb = cin / WSU_COB;
     a.nch1 = cout / 16; a.nch = cout / 16; a.relu = 0;

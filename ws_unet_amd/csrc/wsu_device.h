@@ -190,6 +190,61 @@ __device__ __forceinline__ u32x2 wsu_f16x8_to_fp8(const u32x4& h) {
     hi = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(hi, __builtin_shufflevector(c, c, 6, 7), WSU_F8_X_DIV, true);
     return mk_u2(__builtin_bit_cast(uint32_t, lo), __builtin_bit_cast(uint32_t, hi));
 }
+// ---- block-scaled fp4 (e2m1) cross terms ("Q4", round 3; semantics probed on the device: tools/fp4_probe.hip) -------------------------------------
+// A block = the 16 channels of one (pixel, chunk) resp. one (output channel, tap, chunk); its E8M0 scale is 2^E with E = (exponent of the block's
+// largest |f16 part|) - 1, so that value / 2^E lies in [2, 4) for the largest element (no saturation: fp4 reaches 6); both halves of a block
+// share it -- the copy c = f16 part and the residual pre-scaled by 2^11 (|residual| <= 2^-11 |value|).  v_cvt_scalef32_pk_fp4_f16 / _f32
+// return fp4(x / scale), round to nearest even, saturating, low nibble first; the MFMA multiplies a lane's 32 nibbles by 2^(scale byte - 127).
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+typedef __attribute__((ext_vector_type(2))) unsigned short u16x2_t;
+__device__ __forceinline__ int wsu_q4_block_exp(uint32_t max_abs_f16_bits) { return (int)(max_abs_f16_bits >> 10) - 16; }     // exponent field - 15 - 1
+__device__ __forceinline__ float wsu_pow2f(int e) { return __builtin_bit_cast(float, (uint32_t)(e + 127) << 23); }
+// largest |f16| bit pattern of the 16 values of two granules
+__device__ __forceinline__ uint32_t wsu_f16x16_max_abs_bits(const u32x4& h0, const u32x4& h1) {
+    u16x2_t m = __builtin_bit_cast(u16x2_t, h0.x & 0x7FFF7FFFu);
+    m = __builtin_elementwise_max(m, __builtin_bit_cast(u16x2_t, h0.y & 0x7FFF7FFFu));
+    m = __builtin_elementwise_max(m, __builtin_bit_cast(u16x2_t, h0.z & 0x7FFF7FFFu));
+    m = __builtin_elementwise_max(m, __builtin_bit_cast(u16x2_t, h0.w & 0x7FFF7FFFu));
+    m = __builtin_elementwise_max(m, __builtin_bit_cast(u16x2_t, h1.x & 0x7FFF7FFFu));
+    m = __builtin_elementwise_max(m, __builtin_bit_cast(u16x2_t, h1.y & 0x7FFF7FFFu));
+    m = __builtin_elementwise_max(m, __builtin_bit_cast(u16x2_t, h1.z & 0x7FFF7FFFu));
+    m = __builtin_elementwise_max(m, __builtin_bit_cast(u16x2_t, h1.w & 0x7FFF7FFFu));
+    return m.x > m.y ? m.x : m.y;
+}
+// 8 f16 values (one granule) -> 8 fp4 nibbles (one dword), value / scale.  Inline assembly: with the builtin, hipcc (ROCm 7.2) converted the
+// FIRST dword of the granule four times (`v_cvt_scalef32_pk_fp4_f16 v14, v2, v5` with every op_sel) -- the element index of the bit-cast source was lost.
+__device__ __forceinline__ uint32_t wsu_f16x8_to_fp4(const u32x4& h, float scale) {
+    uint32_t d = 0;
+    asm volatile("v_cvt_scalef32_pk_fp4_f16 %0, %1, %2" : "+v"(d) : "v"(h.x), "v"(scale));
+    asm volatile("v_cvt_scalef32_pk_fp4_f16 %0, %1, %2 op_sel:[0,0,1,0]" : "+v"(d) : "v"(h.y), "v"(scale));
+    asm volatile("v_cvt_scalef32_pk_fp4_f16 %0, %1, %2 op_sel:[0,0,0,1]" : "+v"(d) : "v"(h.z), "v"(scale));
+    asm volatile("v_cvt_scalef32_pk_fp4_f16 %0, %1, %2 op_sel:[0,0,1,1]" : "+v"(d) : "v"(h.w), "v"(scale));
+    return d;
+}
+// 8 stored e4m3 residual bytes (two dwords; value = byte * res_mul) -> 8 fp4 nibbles of (residual value / scale)
+__device__ __forceinline__ uint32_t wsu_fp8x8_to_fp4(uint32_t r0, uint32_t r1, float res_mul, float scale) {
+    uint32_t d = 0;
+    d = __builtin_amdgcn_cvt_scalef32_pk_fp4_f16(d, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(r0, res_mul, false), scale, 0);
+    d = __builtin_amdgcn_cvt_scalef32_pk_fp4_f16(d, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(r0, res_mul, true), scale, 1);
+    d = __builtin_amdgcn_cvt_scalef32_pk_fp4_f16(d, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(r1, res_mul, false), scale, 2);
+    d = __builtin_amdgcn_cvt_scalef32_pk_fp4_f16(d, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(r1, res_mul, true), scale, 3);
+    return d;
+}
+// The Q granule and scale byte of one (pixel, chunk) from its three stored granules (f16 ch 0-7 | f16 ch 8-15 | e4m3 residuals * 2^12):
+// nibbles 0-15 = fp4(f16 part / 2^E), nibbles 16-31 = fp4(residual * 2^11 / 2^E); *scale_byte = E + 127.
+__device__ __forceinline__ u32x4 wsu_q4_encode_x(const u32x4& h0, const u32x4& h1, const u32x4& res, uint32_t* scale_byte) {
+    const int e = wsu_q4_block_exp(wsu_f16x16_max_abs_bits(h0, h1));
+    const float sc = wsu_pow2f(e);
+    *scale_byte = (uint32_t)(e + 127);
+    // stored residual byte = e4m3((x - f16 x) * 2^12): (x - f16 x) * 2^11 = byte value / 2
+    return mk_u4(wsu_f16x8_to_fp4(h0, sc), wsu_f16x8_to_fp4(h1, sc), wsu_fp8x8_to_fp4(res.x, res.y, 0.5f, sc), wsu_fp8x8_to_fp4(res.z, res.w, 0.5f, sc));
+}
+// fp4 cross-term MFMA: one granule per operand, per-lane E8M0 scale bytes
+__device__ __forceinline__ void wsu_mfma_q4(const u32x4& a, const u32x4& b, int scale_a, int scale_b, f32x16& acc) {
+    const i32x8 av = {(int)a.x, (int)a.y, (int)a.z, (int)a.w, 0, 0, 0, 0}, bv = {(int)b.x, (int)b.y, (int)b.z, (int)b.w, 0, 0, 0, 0};
+    acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, acc, 4, 4, 0, scale_a, 0, scale_b);
+}
+
 // the same for a stored GRADIENT granule: e4m3(g * 4)
 __device__ __forceinline__ u32x2 wsu_f16x8_to_fp8_grad(const u32x4& h) {
     const _Float16 m = (_Float16)112.f;

@@ -155,6 +155,22 @@ def pack_conv3x3(w: torch.Tensor, mode: int, dgrad: bool = False) -> torch.Tenso
     return out
 
 
+def pack_conv3x3_f4(w: torch.Tensor) -> torch.Tensor:
+    """w: (Cout, Cin, 3, 3) fp32 OIHW on the device -> the packed weights of conv3x3_pl(..., x_residual=2): f16 planes + block-scaled fp4 cross-term
+    granules + scale bytes (wsu_conv3x3_pack_f4)."""
+    lib = _lib.load()
+    w = w.detach()
+    _dev_check(w)
+    assert w.dtype == torch.float32 and w.dim() == 4 and w.shape[2:] == (3, 3)
+    cout, cin = w.shape[:2]
+    nbytes = lib.wsu_conv3x3_packed_f4_bytes(cin, cout)
+    if nbytes == 0:
+        raise _lib.WsuError(f"fp4 packing needs cin % 16 == 0 and cout % 64 == 0 (got {cin}, {cout})")
+    out = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    check(lib.wsu_conv3x3_pack_f4(w.data_ptr(), out.data_ptr(), cin, cout, _stream()), "wsu_conv3x3_pack_f4")
+    return out
+
+
 def pack_convt2x2(w: torch.Tensor, mode: int) -> torch.Tensor:
     """w: (Cin, Cout, 2, 2) fp32 on the device -> packed byte buffer."""
     lib = _lib.load()
@@ -259,10 +275,10 @@ def planar_shape(n: int, c: int, h: int, w: int):
 def conv3x3_pl(x1: torch.Tensor, x2: Optional[torch.Tensor], w_packed: torch.Tensor, bias: Optional[torch.Tensor], cout: int,
                relu: bool = True, pool: bool = False, want_y: bool = True,
                head_w: Optional[torch.Tensor] = None, head_b: Optional[torch.Tensor] = None, want_logit: bool = False,
-               range_flag: Optional[torch.Tensor] = None, x_residual: bool = True, want_mask: bool = False):
+               range_flag: Optional[torch.Tensor] = None, x_residual=True, want_mask: bool = False):
     """3x3 reflect conv (+ReLU, +2x2 max-pool, +1x1 head and sigmoid) on planar F16F8P activations (wsu_conv3x3_pl_fwd).
-    x1 / x2: planar tensors (N, C/16, 4, H, W, 4); w_packed from pack_conv3x3(mode f16f8).  Returns y [, y_pool] or, with head_w,
-    out [, logit][, y]."""
+    x1 / x2: planar tensors (N, C/16, 4, H, W, 4); w_packed from pack_conv3x3(mode f16f8) -- or, with x_residual=2 (block-scaled fp4 cross
+    terms), from pack_conv3x3_f4.  Returns y [, y_pool] or, with head_w, out [, logit][, y]."""
     lib = _lib.load()
     hw2 = None if head_w is None else head_w.detach().reshape(head_w.shape[0], -1).contiguous()
     _dev_check(x1, x2, w_packed, bias, hw2, head_b)
