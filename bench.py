@@ -41,7 +41,7 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
-PEAK = {"bf16x3": 2.5e15, "bf16x3s": 2.5e15, "f16f8": 2.5e15, "f16f8p": 2.5e15, "f16f8q": 2.5e15, "bf16": 2.5e15, "f32": 157.3e12}     # dense MFMA peaks, MI355X_MICROARCH.md
+PEAK = {"bf16x3": 2.5e15, "bf16x3s": 2.5e15, "f16f8": 2.5e15, "f16f8p": 2.5e15, "f16f8q": 2.5e15, "f16f4p": 2.5e15, "bf16": 2.5e15, "f32": 157.3e12}     # dense MFMA peaks, MI355X_MICROARCH.md
 HBM_PEAK = 8.0e12
 NUM_CU = 256
 TRAIN_FLOP_PER_IMAGE_512 = 606.0e9        # 3 x forward minus the e11 data gradient
@@ -52,7 +52,7 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--mode", default=os.environ.get("WSU_BENCH_MODE", "f16f8p"), choices=["bf16x3", "bf16x3s", "f16f8", "f16f8p", "f16f8q", "bf16", "f32"])
+    ap.add_argument("--mode", default=os.environ.get("WSU_BENCH_MODE", "f16f8p"), choices=["bf16x3", "bf16x3s", "f16f8", "f16f8p", "f16f8q", "f16f4p", "bf16", "f32"])
     ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -469,7 +469,7 @@ def main():
         # matrix-pipe occupancy next to the algorithmic fraction: one unit = one 32x32x16 bf16/f16 MFMA (32 cycles, 32 768 FLOP); per
         # 16-channel chunk and 32x32 output tile a product costs 9 units of work, the modes issue 27 (bf16x3: 3 per tap), 19 (f16f8: 9
         # f16 + 5 fp8 instructions of 2 units), 9 (bf16) -- the fused first layer and the 16x16x32 shape issue the same unit counts
-        units = {"bf16x3": 27 / 9, "bf16x3s": 27 / 9, "f16f8": 19 / 9, "f16f8p": 19 / 9, "bf16": 1.0}.get(args.mode)       # f16f8q mixes 19 and 15
+        units = {"bf16x3": 27 / 9, "bf16x3s": 27 / 9, "f16f8": 19 / 9, "f16f8p": 19 / 9, "f16f4p": 14 / 9, "bf16": 1.0}.get(args.mode)       # f16f8q mixes 19 and 15
         if units is not None:
             roofline["mfma_issue"] = {"units_per_product": units, "tflops_equivalent": achieved * units / 1e12,
                                       "frac_of_peak": achieved * units / PEAK[args.mode],
@@ -496,6 +496,7 @@ def main():
                       "f16f8": "f16f8 (f16 MFMA on the f16 halves + block-scaled fp8 MFMA on the residual cross terms, fp32 accumulate)",
                       "f16f8p": "f16f8 (f16 MFMA on the f16 halves + block-scaled fp8 MFMA on the residual cross terms, fp32 accumulate; planar storage, LDS-DMA pipeline)",
                       "f16f8q": "f16f8 on planar storage with one cross term on the first conv of each decoder block",
+                      "f16f4p": "f16 MFMA on the f16 halves + ONE block-scaled fp4 (e2m1) MFMA per tap pair for both residual cross terms (per-pixel / per-(co, tap) E8M0 scales), fp32 accumulate; planar storage",
                       "bf16": "bf16", "f32": "f32"}[args.mode],
             "data": "synthetic",
             "config": {"workload": f"unet_2 forward-only predict, batch={args.batch}/GPU synthetic {args.size}x{args.size}x1 "
@@ -509,7 +510,7 @@ def main():
     # other precision modes, same run, fewer steps (rank 0 only, N = 1 only)
     if rank == 0 and world == 1 and not args.no_other_modes:
         other = {}
-        for md in [m for m in ("bf16", "f32", "bf16x3", "bf16x3s", "f16f8", "f16f8p", "f16f8q") if m != args.mode]:
+        for md in [m for m in ("bf16", "f32", "bf16x3", "bf16x3s", "f16f8", "f16f8p", "f16f8q", "f16f4p") if m != args.mode]:
             mm = build_model(md, dev)
             st = max(2, args.steps // 3)
             d2, y2 = timed_steps(mm, x, st, 1, False)

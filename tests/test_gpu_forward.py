@@ -324,3 +324,22 @@ def test_model_with_and_without_first_layer_fusion_agree():
             m.fuse_first = False
             y0 = m(x.clone())
         assert torch.equal(y0, y1)
+
+
+@pytest.mark.gpu
+def test_f16f4p_mode_within_the_gate():
+    """mode 'f16f4p' (block-scaled fp4 cross terms in the 3x3 convs, opt-in): the whole unet_2 forward on the gate's weights stays inside the
+    north star's 1e-4 MAE against the CPU oracle -- about 2.5e-5, against 4e-6 for the default 'f16f8p' (tools/precision_study_lowbit.py emulates
+    both) -- and is deterministic."""
+    import numpy as np
+    u8 = formula.synthetic_images(2, 256, 256, seed=1000)
+    x = torch.from_numpy(u8.astype(np.float32) / np.float32(255.))[:, None]
+    ref = oracle_forward(x, 2, "he")
+    m4 = gpu_model(2, "he", "f16f4p")
+    m8 = gpu_model(2, "he", "f16f8p")
+    with torch.no_grad():
+        y4, y4b, y8 = m4(x.to(DEV)).cpu(), m4(x.to(DEV)).cpu(), m8(x.to(DEV)).cpu()
+    mae4, mae8 = float((y4 - ref).abs().mean()), float((y8 - ref).abs().mean())
+    assert torch.equal(y4, y4b)
+    assert mae8 < 1e-5 and mae8 < mae4 < 6e-5, (mae4, mae8)
+    assert float((y4 - ref).abs().max()) < 1e-3

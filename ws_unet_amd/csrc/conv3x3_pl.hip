@@ -487,11 +487,13 @@ __device__ __forceinline__ void pl_loader_q4(const PlArgs& a, char* smem, int la
             voff[k] = (unsigned)(yy * a.w + xx) * 16u;
         });
     };
-    u32x4 rres[2][NSEG];                                              // the residual granules of the step being fetched / the step being converted
-    int issued = 0, mark_in[Q4_NIN] = {0, 0, 0}, mark_w[Q4_NW] = {0, 0};   // operation counts of this wave: total, and the total right after an issue
+    // residual granules of the step being fetched / the step being converted: two register sets addressed at COMPILE time (the step loop below is
+    // unrolled by two) -- a run-time index put them, and the operation counters of the vmcnt arithmetic, into scratch memory
+    u32x4 rres[2][NSEG];
     Tile ti = tile_of(a, lw); int ci = 0, kti = 0;                    // cursor of the input issue
     int cbw = ti.cb, cw = 0, ktw = 0;                                 // cursor of the weight issue (block, chunk)
-    auto issue_in = [&](int s) __attribute__((always_inline)) {
+    auto issue_in = [&](auto par, int s) __attribute__((always_inline)) {
+        constexpr int P = decltype(par)::value;
         const unsigned plane3 = hw16 * HBM_PLANES;
         const char* in_src = ci < a.nch1 ? a.x1 + ((size_t)ti.n * a.nch1 + ci) * plane3 : a.x2 + ((size_t)ti.n * (a.nch - a.nch1) + (ci - a.nch1)) * plane3;
         const auto rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(in_src), 0, (int)plane3, 0x00020000);
@@ -503,9 +505,8 @@ __device__ __forceinline__ void pl_loader_q4(const PlArgs& a, char* smem, int la
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void*)(slot + seg * 1024), 16, voff[k], 0, 0, 0);
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void*)(slot + PLANE + seg * 1024), 16, voff[k], (int)hw16, 0, 0);
             }
-            rres[s & 1][k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)voff[k], (int)(2u * hw16), 0));
+            rres[P][k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)voff[k], (int)(2u * hw16), 0));
         });
-        issued += NIN; mark_in[s % Q4_NIN] = issued;
         if (++ci == a.nch && s + 1 < J) { ci = 0; ++kti; ti = tile_of(a, lw + kti * G); plan(ti); }
     };
     auto issue_w = [&](int s) __attribute__((always_inline)) {
@@ -516,10 +517,11 @@ __device__ __forceinline__ void pl_loader_q4(const PlArgs& a, char* smem, int la
             constexpr int piece = LW + NLOAD * k;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void*)(slot + piece * 1024), 16, (unsigned)lane * 16u, w_base + piece * 1024, 0, 0);
         });
-        issued += NW; mark_w[s % Q4_NW] = issued;
         if (++cw == a.nch && s + 1 < J) { cw = 0; ++ktw; cbw = tile_of(a, lw + ktw * G).cb; }
     };
-    auto derive = [&](int s) __attribute__((always_inline)) {        // Q granule + scale byte of this lane's pixels of step s (planes 0 / 1 landed in LDS, residuals in registers)
+    auto derive = [&](auto par, int s) __attribute__((always_inline)) {  // Q granule + scale byte of this lane's pixels of step s (planes 0 / 1 landed in LDS, residuals in registers)
+        constexpr int P = decltype(par)::value;
+        if (a.ablate & 8) return;                                     // timing only
         char* slot = smem + (s % Q4_NIN) * Q4_IN_SLOT;
         WSU_STATIC_FOR(NSEG, k, {
             constexpr int seg = LW + NLOAD * k;
@@ -527,29 +529,45 @@ __device__ __forceinline__ void pl_loader_q4(const PlArgs& a, char* smem, int la
             if (seg < IN_SEG - 1 || idx < NPIX) {
                 const u32x4 h0 = *reinterpret_cast<const u32x4*>(slot + idx * 16), h1 = *reinterpret_cast<const u32x4*>(slot + PLANE + idx * 16);
                 uint32_t sb;
-                const u32x4 q = wsu_q4_encode_x(h0, h1, rres[s & 1][k], &sb);
+                const u32x4 q = wsu_q4_encode_x(h0, h1, rres[P][k], &sb);
                 *reinterpret_cast<u32x4*>(slot + 2 * PLANE + idx * 16) = q;
                 *reinterpret_cast<unsigned char*>(slot + 3 * PLANE + idx) = (unsigned char)sb;
             }
         });
     };
+    // vmcnt arithmetic: a wave issues, per step, NW weight operations and then NIN input operations (NSEG x (2 DMA pieces + 1 register load));
+    // `s_waitcnt vmcnt(n)` = all but the n youngest have completed
+    auto wait_all_but = [&](bool in_behind, int base) __attribute__((always_inline)) {
+        if (in_behind) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NIN + NW) : "memory");   // (only used with base = NW)
+        else if (base) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
     if (J <= 0) return;
+    const std::integral_constant<int, 0> even{}; const std::integral_constant<int, 1> odd{};
     plan(ti);
     issue_w(0);
-    issue_in(0);
-    if (J > 1) issue_in(1);
-    wsu_wait_vmcnt(issued - mark_in[0]);                             // step 0's inputs (its weights are older)
-    derive(0);
-    for (int j = 0; j < J; ++j) {
+    issue_in(even, 0);
+    if (J > 1) issue_in(odd, 1);
+    if (J > 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NIN) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // step 0's inputs (its weights are older)
+    derive(even, 0);
+    // one step: barrier j, then issue W(j+1), IN(j+2), convert step j+1 (its inputs were issued a whole step ago), wait for W(j+1)
+    auto step = [&](auto par, int j) __attribute__((always_inline)) -> bool {       // par = parity of j; returns false after the last barrier
+        constexpr int P = decltype(par)::value;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // this wave's Q / S of step j are written
         __builtin_amdgcn_s_barrier();                                 // barrier j: step j is complete in LDS; every matrix wave has left step j - 1
         asm volatile("" ::: "memory");
-        if (j + 1 >= J) break;
+        if (j + 1 >= J) return false;
         issue_w(j + 1);                                               // its slot held step j - 1
-        if (j + 2 < J) issue_in(j + 2);                               // its slot held step j - 1
-        wsu_wait_vmcnt(issued - mark_in[(j + 1) % Q4_NIN]);           // step j + 1's inputs, issued a whole step ago
-        derive(j + 1);
-        wsu_wait_vmcnt(issued - mark_w[(j + 1) % Q4_NW]);             // step j + 1's weights
+        const bool more = j + 2 < J;
+        if (more) issue_in(par, j + 2);                               // (same parity as j) its slot held step j - 1
+        wait_all_but(more, NW);                                       // step j + 1's inputs: younger are W(j+1) and, if issued, IN(j+2)
+        derive(std::integral_constant<int, 1 - P>{}, j + 1);
+        if (more) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NIN) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // step j + 1's weights
+        return true;
+    };
+    for (int j = 0; ; j += 2) {
+        if (!step(even, j)) break;
+        if (!step(odd, j + 1)) break;
     }
 }
 
@@ -650,8 +668,9 @@ __global__ __launch_bounds__(NT) void conv3x3_pl_kernel(const PlArgs a) {
         asm volatile("" ::: "memory");
         STAMP(s2);
         char* st = HONLY ? smem + (j % NSTAGE_H) * STAGE_H : smem + (j & 1) * STAGE;
-        [[maybe_unused]] const char* q_in = smem + (j % Q4_NIN) * Q4_IN_SLOT;                 // Q4: this step's input slot / weight slot
-        [[maybe_unused]] const char* q_w = smem + Q4_W_BASE + (j % Q4_NW) * Q4_W_SLOT;
+        [[maybe_unused]] const unsigned q_in_off = (unsigned)(j % Q4_NIN) * Q4_IN_SLOT, q_w_off = Q4_W_BASE + (unsigned)(j % Q4_NW) * Q4_W_SLOT;   // Q4: this step's input / weight slot
+        [[maybe_unused]] const char* q_in = smem + q_in_off;
+        [[maybe_unused]] const char* q_w = smem + q_w_off;
         STAMP(s3);
         if (c == 0) {
 #pragma unroll
@@ -741,15 +760,22 @@ _Pragma("unroll")
             const int tap = hh ? t1 : t0;
             const int pixoff = (tap / 3) * IW + tap % 3;                        // (dy, dx) of this lane's tap
             u32x4 a4[2], b4[2]; int sa[2], sb[2];
+            // 32-bit LDS addresses (address space 3): as generic 64-bit pointers the per-lane scale addresses were spilled and re-loaded from scratch inside this loop
+            typedef __attribute__((address_space(3))) const unsigned char lds_cuchar;
+            typedef __attribute__((address_space(3))) const u32x4 lds_cu32x4;
+            lds_char* L = (lds_char*)smem;
+            const unsigned wbase = q_w_off + (unsigned)(cur.mh * 32 + l31) * 16u + (unsigned)((tap * 3 + 2) * 64) * 16u;
+            const unsigned sabase = q_w_off + Q4_W_GRAN + (unsigned)(tap * 64 + cur.mh * 32 + l31);
+            const unsigned pix = (unsigned)((2 * wv) * IW + l31 + pixoff);
 _Pragma("unroll")
             for (int m = 0; m < MH; ++m) {
-                a4[m] = *reinterpret_cast<const u32x4*>(ldsA + ((tap * 3 + 2) * 64 + m * 32) * 16);
-                sa[m] = *reinterpret_cast<const unsigned char*>(q_w + Q4_W_GRAN + tap * 64 + cur.mh * 32 + m * 32 + l31);
+                a4[m] = *(lds_cu32x4*)(L + wbase + m * 32 * 16);
+                sa[m] = *(lds_cuchar*)(L + sabase + m * 32);
             }
 _Pragma("unroll")
             for (int q = 0; q < 2; ++q) {
-                b4[q] = *reinterpret_cast<const u32x4*>(ldsB + 2 * PLANE + (q * IW + pixoff) * 16);
-                sb[q] = *reinterpret_cast<const unsigned char*>(q_in + 3 * PLANE + (2 * wv + q) * IW + l31 + pixoff);
+                b4[q] = *(lds_cu32x4*)(L + q_in_off + 2 * PLANE + (pix + q * IW) * 16u);
+                sb[q] = *(lds_cuchar*)(L + q_in_off + 3 * PLANE + pix + q * IW);
             }
             if (single && hh) {
                 const u32x4 z = mk_u4(0, 0, 0, 0);
@@ -764,10 +790,13 @@ _Pragma("unroll")
         };
         static_assert(!HONLY || !XRES, "HONLY reads neither residual plane");
         if constexpr (Q4) {
+            // scheduling fences between the tap-pair groups: left free, the compiler hoists the next groups' fragment and scale-byte reads over this
+            // group's MFMAs and the variant ends 8-13 registers above the 168 of three waves per SIMD (spills re-loaded inside the epilogue)
             WSU_STATIC_FOR(5, tp, {
                 cross_q4(std::integral_constant<int, tp>{});
                 main_term(std::integral_constant<int, 2 * tp>{});
                 if constexpr (2 * tp + 1 < 9) main_term(std::integral_constant<int, 2 * tp + 1>{});
+                __builtin_amdgcn_sched_barrier(0);
             });
         } else if constexpr (HONLY) {
             WSU_STATIC_FOR(9, tap, { main_term(std::integral_constant<int, tap>{}); });
@@ -888,9 +917,13 @@ _Pragma("unroll")
                         uint32_t xlp = xlo, ylp = ylo;
                         swap32(xlo, xlp); swap32(ylo, ylp);                     // lanes 0-31: xlp / ylp = the partner lane's residuals (ch 4-7 / 12-15)
                         if (ok) {
-                            *reinterpret_cast<u32x4*>(base + off + hh * plane_bytes) = mk_u4(xh0, xh1, yh0, yh1);
+                            // (one 32-bit lane offset per store: written `base + off + hh * plane_bytes` the loop-invariant 64-bit `hh * plane_bytes` stayed live
+                            // across the tile loop, was spilled, and every re-load drained the epilogue's stores with an s_waitcnt vmcnt(0))
+                            uint32_t hoff = hh ? plane_bytes : 0u;
+                            asm volatile("" : "+v"(hoff));                     // (recomputed per store: hoisted out of the tile loop it was the next value to be spilled)
+                            *reinterpret_cast<u32x4*>(base + (uint32_t)(off + hoff)) = mk_u4(xh0, xh1, yh0, yh1);
                             if constexpr (!HONLY) {                                   // (HONLY = products F16: gradient tensors carry no residual plane)
-                                if (!hh) *reinterpret_cast<u32x4*>(base + off + 2 * plane_bytes) = mk_u4(xlo, xlp, ylo, ylp);
+                                if (!hh) *reinterpret_cast<u32x4*>(base + (uint32_t)(off + 2u * plane_bytes)) = mk_u4(xlo, xlp, ylo, ylp);
                             }
                             if constexpr (!GRAD && !HEAD && !POOL) {            // the training forward's ReLU-mask byte of this lane's granule
                                 if (mdst) *mdst = (unsigned char)wsu_f16x8_pos_bits(mk_u4(xh0, xh1, yh0, yh1));

@@ -44,7 +44,7 @@ def range_fallback(model, collective: bool = False) -> bool:
     switch the model to 'bf16x3s' (fp32-range storage) and return True -- the caller recomputes what it computed since the last look.
     The evaluate drivers call this once per data-set pass (one sync per pass), the per-image functions once per image (they synchronise
     on their result anyway).  `collective`: OR the flag over the ranks first (every rank of a sharded pass takes the same decision)."""
-    if getattr(model, "mode", None) not in ("f16f8p", "f16f8q") or not hasattr(model, "range_exceeded"):
+    if getattr(model, "mode", None) not in ("f16f8p", "f16f8q", "f16f4p") or not hasattr(model, "range_exceeded"):
         return False
     if collective:
         from . import parallel

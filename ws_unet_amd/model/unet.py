@@ -17,6 +17,9 @@ Precision modes (``mode=`` or env ``WSU_MODE``):
   'f16f8p'  the 'f16f8' arithmetic on PLANAR storage -- [n][C/16][4 planes][H][W][16 B], the LDS image of the matrix kernels: staging is a
                                                    pure LDS-DMA and one persistent workgroup per CU pipelines it across chunks and tiles
                                                    (csrc/conv3x3_pl.hip, planar.hip); same values as 'f16f8' up to the accumulation order
+  'f16f4p'  'f16f8p' storage; the 3x3 convs multiply both cross terms as ONE block-scaled fp4 (e2m1) operand pair per tap pair (14 instead of 19
+            matrix units per chunk; include/wsu.h x_residual = 2): MAE ~2.5e-5 instead of 4e-6, -7 .. -15 % time on the deep layers (opt-in; training
+            and the transposed convs keep the e4m3 arithmetic)
   'f16f8q'  'f16f8p' with ONE cross term (the weights' residual) on the first conv of every decoder block: MAE ~4e-5 instead of 4e-6
   'f16f8'   f16 products + fp8 cross terms      -- default: f16(w)*f16(x) exactly, the two residual cross terms on the block-scaled fp8
                                                    matrix pipe (0.70 of bf16x3's matrix cycles, ~2^-15 relative error per product, MAE
@@ -105,7 +108,7 @@ class UNet(nn.Module):
         # activations AND gradients (3 bytes per element, model/autograd.py; single-plane inputs, falls back to 'bf16x3' otherwise and when the
         # input gradient is asked for); else split-bf16 on fp32 tensors (~2^-16 relative per product -- finer than the TF32 convs PyTorch
         # trains with by default on the reference's GPUs)
-        self.train_mode = os.environ.get("WSU_TRAIN_MODE") or ("f32" if self.mode == "f32" else "f16f8p" if self.mode in ("f16f8p", "f16f8q") else "bf16x3")
+        self.train_mode = os.environ.get("WSU_TRAIN_MODE") or ("f32" if self.mode == "f32" else "f16f8p" if self.mode in ("f16f8p", "f16f8q", "f16f4p") else "bf16x3")
         # train_mode 'f16f8p': the terms the BACKWARD matrix kernels (3x3 data and weight gradients) multiply -- 'f16' (default: exact products of
         # the operands' f16 parts, fp32 accumulation; include/wsu.h WSU_PRODUCTS_*) or 'f16f8' (+ both residual cross terms, the forward's
         # arithmetic).  The forward -- loss, predictions, ReLU masks -- is the same.  Why 'f16' is enough (profiles/r03/
@@ -154,7 +157,9 @@ class UNet(nn.Module):
         hit = self._pack_cache.get(key)
         if hit is not None and hit[0] == tag:
             return hit[1]
-        if kind == "conv":
+        if kind == "conv_f4":
+            packed = ops.pack_conv3x3_f4(p)
+        elif kind == "conv":
             packed = ops.pack_conv3x3(p, mode)
         elif kind == "dgrad":
             packed = ops.pack_conv3x3(p, mode, dgrad=True)
@@ -189,7 +194,7 @@ class UNet(nn.Module):
         t = keep if keep is not None else {}
         save = keep is not None
         e11 = self.e11
-        if m in (ops.MODE_F16F8P, ops.MODE_F16F8Q):
+        if m in (ops.MODE_F16F8P, ops.MODE_F16F8Q, ops.MODE_F16F4P):
             if save or not self._planar_ok():
                 m = ops.MODE_BF16X3             # intermediates are only kept in fp32 NHWC; odd channel counts take the general path
             else:
@@ -309,6 +314,9 @@ class UNet(nn.Module):
         # 'f16f8q': the first conv of every decoder block (the two most expensive layers of unet_2) multiplies without the activations'
         # residual term: 15 instead of 19 matrix units there, MAE 4e-6 -> ~4e-5 on the gate's weights (still 2.5x inside 1e-4)
         quick = self.mode == "f16f8q"
+        q4 = self.mode == "f16f4p"                                   # block-scaled fp4 cross terms: own packed weights, x_residual = 2
+        CK = "conv_f4" if q4 else "conv"
+        XR = 2 if q4 else True
         tag = ops.set_layer
         e11 = self.e11
         rf = self._range_flag_tensor(x.device)
@@ -324,39 +332,39 @@ class UNet(nn.Module):
             if lvl == 0 and fuse_first:
                 lb = self.e12
                 tag("e11+e12")
-                full, cur = ops.conv3x3_pl_fused_first(x, e11.weight, e11.bias.detach(), self._packed("e12", W, "conv"), lb.bias.detach(),
+                full, cur = ops.conv3x3_pl_fused_first(x, e11.weight, e11.bias.detach(), self._packed("e12", W, CK), lb.bias.detach(),
                                                        lb.out_channels, pool=True, range_flag=rf)
                 skips.append(full)
                 continue
             if lvl >= 1:
                 la = getattr(self, a)
                 tag(a)
-                cur = ops.conv3x3_pl(cur, None, self._packed(a, W, "conv"), la.bias.detach(), la.out_channels, range_flag=rf)
+                cur = ops.conv3x3_pl(cur, None, self._packed(a, W, CK), la.bias.detach(), la.out_channels, range_flag=rf, x_residual=XR)
             lb = getattr(self, b)
             tag(b)
             last = lvl == self.nsteps
             if last and self.nsteps == 0:
                 tag(b + "+outconv")
-                return ops.conv3x3_pl(cur, None, self._packed(b, W, "conv"), lb.bias.detach(), lb.out_channels, want_y=False,
-                                      head_w=self.outconv.weight.detach(), head_b=self.outconv.bias.detach(), want_logit=want_logit)
+                return ops.conv3x3_pl(cur, None, self._packed(b, W, CK), lb.bias.detach(), lb.out_channels, want_y=False,
+                                      head_w=self.outconv.weight.detach(), head_b=self.outconv.bias.detach(), want_logit=want_logit, x_residual=XR)
             if not last:
-                full, cur = ops.conv3x3_pl(cur, None, self._packed(b, W, "conv"), lb.bias.detach(), lb.out_channels, pool=True, range_flag=rf)
+                full, cur = ops.conv3x3_pl(cur, None, self._packed(b, W, CK), lb.bias.detach(), lb.out_channels, pool=True, range_flag=rf, x_residual=XR)
                 skips.append(full)
             else:
-                cur = ops.conv3x3_pl(cur, None, self._packed(b, W, "conv"), lb.bias.detach(), lb.out_channels, range_flag=rf)
+                cur = ops.conv3x3_pl(cur, None, self._packed(b, W, CK), lb.bias.detach(), lb.out_channels, range_flag=rf, x_residual=XR)
         for depth in range(self.nsteps, 0, -1):
             up, c1, c2 = dec_names(depth)
             lu, l1, l2 = getattr(self, up), getattr(self, c1), getattr(self, c2)
             tag(up)
             xu = ops.convt2x2_pl(cur, self._packed(up, W, "convt"), lu.bias.detach(), lu.out_channels, range_flag=rf)
             tag(c1)
-            cur = ops.conv3x3_pl(xu, skips[depth - 1], self._packed(c1, W, "conv"), l1.bias.detach(), l1.out_channels, range_flag=rf, x_residual=not quick)
+            cur = ops.conv3x3_pl(xu, skips[depth - 1], self._packed(c1, W, CK), l1.bias.detach(), l1.out_channels, range_flag=rf, x_residual=(2 if q4 else not quick))
             if depth == 1:
                 tag(c2 + "+outconv")
-                return ops.conv3x3_pl(cur, None, self._packed(c2, W, "conv"), l2.bias.detach(), l2.out_channels, want_y=False,
-                                      head_w=self.outconv.weight.detach(), head_b=self.outconv.bias.detach(), want_logit=want_logit)
+                return ops.conv3x3_pl(cur, None, self._packed(c2, W, CK), l2.bias.detach(), l2.out_channels, want_y=False,
+                                      head_w=self.outconv.weight.detach(), head_b=self.outconv.bias.detach(), want_logit=want_logit, x_residual=XR)
             tag(c2)
-            cur = ops.conv3x3_pl(cur, None, self._packed(c2, W, "conv"), l2.bias.detach(), l2.out_channels, range_flag=rf)
+            cur = ops.conv3x3_pl(cur, None, self._packed(c2, W, CK), l2.bias.detach(), l2.out_channels, range_flag=rf, x_residual=XR)
         raise AssertionError("unreachable")
 
     def forward(self, x_in: torch.Tensor) -> torch.Tensor:

@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import MODES, MODE_BF16, MODE_BF16X3, MODE_BF16X3S, MODE_F16F8, MODE_F16F8X, MODE_F16F8P, MODE_F16F8Q, check
+from ._lib import MODES, MODE_BF16, MODE_BF16X3, MODE_BF16X3S, MODE_F16F8, MODE_F16F8X, MODE_F16F8P, MODE_F16F8Q, MODE_F16F4P, check
 
 
 def _stream() -> int:
@@ -113,7 +113,7 @@ def _esz(mode: int) -> int:
 def weight_mode(mode: int) -> int:
     """The packed weights of 'bf16x3s' are the 'bf16x3' ones; 'f16f8' has its own packing, shared by 'f16f8x' (the same arithmetic on
     fp32 tensors: the training forward)."""
-    return MODE_BF16X3 if mode == MODE_BF16X3S else (MODE_F16F8 if mode in (MODE_F16F8X, MODE_F16F8P, MODE_F16F8Q) else mode)
+    return MODE_BF16X3 if mode == MODE_BF16X3S else (MODE_F16F8 if mode in (MODE_F16F8X, MODE_F16F8P, MODE_F16F8Q, MODE_F16F4P) else mode)
 
 
 def first_layer_weight_mode(mode: int) -> int:

@@ -192,7 +192,7 @@ class Trainer:
             was = (getattr(self.model, "train_mode", None), getattr(self.model, "mode", None))
             if was[0] == "f16f8p":
                 self.model.train_mode = "bf16x3"
-            if was[1] in ("f16f8p", "f16f8q"):
+            if was[1] in ("f16f8p", "f16f8q", "f16f4p"):
                 self.model.mode = "bf16x3s"
             logging.warning("ws_unet_amd.Trainer: activations beyond +-448 during %s epoch %d (the planar format's e4m3 residual saturates "
                             "there): train_mode %s -> %s, mode %s -> %s", "training" if train else "validation", epoch, was[0],
