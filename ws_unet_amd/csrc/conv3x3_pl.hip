@@ -790,13 +790,13 @@ _Pragma("unroll")
         };
         static_assert(!HONLY || !XRES, "HONLY reads neither residual plane");
         if constexpr (Q4) {
-            // scheduling fences between the tap-pair groups: left free, the compiler hoists the next groups' fragment and scale-byte reads over this
-            // group's MFMAs and the variant ends 8-13 registers above the 168 of three waves per SIMD (spills re-loaded inside the epilogue)
+            // (the Q4 variants end 6-13 registers above the 168 of three waves per SIMD: lane-derived epilogue constants are spilled at the kernel entry
+            // and re-loaded per tile; scheduling fences between the groups, or recomputing those constants in the epilogue, moved the spills into
+            // this loop and measured slower)
             WSU_STATIC_FOR(5, tp, {
                 cross_q4(std::integral_constant<int, tp>{});
                 main_term(std::integral_constant<int, 2 * tp>{});
                 if constexpr (2 * tp + 1 < 9) main_term(std::integral_constant<int, 2 * tp + 1>{});
-                __builtin_amdgcn_sched_barrier(0);
             });
         } else if constexpr (HONLY) {
             WSU_STATIC_FOR(9, tap, { main_term(std::integral_constant<int, tap>{}); });
@@ -920,7 +920,7 @@ _Pragma("unroll")
                             // (one 32-bit lane offset per store: written `base + off + hh * plane_bytes` the loop-invariant 64-bit `hh * plane_bytes` stayed live
                             // across the tile loop, was spilled, and every re-load drained the epilogue's stores with an s_waitcnt vmcnt(0))
                             uint32_t hoff = hh ? plane_bytes : 0u;
-                            asm volatile("" : "+v"(hoff));                     // (recomputed per store: hoisted out of the tile loop it was the next value to be spilled)
+                            asm volatile("" : "+v"(hoff));                     // (kept out of the 64-bit address arithmetic)
                             *reinterpret_cast<u32x4*>(base + (uint32_t)(off + hoff)) = mk_u4(xh0, xh1, yh0, yh1);
                             if constexpr (!HONLY) {                                   // (HONLY = products F16: gradient tensors carry no residual plane)
                                 if (!hh) *reinterpret_cast<u32x4*>(base + (uint32_t)(off + 2u * plane_bytes)) = mk_u4(xlo, xlp, ylo, ylp);
