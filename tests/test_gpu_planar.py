@@ -337,3 +337,43 @@ def test_conv3x3_pl_q4_matches_emulation(n, h, w, c1, c2, cout, pool):
     assert float((y - exact).abs().max()) < 2e-3 * scale, float((y - exact).abs().max()) / scale
     if pool:
         assert float((planar_decode(out[1]) - F.max_pool2d(y, 2)).abs().max()) == 0.0
+
+
+@pytest.mark.gpu
+def test_conv3x3_pl_q4_variants_and_repeatability():
+    """The other instantiations of the fp4 variant against the same emulation -- fused head (1 and 3 planes), small grids (half-block work items),
+    no ReLU -- and launch-to-launch repeatability of the three-slot / two-slot rings (a missing wait on a DMA piece or a register load shows as a
+    difference between launches)."""
+    from ws_unet_amd import ops
+    g = torch.Generator().manual_seed(11)
+    # fused head
+    for hc in (1, 3):
+        n, h, w, cin = 2, 24, 40, 64
+        x = planar_decode(planar_encode(torch.relu(torch.randn((n, cin, h, w), generator=g))))
+        wgt = torch.randn((64, cin, 3, 3), generator=g) * (2.0 / (9 * cin)) ** 0.5
+        b = torch.randn(64, generator=g) * 0.1
+        hw_, hb = torch.randn((hc, 64, 1, 1), generator=g) * 0.2, torch.randn(hc, generator=g) * 0.1
+        ref = torch.sigmoid(F.conv2d(torch.relu(_conv3x3_q4_ref(x, wgt, b)), hw_, hb))
+        out = ops.conv3x3_pl(planar_encode(x).to(DEV), None, ops.pack_conv3x3_f4(wgt.to(DEV)), b.to(DEV), 64, head_w=hw_.to(DEV), head_b=hb.to(DEV), want_y=False, x_residual=2)
+        torch.cuda.synchronize()
+        assert float((out.cpu() - ref).abs().max()) < 2e-5, (hc, float((out.cpu() - ref).abs().max()))
+    # small grid: 2 x (32 x 32) x 128 channels = 16 tiles -> half-block work items (kernel variant MSPLIT); and no ReLU
+    n, h, w, cin, cout = 2, 32, 32, 128, 128
+    x = planar_decode(planar_encode(torch.randn((n, cin, h, w), generator=g)))
+    wgt = torch.randn((cout, cin, 3, 3), generator=g) * (2.0 / (9 * cin)) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    ref = _conv3x3_q4_ref(x, wgt, b)
+    y = planar_decode(ops.conv3x3_pl(planar_encode(x).to(DEV), None, ops.pack_conv3x3_f4(wgt.to(DEV)), b.to(DEV), cout, relu=False, x_residual=2))
+    assert float((y - ref).abs().max()) < 3e-5 * float(ref.abs().max())
+    # repeatability at a size where every workgroup walks several tiles of 4 and of 16 steps
+    for (n, s, cin, cout, pool) in ((8, 256, 64, 64, True), (4, 128, 256, 128, False)):
+        xe = planar_encode(torch.relu(torch.randn((n, cin, s, s), generator=g))).to(DEV)
+        wp = ops.pack_conv3x3_f4((torch.randn((cout, cin, 3, 3), generator=g) * 0.05).to(DEV))
+        bz = torch.zeros(cout, device=DEV)
+        first = ops.conv3x3_pl(xe, None, wp, bz, cout, pool=pool, x_residual=2)
+        first = [t.clone() for t in (first if pool else (first,))]
+        for _ in range(10):
+            again = ops.conv3x3_pl(xe, None, wp, bz, cout, pool=pool, x_residual=2)
+            again = again if pool else (again,)
+            for a_, f_ in zip(again, first):
+                assert torch.equal(a_.view(torch.int32), f_.view(torch.int32))

@@ -21,6 +21,10 @@
 #include "wsu_device.h"
 #include <cstdlib>
 
+#ifndef WSU_PL_OPAQUE_HH
+#define WSU_PL_OPAQUE_HH 0      // experiment: 1 = the e4m3 variants, too, recompute their tap-pair offsets per step (see hh_q in the kernel)
+#endif
+
 namespace {
 
 constexpr int TW = 32, TH = 16, IW = TW + 2, IH = TH + 2;
@@ -686,12 +690,17 @@ __global__ __launch_bounds__(NT) void conv3x3_pl_kernel(const PlArgs a) {
 #if WSU_PROBE == 5
         u32x4 sa0[2], sa1[2], sb0[2], sb1[2], sah[2], sbh[2];
 #endif
+        // (an opaque copy of the lane half per step: the tap-pair offsets of the cross terms -- in the Q4 variant weight granule, both scale bytes
+        // and pixel -- are loop invariant per lane, and hoisted out of the tile loop the 15-20 of them stayed live across it: the variant spilled the
+        // epilogue's constants, whose re-loads drained the epilogue's stores.  Recomputed per step: no spill.)
+        [[maybe_unused]] int hh_q = hh;
+        if constexpr (Q4 || WSU_PL_OPAQUE_HH) asm volatile("" : "+v"(hh_q));
         auto cross = [&](auto tp_c) __attribute__((always_inline)) {
             constexpr int tp = decltype(tp_c)::value;
             constexpr int t0 = 2 * tp, t1 = (2 * tp + 1 < 9) ? 2 * tp + 1 : 2 * tp;
             constexpr bool single = 2 * tp + 1 >= 9;
-            const int aoff = ((hh ? t1 : t0) * 4 + 2) * 64 * 16;
-            const int boff = 2 * PLANE + (hh ? ((t1 / 3) * IW + t1 % 3) : ((t0 / 3) * IW + t0 % 3)) * 16;
+            const int aoff = ((hh_q ? t1 : t0) * 4 + 2) * 64 * 16;
+            const int boff = 2 * PLANE + (hh_q ? ((t1 / 3) * IW + t1 % 3) : ((t0 / 3) * IW + t0 % 3)) * 16;
             u32x4 a0[2], a1[2], b0[2], b1[2];
 #if WSU_PROBE == 5                                                      // timing probe 5 (make probes): LDS fragments are read for the first group of a step only
             if (tp == 0) {
@@ -757,7 +766,7 @@ _Pragma("unroll")
             constexpr int tp = decltype(tp_c)::value;
             constexpr int t0 = 2 * tp, t1 = (2 * tp + 1 < 9) ? 2 * tp + 1 : 2 * tp;
             constexpr bool single = 2 * tp + 1 >= 9;
-            const int tap = hh ? t1 : t0;
+            const int tap = hh_q ? t1 : t0;
             const int pixoff = (tap / 3) * IW + tap % 3;                        // (dy, dx) of this lane's tap
             u32x4 a4[2], b4[2]; int sa[2], sb[2];
             // 32-bit LDS addresses (address space 3): as generic 64-bit pointers the per-lane scale addresses were spilled and re-loaded from scratch inside this loop
@@ -777,7 +786,7 @@ _Pragma("unroll")
                 b4[q] = *(lds_cu32x4*)(L + q_in_off + 2 * PLANE + (pix + q * IW) * 16u);
                 sb[q] = *(lds_cuchar*)(L + q_in_off + 3 * PLANE + pix + q * IW);
             }
-            if (single && hh) {
+            if (single && hh_q) {
                 const u32x4 z = mk_u4(0, 0, 0, 0);
 _Pragma("unroll")
                 for (int m = 0; m < MH; ++m) a4[m] = z;

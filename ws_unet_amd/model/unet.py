@@ -348,11 +348,7 @@ class UNet(nn.Module):
                 return ops.conv3x3_pl(cur, None, self._packed(b, W, CK), lb.bias.detach(), lb.out_channels, want_y=False,
                                       head_w=self.outconv.weight.detach(), head_b=self.outconv.bias.detach(), want_logit=want_logit, x_residual=XR)
             if not last:
-                # 'f16f4p': a pooled conv of 64 input channels (4 chunk steps per tile, the heaviest epilogue) measures slower in the fp4 variant
-                # (its register spills sit in the epilogue: profiles/r03/f16f4p.md) -- it keeps the e4m3 cross terms
-                e4 = q4 and lb.in_channels < 128
-                full, cur = ops.conv3x3_pl(cur, None, self._packed(b, W, "conv" if e4 else CK), lb.bias.detach(), lb.out_channels, pool=True, range_flag=rf,
-                                           x_residual=True if e4 else XR)
+                full, cur = ops.conv3x3_pl(cur, None, self._packed(b, W, CK), lb.bias.detach(), lb.out_channels, pool=True, range_flag=rf, x_residual=XR)
                 skips.append(full)
             else:
                 cur = ops.conv3x3_pl(cur, None, self._packed(b, W, CK), lb.bias.detach(), lb.out_channels, range_flag=rf, x_residual=XR)
