@@ -8,11 +8,12 @@ from oracle import unet_ref
 
 DEV = "cuda"
 MODE_NAMES = ["f32", "bf16x3", "bf16"]
-NET_MODES = MODE_NAMES + ["f16f8", "f16f8p"]          # whole-network tests also cover the default inference mode (its storage format is opaque)
+DEFAULT_MODE = "f16f4p"                               # what get_model(mode=None) / get_pretrained build (planar storage, block-scaled fp4 cross terms in the 3x3 convs)
+NET_MODES = MODE_NAMES + ["f16f8", "f16f8p", "f16f4p"]          # whole-network tests also cover the default inference mode (its storage format is opaque)
 # absolute tolerance on the [0,1] sigmoid output / relative tolerance on activations, per precision mode
-OUT_ATOL = {"f32": 4e-6, "bf16x3": 2e-5, "bf16": 3e-2, "f16f8": 1e-4, "f16f8p": 1e-4, "f16f8q": 4e-4}        # f16f8q: plain-f16 activations into d*1: measured max ~2e-4, mean 4e-5        # f16f8: measured max 4.5e-5 (mean 4e-6)
+OUT_ATOL = {"f32": 4e-6, "bf16x3": 2e-5, "bf16": 3e-2, "f16f8": 1e-4, "f16f8p": 1e-4, "f16f4p": 6e-4, "f16f8q": 4e-4}        # f16f4p: measured max 2.6e-4 (MAE 2.5e-5); f16f8q: plain-f16 activations into d*1: measured max ~2e-4, mean 4e-5        # f16f8: measured max 4.5e-5 (mean 4e-6)
 # deeper nets (K up to 9*2048 terms) accumulate more fp32 summation-order noise vs oneDNN
-OUT_ATOL_DEEP = {"f32": 1e-5, "bf16x3": 4e-5, "bf16": 5e-2, "f16f8": 1.5e-4, "f16f8p": 1.5e-4, "f16f8q": 6e-4}
+OUT_ATOL_DEEP = {"f32": 1e-5, "bf16x3": 4e-5, "bf16": 5e-2, "f16f8": 1.5e-4, "f16f8p": 1.5e-4, "f16f4p": 9e-4, "f16f8q": 6e-4}
 ACT_RTOL = {"f32": 2e-5, "bf16x3": 1e-4, "bf16": 6e-2}
 
 

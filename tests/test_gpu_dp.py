@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 import torch
 
-from gpu_util import DEV, gpu_model
+from gpu_util import DEV, gpu_model, DEFAULT_MODE
 from ws_unet_amd.trainer import Trainer
 
 pytestmark = pytest.mark.gpu
@@ -129,7 +129,7 @@ def test_two_rank_sharded_evaluate(tmp_path):
         logs.append(o)
     assert all(p.returncode == 0 for p in procs), "\n".join(logs)
     model = gpu_model(2, "he", None, drop_rate=0.)
-    assert model.mode == "f16f8p"
+    assert model.mode == DEFAULT_MODE
     ref_c = evaluate.predict_unet_cover(data, model=model, progress_on=False)              # the reference-shaped per-image loop
     ref_s = evaluate.predict_unet_stego(data, model=model, stego_method="LSBR")
     assert ref_c["name"].tolist() == ["images/1.png", "images/10.png", "images/22.png", "images/3.png", "images/7.png"]

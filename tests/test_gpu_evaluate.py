@@ -8,7 +8,7 @@ import torch
 from PIL import Image
 
 from conftest import GOLDEN
-from gpu_util import DEV, gpu_model
+from gpu_util import DEV, gpu_model, DEFAULT_MODE
 from ws_unet_amd import evaluate, formula, get_unet_estimator
 from ws_unet_amd.imread import imread4_f32
 from oracle import evaluate_ref, unet_ref
@@ -21,12 +21,12 @@ def ref_model():
     return unet_ref.build_ref(2, formula.formula_state_dict(2, "he"))
 
 
-# (mode, max |prediction - oracle| in 0..255 units).  None = what get_pretrained(mode=None) builds: 'f16f8p'
-@pytest.mark.parametrize("mode,tol", [("f32", 3e-3), ("bf16x3", 1e-2), ("f16f8", 3e-2), ("f16f8p", 3e-2), (None, 3e-2)])
+# (mode, max |prediction - oracle| in 0..255 units).  None = what get_pretrained(mode=None) builds: 'f16f4p' (measured: max 0.07, mean 0.006)
+@pytest.mark.parametrize("mode,tol", [("f32", 3e-3), ("bf16x3", 1e-2), ("f16f8", 3e-2), ("f16f8p", 3e-2), ("f16f4p", 1.5e-1), (None, 1.5e-1)])
 def test_infere_single_and_predict_unet_on_real_cover(ref_model, mode, tol):
     """cover_10.png is one of the reference's own 512x512 covers; tolerances are in 0..255 units
-    (tol/255 on the [0,1] output: 1.2e-5 / 4e-5 / 1.2e-4, max over 260k pixels).  mode None is the DEFAULT a user of get_pretrained /
-    get_unet_estimator gets (planar 'f16f8p', drop_rate 0.)."""
+    (tol/255 on the [0,1] output: 1.2e-5 / 4e-5 / 1.2e-4 / 6e-4, max over 260k pixels).  mode None is the DEFAULT a user of get_pretrained /
+    get_unet_estimator gets (planar storage, fp4 cross terms: 'f16f4p'; drop_rate 0.)."""
     fname = GOLDEN / "cover_10.png"
     x = imread4_f32(fname)[..., 3:]
     model = gpu_model(2, "he", mode, drop_rate=0.)                 # get_pretrained builds with drop_rate=0.
@@ -34,14 +34,15 @@ def test_infere_single_and_predict_unet_on_real_cover(ref_model, mode, tol):
     y_ref = evaluate_ref.infere_single(x, ref_model)
     assert y.shape == (510, 510, 1) and y.dtype == np.float32
     if mode is None:
-        assert model.mode == "f16f8p" and model.input_dropout is not None
+        assert model.mode == DEFAULT_MODE and model.input_dropout is not None
     assert np.abs(y - y_ref).max() <= tol
-    assert np.abs(y - y_ref).mean() <= tol / 10                    # 'f16f8p': MAE 4e-6 on the [0,1] output = 1e-3 in these units
+    assert np.abs(y - y_ref).mean() <= tol / 10                    # 'f16f8p': MAE 4e-6 on the [0,1] output = 1e-3 in these units; 'f16f4p': 2.5e-5 = 6e-3
     assert x.max() > 1.0                                            # the caller's array is not modified in place
     res = evaluate.predict_unet(fname, model, name="images/10.png", height=512, width=512)
     ref = evaluate_ref.predict_unet_array(x, ref_model)
     assert set(res) == {"name", "height", "width", "beta_hat", "l1"}
-    assert abs(res["beta_hat"] - ref["beta_hat"]) <= 1e-4 and abs(res["l1"] - ref["l1"]) <= 1e-4
+    stat_tol = 1e-3 if mode in (None, "f16f4p") else 1e-4           # beta_hat / l1 are means over the image: they follow the MAE
+    assert abs(res["beta_hat"] - ref["beta_hat"]) <= stat_tol and abs(res["l1"] - ref["l1"]) <= stat_tol
 
 
 def _make_dataset(root, n=5):
@@ -73,7 +74,8 @@ def test_evaluate_loop_per_image_vs_batched(tmp_path, ref_model, mode):
     np.testing.assert_allclose(dfb["l1"].to_numpy(float), df["l1"].to_numpy(float), atol=2e-5)
     # oracle for the first row (images/1.png is u8[2])
     ref = evaluate_ref.predict_unet_array(u8[2][..., None].astype(np.float32), ref_model)
-    assert abs(df["beta_hat"][0] - ref["beta_hat"]) <= 1e-4 and abs(df["l1"][0] - ref["l1"]) <= 1e-4
+    # l1 is a mean |x - prediction| in 0..255 units: it follows the mode's MAE (default 'f16f4p': 2.5e-5 x 255 = 6e-3; measured difference 8e-4)
+    assert abs(df["beta_hat"][0] - ref["beta_hat"]) <= 1e-4 and abs(df["l1"][0] - ref["l1"]) <= (5e-3 if mode is None else 1e-4)
     st = evaluate.predict_unet_stego(tmp_path, model=model, stego_method="LSBR")
     stb = evaluate.predict_unet_stego_batched(tmp_path, model=model, stego_method="LSBR", alpha=0.4)
     assert list(st.columns) == ["name", "height", "width", "stego_method", "alpha", "beta_hat", "l1"] == list(stb.columns)
@@ -116,9 +118,9 @@ def test_model_discovery_and_checkpoint_roundtrip(tmp_path):
     x = formula.synthetic_images(1, 512, 512, seed=3)[0][..., None].astype(np.float32)
     y = predict(x)
     assert y.shape == (510, 510, 1) and 0 <= y.min() and y.max() <= 255
-    # the DEFAULT closure (planar 'f16f8p', drop_rate 0.) against the oracle's infere_single on the same weights (0..255 units)
+    # the DEFAULT closure ('f16f4p', drop_rate 0.) against the oracle's infere_single on the same weights (0..255 units)
     y_ref = evaluate_ref.infere_single(x, unet_ref.build_ref(2, sd))
-    assert np.abs(y - y_ref).max() <= 3e-2 and np.abs(y - y_ref).mean() <= 3e-3
+    assert np.abs(y - y_ref).max() <= 1.5e-1 and np.abs(y - y_ref).mean() <= 1.5e-2
     from ws_unet_amd.model import get_model
     with pytest.raises(NotImplementedError):
         get_model("cnn_1", in_channels=1)
@@ -127,7 +129,7 @@ def test_model_discovery_and_checkpoint_roundtrip(tmp_path):
 @pytest.mark.parametrize("mode", ["f32", None])
 def test_sharded_dataset_evaluate_and_cli(tmp_path, mode):
     """predict_unet_sharded == the per-image iterators' table (single rank), and the `python -m ws_unet_amd.evaluate` driver writes it
-    (mode None: the driver's and get_pretrained's default, planar 'f16f8p')."""
+    (mode None: the driver's and get_pretrained's default, 'f16f4p')."""
     data = tmp_path / "data"
     data.mkdir()
     _make_dataset(data)
@@ -164,13 +166,13 @@ def test_range_guard_looks_once_per_dataset_pass(tmp_path, caplog):
     _make_dataset(tmp_path)
     clean = gpu_model(2, "he", None, drop_rate=0.)
     ref = evaluate.predict_unet_cover_batched(tmp_path, model=clean)
-    assert clean.mode == "f16f8p"
+    assert clean.mode == DEFAULT_MODE
     for driver in ("batched", "sharded", "per_image"):
         m = gpu_model(2, "he", None, drop_rate=0.)
         x0 = torch.zeros(1, 1, 16, 16, device=DEV)
         with torch.no_grad():
             m(x0)                                                     # first forward: range check spent on harmless activations
-        assert m.mode == "f16f8p" and m._range_checked
+        assert m.mode == DEFAULT_MODE and m._range_checked
         with torch.no_grad():
             m.e11.weight.data.mul_(3000.0); m.e11.bias.data.mul_(3000.0); m.e12.weight.data.div_(3000.0)
         m._pack_cache.clear()                                         # packed weights follow, the range check stays spent
@@ -199,7 +201,7 @@ def test_load_state_dict_rearms_the_range_check(caplog):
     x = torch.rand((1, 1, 32, 64), generator=torch.Generator().manual_seed(2)).to(DEV)
     with torch.no_grad():
         m(x)
-    assert m._range_checked and m.mode == "f16f8p"
+    assert m._range_checked and m.mode == DEFAULT_MODE
     m.invalidate_packed(recheck_range=False)
     assert m._range_checked
     sd = {k: v.detach().clone() for k, v in m.state_dict().items()}

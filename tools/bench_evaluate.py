@@ -13,7 +13,7 @@ from ws_unet_amd.model import get_model
 ap = argparse.ArgumentParser()
 ap.add_argument("--images", type=int, default=256)
 ap.add_argument("--batch", type=int, default=32)
-ap.add_argument("--mode", default="f16f8p")
+ap.add_argument("--mode", default="f16f4p")
 a = ap.parse_args()
 root = Path(tempfile.mkdtemp())
 (root / "images").mkdir()

@@ -14,7 +14,7 @@ echo "pmc write done"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/kt_train -o train --output-format csv -- python3 $R/tools/bench_train.py --batch 64 --steps 3 > $O/train_kt.log 2>&1
 echo "train kernel trace done"
 cd $R
-python3 tools/pmc_traffic.py $(ls $O/pmc_fetch/*counter_collection.csv | head -1) $(ls $O/pmc_write/*counter_collection.csv | head -1) $O/pmc_conv3x3_traffic.json conv3x3_pl_kernel f16f8p > $O/pmc_traffic.log 2>&1 || echo "pmc summary failed"
+python3 tools/pmc_traffic.py $(ls $O/pmc_fetch/*counter_collection.csv | head -1) $(ls $O/pmc_write/*counter_collection.csv | head -1) $O/pmc_conv3x3_traffic.json conv3x3_pl_kernel f16f4p > $O/pmc_traffic.log 2>&1 || echo "pmc summary failed"
 timeout -k 10 300 python tools/bench_evaluate.py > $O/evaluate_loop.log 2>&1
 echo "evaluate done"
 timeout -k 10 300 python tools/bench_ws_attack.py > $O/ws_attack.log 2>&1

@@ -98,7 +98,7 @@ class UNet(nn.Module):
         if nsteps > 4:
             raise NotImplementedError("the reference defines at most 4 pooling steps (unet.py:85-132)")
         self.nsteps = nsteps
-        self.mode = mode or os.environ.get("WSU_MODE", "f16f8p")
+        self.mode = mode or os.environ.get("WSU_MODE", "f16f4p")
         self.fuse_head = os.environ.get("WSU_FUSE_HEAD", "1") != "0"  # fold outconv + sigmoid into the last 3x3 conv
         self.fuse_first = os.environ.get("WSU_FUSE_FIRST", "1") != "0"  # fold e11 into e12's input staging
         # planar path: e11 computed by the loader waves of e12's kernel (wsu_conv3x3_pl_fused_first_fwd).  Off by default: xe11 never
