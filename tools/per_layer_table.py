@@ -1,11 +1,11 @@
-"""profiles/rNN/per_layer_*.md from a bench.py line: python tools/per_layer_table.py profiles/r03/bench_n1.json.log > profiles/r03/per_layer_f16f8p.md"""
+"""profiles/rNN/per_layer_*.md from a bench.py line: python tools/per_layer_table.py profiles/r03/bench_n1.json.log > profiles/r03/per_layer.md"""
 import json
 import sys
 
 d = json.loads(open(sys.argv[1]).read().strip().split("\n")[-1])
 pl = d["roofline"]["per_layer"]
 rows = pl["layers"] if isinstance(pl, dict) else pl
-print(f"# Per-layer roofline of the predict step (mode f16f8p, batch 32 @ 512x512, one MI355X) -- `roofline.per_layer` of `{sys.argv[1].split('/')[-1]}`\n")
+print(f"# Per-layer roofline of the predict step (default mode, batch 32 @ 512x512, one MI355X) -- `roofline.per_layer` of `{sys.argv[1].split('/')[-1]}`\n")
 print("roof = max(algorithmic FLOPs / 2.5 PFLOP/s, algorithmic bytes / 8 TB/s); bytes = inputs once + outputs once + weights, priced at the format's 3 B per element "
       "AND at SURVEY 8d's 2 B (VERDICT r02 #12).\n")
 print("| layer | kernel | ms | GFLOP | MB (3 B) | MB (2 B) | bound | roof / measured (3 B) | roof / measured (2 B) | TFLOP/s | GB/s | tiles (16x32 px x 64 co) | steps per tile |")

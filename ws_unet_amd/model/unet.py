@@ -17,11 +17,11 @@ Precision modes (``mode=`` or env ``WSU_MODE``):
   'f16f8p'  the 'f16f8' arithmetic on PLANAR storage -- [n][C/16][4 planes][H][W][16 B], the LDS image of the matrix kernels: staging is a
                                                    pure LDS-DMA and one persistent workgroup per CU pipelines it across chunks and tiles
                                                    (csrc/conv3x3_pl.hip, planar.hip); same values as 'f16f8' up to the accumulation order
-  'f16f4p'  'f16f8p' storage; the 3x3 convs multiply both cross terms as ONE block-scaled fp4 (e2m1) operand pair per tap pair (14 instead of 19
-            matrix units per chunk; include/wsu.h x_residual = 2): MAE ~2.5e-5 instead of 4e-6, -7 .. -15 % time on the deep layers (opt-in; training
-            and the transposed convs keep the e4m3 arithmetic)
+  'f16f4p'  (DEFAULT since round 3) 'f16f8p' storage; the 3x3 convs multiply both cross terms as ONE block-scaled fp4 (e2m1) operand pair per tap
+            pair (14 instead of 19 matrix units per chunk; include/wsu.h x_residual = 2): MAE 2.5e-5 (the gate is 1e-4) instead of 4e-6, 14 % more
+            images/s; training forwards and the transposed convs keep the e4m3 arithmetic (profiles/r03/f16f4p.md)
   'f16f8q'  'f16f8p' with ONE cross term (the weights' residual) on the first conv of every decoder block: MAE ~4e-5 instead of 4e-6
-  'f16f8'   f16 products + fp8 cross terms      -- default: f16(w)*f16(x) exactly, the two residual cross terms on the block-scaled fp8
+  'f16f8'   f16 products + fp8 cross terms      -- f16(w)*f16(x) exactly, the two residual cross terms on the block-scaled fp8
                                                    matrix pipe (0.70 of bf16x3's matrix cycles, ~2^-15 relative error per product, MAE
                                                    4e-6 on the full-range test weights); same storage discipline as 'bf16x3s'.
                                                    Activations beyond +-448 fall back to plain f16 accuracy (include/wsu.h): networks
