@@ -1,5 +1,5 @@
-"""Race screen for conv3x3_pl: many launches of several shapes, every result compared bitwise with the first one and (once) with the
-old f16f8 kernel's values.  Prints the number of mismatching launches per shape."""
+"""Race screen for conv3x3_pl: many launches of several shapes, every result compared bitwise with the first one.  Prints the number of
+mismatching launches per shape.  python tools/stress_pl.py [iterations] [--q4]"""
 import sys
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent)); sys.path.insert(0, str(Path(__file__).resolve().parent))
@@ -7,7 +7,9 @@ import torch
 from ws_unet_amd import ops
 from time_pl import enc_planar, enc_nhwc
 M = ops.mode_id("f16f8")
-iters = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+_num = [a for a in sys.argv[1:] if a.isdigit()]
+iters = int(_num[0]) if _num else 100
+Q4 = "--q4" in sys.argv                      # the block-scaled fp4 variant (x_residual = 2; the default mode's 3x3 convs)
 g = torch.Generator(device="cuda").manual_seed(7)
 bad_total = 0
 for (n, h, w, c1, c2, cout, pool, head) in [(8, 64, 96, 64, 0, 64, True, False), (4, 128, 128, 128, 128, 128, False, False), (16, 48, 80, 64, 0, 64, False, True),
@@ -16,14 +18,15 @@ for (n, h, w, c1, c2, cout, pool, head) in [(8, 64, 96, 64, 0, 64, True, False),
     x2 = torch.randn(n, h, w, c2, device="cuda", generator=g).clamp_min(0) if c2 else None
     wt = torch.randn(cout, c1 + c2, 3, 3, device="cuda", generator=g) * (2.0 / (9 * (c1 + c2))) ** 0.5
     b = torch.randn(cout, device="cuda", generator=g) * 0.1
-    wp = ops.pack_conv3x3(wt, M)
+    wp = ops.pack_conv3x3_f4(wt) if Q4 else ops.pack_conv3x3(wt, M)
+    XR = 2 if Q4 else True
     p1, p2 = enc_planar(x1), (enc_planar(x2) if c2 else None)
     hw_ = torch.randn(1, 64, 1, 1, device="cuda", generator=g) * 0.2 if head else None
     hb = torch.zeros(1, device="cuda") if head else None
     def run():
         if head:
-            return ops.conv3x3_pl(p1, p2, wp, b, cout, head_w=hw_, head_b=hb, want_y=True)
-        r = ops.conv3x3_pl(p1, p2, wp, b, cout, pool=pool)
+            return ops.conv3x3_pl(p1, p2, wp, b, cout, head_w=hw_, head_b=hb, want_y=True, x_residual=XR)
+        r = ops.conv3x3_pl(p1, p2, wp, b, cout, pool=pool, x_residual=XR)
         return r if pool else (r,)
     ref = [t.clone() for t in run()]
     torch.cuda.synchronize()
