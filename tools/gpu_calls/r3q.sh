@@ -5,5 +5,5 @@ for r in 1 2; do
   timeout -k 10 200 python tools/probe_units_pl.py libwsu_plopq.so > $O/opq_$r.log 2>&1 || exit 1
 done
 for f in product_1 opq_1 product_2 opq_2; do echo "== $f"; grep -o "cin=.*us" $O/$f.log | tr '\n' ';'; echo; done
-bash tools/r3n.sh || exit 1
-bash tools/r3o.sh
+bash tools/gpu_calls/r3n.sh || exit 1
+bash tools/gpu_calls/r3o.sh
