@@ -377,3 +377,19 @@ def test_conv3x3_pl_q4_variants_and_repeatability():
             again = again if pool else (again,)
             for a_, f_ in zip(again, first):
                 assert torch.equal(a_.view(torch.int32), f_.view(torch.int32))
+
+
+@pytest.mark.gpu
+def test_conv3x3_pl_q4_argument_errors():
+    """The fp4 variant's entry points refuse what they do not implement, with a message (no silent fallback)."""
+    from ws_unet_amd import ops, _lib
+    with pytest.raises(_lib.WsuError, match="fp4 packing"):
+        ops.pack_conv3x3_f4(torch.zeros((64, 8, 3, 3), device=DEV))                 # cin not a multiple of 16
+    with pytest.raises(_lib.WsuError, match="fp4 packing"):
+        ops.pack_conv3x3_f4(torch.zeros((32, 16, 3, 3), device=DEV))                # cout not a multiple of 64
+    x = planar_encode(torch.zeros((1, 16, 8, 8))).to(DEV)
+    wp = ops.pack_conv3x3_f4(torch.zeros((64, 16, 3, 3), device=DEV))
+    with pytest.raises(_lib.WsuError, match="relu_mask_out"):
+        ops.conv3x3_pl(x, None, wp, None, 64, x_residual=2, want_mask=True)         # the training forward's mask planes come from the e4m3 variant
+    with pytest.raises(_lib.WsuError, match="x_residual"):
+        ops.conv3x3_pl(x, None, wp, None, 64, x_residual=3)
