@@ -393,3 +393,32 @@ def test_conv3x3_pl_q4_argument_errors():
         ops.conv3x3_pl(x, None, wp, None, 64, x_residual=2, want_mask=True)         # the training forward's mask planes come from the e4m3 variant
     with pytest.raises(_lib.WsuError, match="x_residual"):
         ops.conv3x3_pl(x, None, wp, None, 64, x_residual=3)
+
+
+@pytest.mark.gpu
+def test_conv3x3_pl_q4_random_shapes():
+    """A dozen randomly drawn problem shapes (fixed seed): image sizes that are not multiples of the 16 x 32 tile, 1-6 chunks per source, fused
+    concat, pool on even sizes, 1-3 output blocks, negative inputs -- the fp4 variant against the CPU emulation of its arithmetic."""
+    from ws_unet_amd import ops
+    rng = np.random.default_rng(20261004)
+    g = torch.Generator().manual_seed(5)
+    for _ in range(12):
+        n = int(rng.integers(1, 4)); h = int(rng.integers(2, 70)); w = int(rng.integers(2, 90))
+        c1 = 16 * int(rng.integers(1, 7)); c2 = 16 * int(rng.integers(0, 4)); cout = 64 * int(rng.integers(1, 4))
+        pool = bool(rng.integers(0, 2)) and h % 2 == 0 and w % 2 == 0
+        relu = bool(rng.integers(0, 2))
+        cin = c1 + c2
+        x = planar_decode(planar_encode(torch.randn((n, cin, h, w), generator=g) * torch.exp2(torch.randint(-6, 5, (n, 1, h, w), generator=g).float())))
+        wgt = torch.randn((cout, cin, 3, 3), generator=g) * (2.0 / (9 * cin)) ** 0.5
+        b = torch.randn(cout, generator=g) * 0.1
+        ref = _conv3x3_q4_ref(x, wgt, b)
+        ref = torch.relu(ref) if relu else ref
+        out = ops.conv3x3_pl(planar_encode(x[:, :c1]).to(DEV), planar_encode(x[:, c1:]).to(DEV) if c2 else None, ops.pack_conv3x3_f4(wgt.to(DEV)), b.to(DEV), cout,
+                             relu=relu, pool=pool, x_residual=2)
+        torch.cuda.synchronize()
+        y = planar_decode(out[0] if pool else out)
+        scale = float(ref.abs().max())
+        err = float((y - ref).abs().max())
+        assert err < 3e-5 * scale, (n, h, w, c1, c2, cout, pool, relu, err / scale)
+        if pool:
+            assert float((planar_decode(out[1]) - F.max_pool2d(y, 2)).abs().max()) == 0.0
