@@ -21,6 +21,15 @@
 #include "wsu_device.h"
 #include <cstdlib>
 
+#ifndef WSU_PL_EPO
+#define WSU_PL_EPO 1            // 1 = the Q4 variants overlap the first half of a tile's epilogue with the second half of its last step (see `EPO` in the kernel)
+#endif
+#ifndef WSU_PL_EPO_FENCE
+#define WSU_PL_EPO_FENCE 0      // experiment: 1 = one scheduling region per tap pair in the fused part of the last step (measured 0-1 % slower than leaving it to the scheduler)
+#endif
+#ifndef WSU_PL_EPO_HEAD
+#define WSU_PL_EPO_HEAD 0       // experiment: 1 = the head variants, too (their epilogue stores nothing: d42 + head measured 4-6 % slower with the split last step)
+#endif
 #ifndef WSU_PL_OPAQUE_HH
 #define WSU_PL_OPAQUE_HH 0      // experiment: 1 = the e4m3 variants, too, recompute their tap-pair offsets per step (see hh_q in the kernel)
 #endif
@@ -555,24 +564,43 @@ __device__ __forceinline__ void pl_loader_q4(const PlArgs& a, char* smem, int la
     if (J > 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NIN) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // step 0's inputs (its weights are older)
     derive(even, 0);
     // one step: barrier j, then issue W(j+1), IN(j+2), convert step j+1 (its inputs were issued a whole step ago), wait for W(j+1)
+    [[maybe_unused]] unsigned long long q0 = 0, q1 = 0, q2 = 0, q3 = 0, q4 = 0, q5 = 0, t_bar = 0, t_issue = 0, t_win = 0, t_derive = 0, t_ww = 0, t0 = 0, rt0 = 0;   // stamps build only
+    STAMP(t0);
+#ifdef WSU_PL_STAMPS
+    rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
     auto step = [&](auto par, int j) __attribute__((always_inline)) -> bool {       // par = parity of j; returns false after the last barrier
         constexpr int P = decltype(par)::value;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // this wave's Q / S of step j are written
+        STAMP(q0);
         __builtin_amdgcn_s_barrier();                                 // barrier j: step j is complete in LDS; every matrix wave has left step j - 1
         asm volatile("" ::: "memory");
+        STAMP(q1);
         if (j + 1 >= J) return false;
         issue_w(j + 1);                                               // its slot held step j - 1
         const bool more = j + 2 < J;
         if (more) issue_in(par, j + 2);                               // (same parity as j) its slot held step j - 1
+        STAMP(q2);
         wait_all_but(more, NW);                                       // step j + 1's inputs: younger are W(j+1) and, if issued, IN(j+2)
+        STAMP(q3);
         derive(std::integral_constant<int, 1 - P>{}, j + 1);
+        STAMP(q4);
         if (more) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NIN) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // step j + 1's weights
+        STAMP(q5);
+        t_bar += q1 - q0; t_issue += q2 - q1; t_win += q3 - q2; t_derive += q4 - q3; t_ww += q5 - q4;
         return true;
     };
     for (int j = 0; ; j += 2) {
         if (!step(even, j)) break;
         if (!step(odd, j + 1)) break;
     }
+#ifdef WSU_PL_STAMPS
+    if (lane == 0 && LW == 0 && blockIdx.x < 128) {
+        unsigned long long* d = g_pl_stamps + (blockIdx.x * 2 + 1) * 8;
+        d[0] = __builtin_amdgcn_s_memtime() - t0; d[1] = __builtin_amdgcn_s_memrealtime() - rt0;
+        d[2] = t_win; d[3] = t_bar; d[4] = t_issue; d[5] = t_derive; d[6] = t_ww; d[7] = (unsigned long long)J;
+    }
+#endif
 }
 
 // HEAD / POOL are compile-time: the kernel sits at the 168-register step (three waves per SIMD), and the head's partial sums or the pool's
@@ -589,7 +617,10 @@ __device__ __forceinline__ void pl_loader_q4(const PlArgs& a, char* smem, int la
 // HONLY (round 3, a training arithmetic of the data gradient: wsu.h "products"): f16 products only -- the 9 f16 instructions of a chunk, no
 // cross terms; the residual plane of the gradient, the e4m3 weight planes and the derived plane are neither fetched nor built (needs XRES = false).
 template <int HC, bool POOL, bool XRES = true, bool F1 = false, bool GRAD = false, bool MSPLIT = false, bool HONLY = false, bool Q4 = false>   // HC = head planes compiled in: 0 (no head), 1 (the reference's single output plane) or 4 (1..4)
-__global__ __launch_bounds__(NT) void conv3x3_pl_kernel(const PlArgs a) {
+// (EPO variants: the loop nest needs ~125 registers and the compiler then schedules for FOUR waves per SIMD, which the 157 KB of LDS rule out anyway;
+// told that three is all there will be, it uses ~160 and prefetches fragments further ahead: -0.9 % per layer)
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3, (WSU_PL_EPO && Q4 && !MSPLIT && (WSU_PL_EPO_HEAD || HC == 0)) ? 3 : 8)))
+void conv3x3_pl_kernel(const PlArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
@@ -659,42 +690,57 @@ __global__ __launch_bounds__(NT) void conv3x3_pl_kernel(const PlArgs a) {
 #endif
     Tile cur = tile_of(a, lw);
     constexpr int MH = MSPLIT ? 1 : 2;                                        // accumulator tiles along the output channels
+    // EPO (round 3): while a tile's epilogue runs -- ~6.6 vector instructions per stored value -- the matrix pipe of the SIMD idles (both of its
+    // matrix waves are in the epilogue at the same time): 20-30 % of a 4-step tile.  The last step is therefore split by accumulator tile: m = 0
+    // first, then the units of m = 1 in ONE basic block with the epilogue of m = 0 (stores predicated by out-of-range buffer offsets instead of
+    // branches), so that each wave has matrix instructions in flight while it encodes.
+    constexpr bool EPO = WSU_PL_EPO && Q4 && !MSPLIT && (WSU_PL_EPO_HEAD || HC == 0);
     f32x16 acc[2][2];                                                         // [MH][2] used (declared with the template-dependent bound, hipcc (ROCm 7.2)
                                                                               // silently emits no host stub for ANY instantiation of the kernel)
     const int sc_a = hh ? WSU_F8_SCALE_WLO : WSU_F8_SCALE_W;
     const int sc_b = GRAD ? (hh ? WSU_F8_SCALE_G : WSU_F8_SCALE_GLO) : (hh ? WSU_F8_SCALE_X : WSU_F8_SCALE_XLO);
-    int c = 0, kt = 0;                                                        // chunk inside the tile, tile counter
-    for (int j = 0; j < J; ++j) {
+    int c = 0, kt = 0, j = 0;                                                 // chunk inside the tile, tile counter, chunk step
+    // per-step state (set by begin_step; the matrix section's lambdas below capture it by reference)
+    char* st = smem;
+    [[maybe_unused]] unsigned q_in_off = 0, q_w_off = 0;                      // Q4: this step's input / weight slot
+    [[maybe_unused]] const char* q_in = smem;
+    [[maybe_unused]] const char* q_w = smem;
+    const char* ldsA = smem;                                                  // + ((tap*4 + g)*64 + m*32)*16   (HONLY: tap*2 + g; Q4: tap*3 + g)
+    const char* ldsB = smem;                                                  // + g*PLANE + ((q+dy)*IW + dx)*16
+    // (an opaque copy of the lane half per step: the tap-pair offsets of the cross terms -- in the Q4 variant weight granule, both scale bytes
+    // and pixel -- are loop invariant per lane, and hoisted out of the tile loop the 15-20 of them stayed live across it: the variant spilled the
+    // epilogue's constants, whose re-loads drained the epilogue's stores.  Recomputed per step: no spill.)
+    [[maybe_unused]] int hh_q = hh;
+#if WSU_PROBE == 5
+    u32x4 sa0[2], sa1[2], sb0[2], sb1[2], sah[2], sbh[2];
+#endif
+    auto begin_step = [&]() __attribute__((always_inline)) {
         // ---- step j: its DMA (issued by the loaders one step ago) has had a whole matrix section to land -----------------------
         STAMP(s0);
         STAMP(s1);
         __builtin_amdgcn_s_barrier();                                         // the loaders' pieces landed; everyone left the other stage
         asm volatile("" ::: "memory");
         STAMP(s2);
-        char* st = HONLY ? smem + (j % NSTAGE_H) * STAGE_H : smem + (j & 1) * STAGE;
-        [[maybe_unused]] const unsigned q_in_off = (unsigned)(j % Q4_NIN) * Q4_IN_SLOT, q_w_off = Q4_W_BASE + (unsigned)(j % Q4_NW) * Q4_W_SLOT;   // Q4: this step's input / weight slot
-        [[maybe_unused]] const char* q_in = smem + q_in_off;
-        [[maybe_unused]] const char* q_w = smem + q_w_off;
+        st = HONLY ? smem + (j % NSTAGE_H) * STAGE_H : smem + (j & 1) * STAGE;
+        q_in_off = (unsigned)(j % Q4_NIN) * Q4_IN_SLOT; q_w_off = Q4_W_BASE + (unsigned)(j % Q4_NW) * Q4_W_SLOT;
+        q_in = smem + q_in_off;
+        q_w = smem + q_w_off;
         STAMP(s3);
-        if (c == 0) {
-#pragma unroll
-            for (int m = 0; m < MH; ++m)
-#pragma unroll
-                for (int q = 0; q < 2; ++q)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[m][q][r] = 0.f;
-        }
-        // ---- matrix section: identical arithmetic (and accumulation order) to conv3x3_kernel<F16F8> -----------------------------
-        const char* ldsA = Q4 ? q_w + (cur.mh * 32 + l31) * 16 : st + (HONLY ? LDS_IN_H : LDS_IN) + (cur.mh * 32 + l31) * 16;   // + ((tap*4 + g)*64 + m*32)*16   (HONLY: tap*2 + g; Q4: tap*3 + g)
-        const char* ldsB = (Q4 ? q_in : st) + ((2 * wv) * IW + l31) * 16;     // + g*PLANE + ((q+dy)*IW + dx)*16
-#if WSU_PROBE == 5
-        u32x4 sa0[2], sa1[2], sb0[2], sb1[2], sah[2], sbh[2];
-#endif
-        // (an opaque copy of the lane half per step: the tap-pair offsets of the cross terms -- in the Q4 variant weight granule, both scale bytes
-        // and pixel -- are loop invariant per lane, and hoisted out of the tile loop the 15-20 of them stayed live across it: the variant spilled the
-        // epilogue's constants, whose re-loads drained the epilogue's stores.  Recomputed per step: no spill.)
-        [[maybe_unused]] int hh_q = hh;
+        ldsA = Q4 ? q_w + (cur.mh * 32 + l31) * 16 : st + (HONLY ? LDS_IN_H : LDS_IN) + (cur.mh * 32 + l31) * 16;
+        ldsB = (Q4 ? q_in : st) + ((2 * wv) * IW + l31) * 16;
+        hh_q = hh;
         if constexpr (Q4 || WSU_PL_OPAQUE_HH) asm volatile("" : "+v"(hh_q));
+    };
+    auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int m = 0; m < MH; ++m)
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][q][r] = 0.f;
+    };
+    // ---- matrix section: identical arithmetic (and accumulation order) to conv3x3_kernel<F16F8> -----------------------------
+    {
         auto cross = [&](auto tp_c) __attribute__((always_inline)) {
             constexpr int tp = decltype(tp_c)::value;
             constexpr int t0 = 2 * tp, t1 = (2 * tp + 1 < 9) ? 2 * tp + 1 : 2 * tp;
@@ -734,8 +780,9 @@ _Pragma("unroll")
 _Pragma("unroll")
                 for (int q = 0; q < 2; ++q) wsu_mfma_f8x2(a0[m], a1[m], b0[q], b1[q], sc_a, sc_b, acc[m][q]);
         };
-        auto main_term = [&](auto tap_c) __attribute__((always_inline)) {
+        auto main_term = [&](auto tap_c, auto ms_c) __attribute__((always_inline)) {
             constexpr int tap = decltype(tap_c)::value, dy = tap / 3, dx = tap % 3;
+            constexpr int ms = decltype(ms_c)::value, ML = ms < 0 ? 0 : ms, MU = ms < 0 ? MH : ms + 1;
             u32x4 ah[2], bh[2];
 #if WSU_PROBE == 5
             if (tap == 0) {
@@ -743,7 +790,7 @@ _Pragma("unroll")
             {
 #endif
 _Pragma("unroll")
-            for (int m = 0; m < MH; ++m) ah[m] = *reinterpret_cast<const u32x4*>(ldsA + ((tap * (HONLY ? 2 : Q4 ? 3 : 4) + hh) * 64 + m * 32) * 16);
+            for (int m = ML; m < MU; ++m) ah[m] = *reinterpret_cast<const u32x4*>(ldsA + ((tap * (HONLY ? 2 : Q4 ? 3 : 4) + hh) * 64 + m * 32) * 16);
 _Pragma("unroll")
             for (int q = 0; q < 2; ++q) bh[q] = *reinterpret_cast<const u32x4*>(ldsB + hh * PLANE + ((q + dy) * IW + dx) * 16);
 #if WSU_PROBE == 5
@@ -753,17 +800,19 @@ _Pragma("unroll")
             }
 #endif
 _Pragma("unroll")
-            for (int m = 0; m < MH; ++m)
+            for (int m = ML; m < MU; ++m)
 _Pragma("unroll")
                 for (int q = 0; q < 2; ++q) wsu_mfma_f16(ah[m], bh[q], acc[m][q]);
         };
+        constexpr std::integral_constant<int, -1> all_m{};
         // Measured neutral on this section (gpurun_out/ab_prio.log, time_pl*.log): raising the priority of waves 4-7 for its second half so
         // that SIMD partners reach the barrier together; fetching fragments one unit ahead of their matrix instructions behind scheduling
         // fences (two ahead needs 190 registers).
         // Q4: both cross terms of a tap pair in one fp4 instruction -- lane half hh carries tap 2 tp + hh: weight granule plane 2 and the pixel's Q
         // granule, each with its E8M0 scale byte (per (tap, co) / per pixel)
-        auto cross_q4 = [&](auto tp_c) __attribute__((always_inline)) {
+        auto cross_q4 = [&](auto tp_c, auto ms_c) __attribute__((always_inline)) {
             constexpr int tp = decltype(tp_c)::value;
+            constexpr int ms = decltype(ms_c)::value, ML = ms < 0 ? 0 : ms, MU = ms < 0 ? MH : ms + 1;     // accumulator tiles [ML, MU) along the output channels
             constexpr int t0 = 2 * tp, t1 = (2 * tp + 1 < 9) ? 2 * tp + 1 : 2 * tp;
             constexpr bool single = 2 * tp + 1 >= 9;
             const int tap = hh_q ? t1 : t0;
@@ -777,7 +826,7 @@ _Pragma("unroll")
             const unsigned sabase = q_w_off + Q4_W_GRAN + (unsigned)(tap * 64 + cur.mh * 32 + l31);
             const unsigned pix = (unsigned)((2 * wv) * IW + l31 + pixoff);
 _Pragma("unroll")
-            for (int m = 0; m < MH; ++m) {
+            for (int m = ML; m < MU; ++m) {
                 a4[m] = *(lds_cu32x4*)(L + wbase + m * 32 * 16);
                 sa[m] = *(lds_cuchar*)(L + sabase + m * 32);
             }
@@ -789,33 +838,43 @@ _Pragma("unroll")
             if (single && hh_q) {
                 const u32x4 z = mk_u4(0, 0, 0, 0);
 _Pragma("unroll")
-                for (int m = 0; m < MH; ++m) a4[m] = z;
+                for (int m = ML; m < MU; ++m) a4[m] = z;
                 b4[0] = z; b4[1] = z;
             }
 _Pragma("unroll")
-            for (int m = 0; m < MH; ++m)
+            for (int m = ML; m < MU; ++m)
 _Pragma("unroll")
                 for (int q = 0; q < 2; ++q) wsu_mfma_q4(a4[m], b4[q], sa[m], sb[q], acc[m][q]);
         };
         static_assert(!HONLY || !XRES, "HONLY reads neither residual plane");
+        [[maybe_unused]] auto units_q4_range = [&](auto ms_c, auto lo_c, auto hi_c) __attribute__((always_inline)) {     // tap pairs [lo, hi)
+            constexpr int lo = decltype(lo_c)::value, hi = decltype(hi_c)::value;
+            if constexpr (EPO) asm volatile("" : "+v"(hh_q));                 // (per call: the three paths of a step must not share -- and hoist -- their lane offsets)
+            WSU_STATIC_FOR(hi - lo, i, {
+                constexpr int tp = lo + i;
+                cross_q4(std::integral_constant<int, tp>{}, ms_c);
+                main_term(std::integral_constant<int, 2 * tp>{}, ms_c);
+                if constexpr (2 * tp + 1 < 9) main_term(std::integral_constant<int, 2 * tp + 1>{}, ms_c);
+            });
+        };
+        [[maybe_unused]] auto units_q4 = [&](auto ms_c) __attribute__((always_inline)) {
+            units_q4_range(ms_c, std::integral_constant<int, 0>{}, std::integral_constant<int, 5>{});
+        };
+        auto units_all = [&]() __attribute__((always_inline)) {
         if constexpr (Q4) {
             // (the Q4 variants end 6-13 registers above the 168 of three waves per SIMD: lane-derived epilogue constants are spilled at the kernel entry
             // and re-loaded per tile; scheduling fences between the groups, or recomputing those constants in the epilogue, moved the spills into
             // this loop and measured slower)
-            WSU_STATIC_FOR(5, tp, {
-                cross_q4(std::integral_constant<int, tp>{});
-                main_term(std::integral_constant<int, 2 * tp>{});
-                if constexpr (2 * tp + 1 < 9) main_term(std::integral_constant<int, 2 * tp + 1>{});
-            });
+            units_q4(all_m);
         } else if constexpr (HONLY) {
-            WSU_STATIC_FOR(9, tap, { main_term(std::integral_constant<int, tap>{}); });
+            WSU_STATIC_FOR(9, tap, { main_term(std::integral_constant<int, tap>{}, all_m); });
         } else if constexpr (XRES) {
             WSU_STATIC_FOR(5, tp, {
 #if WSU_PROBE != 3                                                      // timing probe 3 (make probes): no cross terms at all = plain f16, 9 units
                 cross(std::integral_constant<int, tp>{});
 #endif
-                main_term(std::integral_constant<int, 2 * tp>{});
-                if constexpr (2 * tp + 1 < 9) main_term(std::integral_constant<int, 2 * tp + 1>{});
+                main_term(std::integral_constant<int, 2 * tp>{}, all_m);
+                if constexpr (2 * tp + 1 < 9) main_term(std::integral_constant<int, 2 * tp + 1>{}, all_m);
             });
         } else {
             // one cross term: residual(w) x e4m3(x), FOUR taps per fp8 instruction -- scale block b (registers 4b..4b+3), lane half hh carry
@@ -842,22 +901,12 @@ _Pragma("unroll")
             };
             WSU_STATIC_FOR(3, g, {
                 cross1(std::integral_constant<int, g>{});
-                WSU_STATIC_FOR(4, i, { if constexpr (4 * g + i < 9) main_term(std::integral_constant<int, 4 * g + i>{}); });
+                WSU_STATIC_FOR(4, i, { if constexpr (4 * g + i < 9) main_term(std::integral_constant<int, 4 * g + i>{}, all_m); });
             });
         }
-
-        STAMP(s4);
-        t_wait += s1 - s0; t_bar += s2 - s1; t_dma += s3 - s2; t_mma += s4 - s3;
+        };
         // ---- epilogue of the tile: accumulators -> planar global memory ---------------------------------------------------------
-        if (c + 1 == a.nch && (a.ablate & 2)) {                            // timing only: the tile's results are dropped (kept alive for the compiler)
-#pragma unroll
-            for (int m = 0; m < MH; ++m)
-#pragma unroll
-                for (int q = 0; q < 2; ++q) asm volatile("" :: "v"(acc[m][q]));
-            ++kt; c = 0;
-            if (j + 1 < J) cur = tile_of(a, lw + kt * G);
-        } else
-        if (c + 1 == a.nch) {
+        auto finish_tile = [&]() __attribute__((always_inline)) {
             const int col = cur.x0 + l31;
             const size_t hw = (size_t)a.h * a.w;
             const int nco = a.cout >> 4;                                       // output chunks
@@ -868,10 +917,11 @@ _Pragma("unroll")
             for (int q = 0; q < 2; ++q)
 #pragma unroll
                 for (int o = 0; o < (HC > 0 ? HC : 1); ++o) hz[q][o] = 0.f;
-#pragma unroll
-            for (int m = 0; m < MH; ++m) {
-#pragma unroll
-                for (int cp = 0; cp < 2; ++cp) {                               // 16 output channels = accumulator groups g4 = 2cp, 2cp+1
+            auto epi_m = [&](auto m_c, auto&& before_piece) __attribute__((always_inline)) {   // one accumulator tile along the output channels: 32 channels x this wave's 2 x 32 pixels
+                constexpr int m = decltype(m_c)::value;
+                auto piece = [&](auto cp_c) __attribute__((always_inline)) {   // 16 output channels = accumulator groups g4 = 2cp, 2cp+1
+                    constexpr int cp = decltype(cp_c)::value;
+                    before_piece(std::integral_constant<int, 3 * cp>{});       // hook 3 cp: before the bias / ReLU of these 16 channels, 3 cp + 1 + q: before the encoding and stores of row q
                     const int oc = cur.cb * 4 + (m + cur.mh) * 2 + cp;
                     const int co0 = oc * 16 + 4 * hh;                          // this lane: channels co0..co0+3 (X) and co0+8..co0+11 (Y)
                     f32x4 vx[2], vy[2];
@@ -918,13 +968,22 @@ _Pragma("unroll")
                     }
                     // addresses = wave-uniform 64-bit base (image, output chunk) + 32-bit lane offset (pixel, plane): the stores take the
                     // SGPR-base form and the epilogue carries no 64-bit address registers (it sits at the 168-register step)
-                    auto store_px = [&](const f32x4& X, const f32x4& Y, char* base, uint32_t off, uint32_t plane_bytes, bool ok, unsigned char* mdst = nullptr) __attribute__((always_inline)) {
+                    auto store_px = [&](const f32x4& X, const f32x4& Y, char* base, uint32_t off, uint32_t plane_bytes, bool ok, unsigned char* mdst = nullptr, bool have = true) __attribute__((always_inline)) {
                         uint32_t xh0, xh1, xlo, yh0, yh1, ylo;
                         wsu_split4_f16r8(X, GRAD ? WSU_F8_GLO_DIV : WSU_F8_XLO_DIV, xh0, xh1, xlo);
                         wsu_split4_f16r8(Y, GRAD ? WSU_F8_GLO_DIV : WSU_F8_XLO_DIV, yh0, yh1, ylo);
                         swap32(xh0, yh0); swap32(xh1, yh1);                     // lanes 0-31: f16 ch 0-7, lanes 32-63: f16 ch 8-15
                         uint32_t xlp = xlo, ylp = ylo;
                         swap32(xlo, xlp); swap32(ylo, ylp);                     // lanes 0-31: xlp / ylp = the partner lane's residuals (ch 4-7 / 12-15)
+                        if constexpr (EPO) {
+                            // no branch (a branch ends the basic block the matrix instructions are scheduled in): a lane that must not store passes
+                            // an offset beyond the buffer's extent, which the hardware drops
+                            const auto rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, have ? (int)(3u * plane_bytes) : 0, 0x00020000);      // (have: wave-uniform)
+                            const uint32_t o1 = ok ? off + (hh ? plane_bytes : 0u) : 0x80000000u;
+                            const uint32_t o2 = (ok && !hh) ? off + 2u * plane_bytes : 0x80000000u;
+                            __builtin_amdgcn_raw_buffer_store_b128(mk_u4(xh0, xh1, yh0, yh1), rs, (int)o1, 0, 0);
+                            __builtin_amdgcn_raw_buffer_store_b128(mk_u4(xlo, xlp, ylo, ylp), rs, (int)o2, 0, 0);
+                        } else
                         if (ok) {
                             // (one 32-bit lane offset per store: written `base + off + hh * plane_bytes` the loop-invariant 64-bit `hh * plane_bytes` stayed live
                             // across the tile loop, was spilled, and every re-load drained the epilogue's stores with an s_waitcnt vmcnt(0))
@@ -949,9 +1008,9 @@ _Pragma("unroll")
                             store_px(vx[q], vy[q], base, (uint32_t)(row * a.w + col) * 16u, (uint32_t)hw * 16u, row < a.h && col < a.w);
                         }
                     } else
-                    if (a.y) {
-#pragma unroll
-                        for (int q = 0; q < 2; ++q) {
+                    if ((EPO && !HEAD) || a.y) {                               // (EPO without a head: no branch -- a null y makes the buffer empty)
+                        WSU_STATIC_FOR(2, q, {
+                            before_piece(std::integral_constant<int, 3 * cp + 1 + q>{});
                             const int row = cur.y0 + 2 * wv + q;
                             char* base = a.y + (((size_t)cur.n * nco + oc) * HBM_PLANES) * hw * 16;
                             unsigned char* mdst = nullptr;
@@ -959,8 +1018,11 @@ _Pragma("unroll")
                                 if (a.relu_mask_out)
                                     mdst = a.relu_mask_out + (((size_t)cur.n * (nco * 2) + oc * 2 + hh) * wsu_mask_hp(a.h) + row) * wsu_mask_wp(a.w) + col;
                             }
-                            store_px(vx[q], vy[q], base, (uint32_t)(row * a.w + col) * 16u, (uint32_t)hw * 16u, row < a.h && col < a.w, mdst);
-                        }
+                            store_px(vx[q], vy[q], base, (uint32_t)(row * a.w + col) * 16u, (uint32_t)hw * 16u, row < a.h && col < a.w, mdst, a.y != nullptr);
+                        });
+                    } else if constexpr (EPO) {                                // (a head that stores no activations: the hooks still run -- they carry matrix units)
+                        before_piece(std::integral_constant<int, 3 * cp + 1>{});
+                        before_piece(std::integral_constant<int, 3 * cp + 2>{});
                     }
                     if constexpr (POOL) {                                      // every lane takes part in the exchanges
                         f32x4 px, py;
@@ -978,7 +1040,26 @@ _Pragma("unroll")
                         char* base = a.ypool + (((size_t)cur.n * nco + oc) * HBM_PLANES) * hp * wp2 * 16;
                         store_px(px, py, base, (uint32_t)(gy * wp2 + gx) * 16u, (uint32_t)(hp * wp2) * 16u, !(l31 & 1) && gy < hp && gx < wp2);
                     }
-                }
+                };
+                piece(std::integral_constant<int, 0>{});
+                piece(std::integral_constant<int, 1>{});
+            };
+            auto nothing = [](auto) __attribute__((always_inline)) {};
+            if constexpr (EPO) {
+                // the last step's units of m = 1, one tap pair per scheduling region, each with a part of the encoding of m = 0
+                epi_m(std::integral_constant<int, 0>{}, [&](auto h_c) __attribute__((always_inline)) {
+                    constexpr int h = decltype(h_c)::value;                    // six hooks, five tap pairs: one scheduling region each (no fragment prefetch across them:
+#if WSU_PL_EPO_FENCE
+                    __builtin_amdgcn_sched_barrier(0);                         // with two tap pairs per region the variants spilled an accumulator tile in EVERY step)
+#endif
+                    if constexpr (h < 5) units_q4_range(std::integral_constant<int, 1>{}, std::integral_constant<int, h>{}, std::integral_constant<int, h + 1>{});
+                });
+#if WSU_PL_EPO_FENCE
+                __builtin_amdgcn_sched_barrier(0);
+#endif
+                epi_m(std::integral_constant<int, 1>{}, nothing);
+            } else {
+                WSU_STATIC_FOR(MH, m, { (void)m; epi_m(m_c, nothing); });
             }
             if constexpr (HEAD) {
                 // the other 32 channels of this pixel sit in the partner lane (lane ^ 32)
@@ -1009,8 +1090,38 @@ _Pragma("unroll")
 #ifdef WSU_PL_STAMPS
             t_epi += __builtin_amdgcn_s_memtime() - s4;
 #endif
+        };
+        if constexpr (EPO) {
+            // one loop nest per tile, the last step spelled out after the inner loop (as ONE step loop with a branch for the last step, the three-way
+            // code of a step made the register allocator copy and spill whole accumulator tiles in every step)
+            for (int t = 0; t < K; ++t) {
+                zero_acc();
+                for (int cc = 1; cc < a.nch; ++cc) { begin_step(); units_all(); ++j; }
+                begin_step();
+                units_q4(std::integral_constant<int, 0>{});                    // the last step: m = 0 first; m = 1 follows inside the epilogue
+                finish_tile();
+                ++j;
+            }
         } else {
-            ++c;
+            for (; j < J; ++j) {
+                begin_step();
+                if (c == 0) zero_acc();
+                units_all();
+                STAMP(s4);
+                t_wait += s1 - s0; t_bar += s2 - s1; t_dma += s3 - s2; t_mma += s4 - s3;
+                if (c + 1 == a.nch && (a.ablate & 2)) {                        // timing only: the tile's results are dropped (kept alive for the compiler)
+#pragma unroll
+                    for (int m = 0; m < MH; ++m)
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) asm volatile("" :: "v"(acc[m][q]));
+                    ++kt; c = 0;
+                    if (j + 1 < J) cur = tile_of(a, lw + kt * G);
+                } else if (c + 1 == a.nch) {
+                    finish_tile();
+                } else {
+                    ++c;
+                }
+            }
         }
     }
 #ifdef WSU_PL_STAMPS
