@@ -14,6 +14,8 @@ if libs:
     _lib.LIB_PATH = Path(_lib.LIB_PATH).parent / libs[0]
 XRES = "--xres0" not in sys.argv
 Q4 = "--q4" in sys.argv                      # the product's block-scaled fp4 variant (x_residual = 2, weights from pack_conv3x3_f4)
+ZEROS = "--zeros" in sys.argv                # all-zero activations and weights: the same instruction stream with (almost) no switching in the data paths --
+                                             # what the kernel would do if it were not power-managed (profiles/r03/conv3x3_pl_last_step.md)
 from ws_unet_amd import ops
 from time_pl import enc_planar
 
@@ -28,6 +30,9 @@ def run(cin, cout, hw, n=32, c2=0, pool=False):
     x1 = act(cin - c2)
     x2 = act(c2) if c2 else None
     w = torch.randn(cout, cin, 3, 3, device="cuda", generator=g) * (2.0 / (9 * cin)) ** 0.5
+    if ZEROS:
+        x1.zero_(); w.zero_()
+        if x2 is not None: x2.zero_()
     b = torch.zeros(cout, device="cuda")
     wp = ops.pack_conv3x3_f4(w) if Q4 else ops.pack_conv3x3(w, M)
     fn = lambda: ops.conv3x3_pl(x1, x2, wp, b, cout, pool=pool, x_residual=2 if Q4 else XRES)
@@ -43,7 +48,7 @@ def run(cin, cout, hw, n=32, c2=0, pool=False):
         e.record(); torch.cuda.synchronize()
         best = min(best, s.elapsed_time(e) / 10)
     fl = 2 * 9 * cin * cout * n * hw * hw
-    print(f"{Path(_lib.LIB_PATH).name}{' q4' if Q4 else '' if XRES else ' x_residual=0'}: cin={cin} cout={cout} hw={hw} concat={c2} pool={int(pool)}: {best * 1e3:.0f} us  {fl / best / 1e9:.0f} TFLOP/s algorithmic", flush=True)
+    print(f"{Path(_lib.LIB_PATH).name}{' q4' if Q4 else '' if XRES else ' x_residual=0'}{' zeros' if ZEROS else ''}: cin={cin} cout={cout} hw={hw} concat={c2} pool={int(pool)}: {best * 1e3:.0f} us  {fl / best / 1e9:.0f} TFLOP/s algorithmic", flush=True)
 
 
 run(64, 64, 512, pool=True); run(64, 128, 256); run(128, 128, 256, pool=True); run(256, 256, 128); run(256, 128, 256, c2=128); run(128, 64, 512, c2=64)

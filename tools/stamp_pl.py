@@ -31,6 +31,9 @@ buf = (ctypes.c_ulonglong * (256 * 8))()
 lib.wsu_debug_read_pl_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
 assert lib.wsu_debug_read_pl_stamps(buf, 256) == 0
 allrows = np.array(buf[:], dtype=np.float64).reshape(128, 2, 8)
+per_wave_bar = allrows[64:128]           # blocks 64-127: [block][0][wave 0-7] barrier wait of the matrix waves, [block][1][0-3] of the fp4 loaders (accumulated cycles)
+per_wave_mma = allrows[32:64, 0]         # blocks 32-63: matrix section time per matrix wave
+allrows = allrows[:32]
 ld = allrows[:, 1][allrows[:, 1, 7] > 0]
 s = allrows[:, 0][allrows[:, 0, 7] > 0]
 J = s[:, 7]
@@ -44,3 +47,7 @@ for k, name in ((2, "wait vmcnt"), (3, "barrier"), (4, "DMA issue (+tile plan)")
     print(f"  {name:24s} {np.median(s[:, k] / J):8.0f} cycles/step  ({100 * np.median(s[:, k] / s[:, 0]):.1f} %)")
 ntile = J / ((cin) // 16)
 print(f"  {'epilogue':24s} {np.median(s[:, 6] / ntile):8.0f} cycles/tile  ({100 * np.median(s[:, 6] / s[:, 0]):.1f} %)")
+Jn = float(np.median(J))
+print("  barrier wait per wave (cycles/step): matrix " + " ".join(f"{np.median(per_wave_bar[:, 0, w]) / Jn:.0f}" for w in range(8))
+      + (" | loaders " + " ".join(f"{np.median(per_wave_bar[:, 1, w]) / Jn:.0f}" for w in range(4)) if Q4 else ""))
+print("  matrix section per wave (cycles/step): " + " ".join(f"{np.median(per_wave_mma[:, w]) / Jn:.0f}" for w in range(8)))

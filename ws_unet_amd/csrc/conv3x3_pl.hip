@@ -462,7 +462,7 @@ __device__ __forceinline__ void pl_loader(const PlArgs& a, char* smem, int lane,
         if (a.range_flag && __builtin_amdgcn_ballot_w64(!(f1_max <= WSU_F8_RANGE)) != 0 && lane == 0) atomicOr(a.range_flag, 1u);
     }
 #ifdef WSU_PL_STAMPS
-    if (lane == 0 && LW == 0 && blockIdx.x < 128) {
+    if (lane == 0 && LW == 0 && blockIdx.x < 32) {
         unsigned long long* d = g_pl_stamps + (blockIdx.x * 2 + 1) * 8;
         d[0] = __builtin_amdgcn_s_memtime() - t0; d[1] = __builtin_amdgcn_s_memrealtime() - rt0;
         d[2] = t_wait; d[3] = t_bar; d[4] = t_dma; d[5] = 0; d[6] = 0; d[7] = (unsigned long long)J;
@@ -595,11 +595,12 @@ __device__ __forceinline__ void pl_loader_q4(const PlArgs& a, char* smem, int la
         if (!step(odd, j + 1)) break;
     }
 #ifdef WSU_PL_STAMPS
-    if (lane == 0 && LW == 0 && blockIdx.x < 128) {
+    if (lane == 0 && LW == 0 && blockIdx.x < 32) {
         unsigned long long* d = g_pl_stamps + (blockIdx.x * 2 + 1) * 8;
         d[0] = __builtin_amdgcn_s_memtime() - t0; d[1] = __builtin_amdgcn_s_memrealtime() - rt0;
         d[2] = t_win; d[3] = t_bar; d[4] = t_issue; d[5] = t_derive; d[6] = t_ww; d[7] = (unsigned long long)J;
     }
+    if (lane == 0 && blockIdx.x >= 64 && blockIdx.x < 128) g_pl_stamps[(blockIdx.x * 2 + 1) * 8 + LW] = t_bar;      // per-wave barrier waits (blocks 64-127)
 #endif
 }
 
@@ -691,9 +692,11 @@ void conv3x3_pl_kernel(const PlArgs a) {
     Tile cur = tile_of(a, lw);
     constexpr int MH = MSPLIT ? 1 : 2;                                        // accumulator tiles along the output channels
     // EPO (round 3): while a tile's epilogue runs -- ~6.6 vector instructions per stored value -- the matrix pipe of the SIMD idles (both of its
-    // matrix waves are in the epilogue at the same time): 20-30 % of a 4-step tile.  The last step is therefore split by accumulator tile: m = 0
-    // first, then the units of m = 1 in ONE basic block with the epilogue of m = 0 (stores predicated by out-of-range buffer offsets instead of
-    // branches), so that each wave has matrix instructions in flight while it encodes.
+    // matrix waves are in the epilogue at the same time).  The last step of a tile is therefore split by accumulator tile: m = 0 first, then the
+    // units of m = 1 in ONE basic block with the epilogue of m = 0 (stores predicated by out-of-range buffer offsets instead of branches), so that
+    // each wave has matrix instructions in flight while it encodes.  Same-box A/B of the whole net: +1.2-1.5 % (profiles/r03/conv3x3_pl_last_step.md,
+    // which also shows why no more: on real data this kernel runs against the chip's power management -- the same binary on all-zero operands
+    // is 27-31 % faster).
     constexpr bool EPO = WSU_PL_EPO && Q4 && !MSPLIT && (WSU_PL_EPO_HEAD || HC == 0);
     f32x16 acc[2][2];                                                         // [MH][2] used (declared with the template-dependent bound, hipcc (ROCm 7.2)
                                                                               // silently emits no host stub for ANY instantiation of the kernel)
@@ -865,6 +868,11 @@ _Pragma("unroll")
             // (the Q4 variants end 6-13 registers above the 168 of three waves per SIMD: lane-derived epilogue constants are spilled at the kernel entry
             // and re-loaded per tile; scheduling fences between the groups, or recomputing those constants in the epilogue, moved the spills into
             // this loop and measured slower)
+            // (stamps build, per-wave view: the arbiter serves the OLDER matrix wave of a SIMD first -- waves 0-3 leave their section after ~3500 cycles,
+            // waves 4-7 after ~4450, alone on the pipe at half its rate for the last ~950, and everyone waits for them at the barrier.  Swapping
+            // s_setprio between the two inside the section, after tap pair 2 or 3, measured 1-2 % SLOWER; fetching the fragments of unit u + 1 before
+            // the matrix instructions of unit u behind scheduling fences, and walking the f16 products column-wise with the shared pixel fragment
+            // carried in registers (12 instead of 18 reads per step), both measured +-0.1 %: profiles/r03/conv3x3_pl_last_step.md.)
             units_q4(all_m);
         } else if constexpr (HONLY) {
             WSU_STATIC_FOR(9, tap, { main_term(std::integral_constant<int, tap>{}, all_m); });
@@ -1125,7 +1133,9 @@ _Pragma("unroll")
         }
     }
 #ifdef WSU_PL_STAMPS
-    if (tid == 64 && blockIdx.x < 128) {                                       // matrix wave 1's view
+    if (lane == 0 && blockIdx.x >= 64 && blockIdx.x < 128) g_pl_stamps[(blockIdx.x * 2) * 8 + wv] = t_bar;          // per-wave barrier waits / section times
+    if (lane == 0 && blockIdx.x >= 32 && blockIdx.x < 64) g_pl_stamps[(blockIdx.x * 2) * 8 + wv] = t_mma;
+    if (tid == 64 && blockIdx.x < 32) {                                        // matrix wave 1's view
         unsigned long long* d = g_pl_stamps + (blockIdx.x * 2) * 8;
         d[0] = __builtin_amdgcn_s_memtime() - t0; d[1] = __builtin_amdgcn_s_memrealtime() - rt0;
         d[2] = t_wait; d[3] = t_bar; d[4] = t_dma; d[5] = t_mma; d[6] = t_epi; d[7] = (unsigned long long)J;
