@@ -355,11 +355,12 @@ def test_maxpool2x2_pl_bwd(with_skip, products):
     assert float(got[0, :, 0:2, 0:2].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("shape", [(2, 64, 24, 40), (2, 64, 192, 200)])      # the second: more pixels than one grid pass (the sum kernels take two pixels per thread then, some threads one)
 @pytest.mark.parametrize("products", ["f16f8", "f16"])
-def test_head_and_first_layer_pl_bwd(products):
+def test_head_and_first_layer_pl_bwd(products, shape):
     ops = _ops()
     f16 = products == "f16"
-    n, c, h, w = 2, 64, 24, 40
+    n, c, h, w = shape
     x = _q(torch.relu(_rand((n, c, h, w), 15)), 4096.0)
     wh = _rand((1, c, 1, 1), 16, 0.2).requires_grad_(True)
     bh = torch.zeros(1, requires_grad=True)
