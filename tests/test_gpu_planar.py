@@ -357,6 +357,19 @@ def test_conv3x3_pl_q4_variants_and_repeatability():
         out = ops.conv3x3_pl(planar_encode(x).to(DEV), None, ops.pack_conv3x3_f4(wgt.to(DEV)), b.to(DEV), 64, head_w=hw_.to(DEV), head_b=hb.to(DEV), want_y=False, x_residual=2)
         torch.cuda.synchronize()
         assert float((out.cpu() - ref).abs().max()) < 2e-5, (hc, float((out.cpu() - ref).abs().max()))
+        # the head together with the stored activations: the same bits as each alone
+        wp4 = ops.pack_conv3x3_f4(wgt.to(DEV))
+        out_y = ops.conv3x3_pl(planar_encode(x).to(DEV), None, wp4, b.to(DEV), 64, head_w=hw_.to(DEV), head_b=hb.to(DEV), want_y=True, x_residual=2)
+        y_alone = ops.conv3x3_pl(planar_encode(x).to(DEV), None, wp4, b.to(DEV), 64, x_residual=2)
+        assert torch.equal(out_y[0], out) and torch.equal(out_y[1].view(torch.int32), y_alone.view(torch.int32))
+    # pooled output alone (no full-resolution store: the split last step passes an empty buffer for it) = the pooled output of the full call, ragged tile edges
+    n, h, w, cin = 3, 40, 72, 64
+    xe = planar_encode(torch.relu(torch.randn((n, cin, h, w), generator=g))).to(DEV)
+    wp4 = ops.pack_conv3x3_f4((torch.randn((64, cin, 3, 3), generator=g) * (2.0 / (9 * cin)) ** 0.5).to(DEV))
+    bz = (torch.randn(64, generator=g) * 0.1).to(DEV)
+    y_full, yp_full = ops.conv3x3_pl(xe, None, wp4, bz, 64, pool=True, x_residual=2)
+    y_none, yp_only = ops.conv3x3_pl(xe, None, wp4, bz, 64, pool=True, want_y=False, x_residual=2)
+    assert y_none is None and torch.equal(yp_only.view(torch.int32), yp_full.view(torch.int32))
     # small grid: 2 x (32 x 32) x 128 channels = 16 tiles -> half-block work items (kernel variant MSPLIT); and no ReLU
     n, h, w, cin, cout = 2, 32, 32, 128, 128
     x = planar_decode(planar_encode(torch.randn((n, cin, h, w), generator=g)))
