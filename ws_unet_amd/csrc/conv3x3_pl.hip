@@ -143,7 +143,7 @@ template <int LW> struct LoaderGeo {
     static constexpr int plane(int k) { return slot(k) / IN_SEG; }
     static constexpr int seg(int k) { return slot(k) % IN_SEG; }
 };
-constexpr unsigned OOB = 0xFFFFFFF0u;                              // beyond any descriptor (num_records = 48 * h * w < 2^32 - 16): reads as zeros
+constexpr unsigned OOB = 0xFFFFFFF0u;                              // beyond any descriptor (num_records = 48 * h * w < 2^32 - 16): reads as zeros, a store is dropped
 
 // per-lane byte offsets (inside one (image, chunk)'s 3 planes) of this wave's input slots for tile t
 template <int LW, bool GRAD>
@@ -987,8 +987,8 @@ _Pragma("unroll")
                             // no branch (a branch ends the basic block the matrix instructions are scheduled in): a lane that must not store passes
                             // an offset beyond the buffer's extent, which the hardware drops
                             const auto rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, have ? (int)(3u * plane_bytes) : 0, 0x00020000);      // (have: wave-uniform)
-                            const uint32_t o1 = ok ? off + (hh ? plane_bytes : 0u) : 0x80000000u;
-                            const uint32_t o2 = (ok && !hh) ? off + 2u * plane_bytes : 0x80000000u;
+                            const uint32_t o1 = ok ? off + (hh ? plane_bytes : 0u) : OOB;
+                            const uint32_t o2 = (ok && !hh) ? off + 2u * plane_bytes : OOB;
                             __builtin_amdgcn_raw_buffer_store_b128(mk_u4(xh0, xh1, yh0, yh1), rs, (int)o1, 0, 0);
                             __builtin_amdgcn_raw_buffer_store_b128(mk_u4(xlo, xlp, ylo, ylp), rs, (int)o2, 0, 0);
                         } else
