@@ -184,7 +184,7 @@ def test_unet_intermediates_golden(golden, mode):
     np.testing.assert_allclose(keep["logit"].cpu().numpy()[:, ::8], g["inter_logit_sub"], atol=50 * OUT_ATOL[mode], rtol=0)
 
 
-@pytest.mark.parametrize("mode", ["f32", "bf16x3", "f16f8"])
+@pytest.mark.parametrize("mode", ["f32", "bf16x3", "f16f8", "f16f8p", "f16f4p"])      # incl. the planar modes (f16f4p = the default): partial tiles in both directions
 def test_unet_default_variant_and_ragged_shape(golden, mode):
     g = golden["unet_fwd_small"]
     _, x = images01(2, 32, 32, seed=1)
