@@ -39,6 +39,10 @@ def load() -> ctypes.CDLL:
 
 
 def default_threads() -> int:
+    """Decode threads of a batch read: WSU_IO_THREADS, else the cores this process may run on, at most 16."""
+    env = os.environ.get("WSU_IO_THREADS")
+    if env:
+        return max(1, int(env))
     try:
         n = len(os.sched_getaffinity(0))
     except AttributeError:                                    # pragma: no cover
