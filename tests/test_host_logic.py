@@ -74,6 +74,12 @@ def test_fabrika_iterators_and_errors(tmp_path):
     batched = fabrika.precovers(iterator="batched", convert_to="pandas", batch_size=4)(
         lambda fnames, kws: [{**kw, "fname": str(f)} for f, kw in zip(fnames, kws)])
     pd.testing.assert_frame_equal(batched(tmp_path), cover_it(tmp_path))
+    # the batched iterator builds its rows from records per chunk: the same native Python objects the per-row path passes to fn
+    seen = {}
+    fabrika.precovers(iterator="python")(lambda f, **kw: seen.setdefault("py", []).append((type(f), {k: type(v) for k, v in kw.items()})))(tmp_path)
+    fabrika.precovers(iterator="batched", batch_size=4)(
+        lambda fnames, kws: [seen.setdefault("b", []).append((type(f), {k: type(v) for k, v in kw.items()})) for f, kw in zip(fnames, kws)])(tmp_path)
+    assert seen["b"] == seen["py"]
     as_np = fabrika.precovers(iterator="python", convert_to="numpy")(lambda f, **kw: kw["height"])
     assert as_np(tmp_path).tolist() == [512] * 6 + [256]
     whole = fabrika.precovers(iterator=None, convert_to=None)(lambda df, **kw: list(df["name"]))
