@@ -145,9 +145,9 @@ int wsu_conv3x3_wino_fwd(const void* x1, const void* x2, const void* w_packed, c
  *      reference lines as wsu_conv3x3_fwd / wsu_conv3x3_head_fwd (unet.py:141-189). */
 /*      x_residual = 2 (round 3): both cross terms in ONE block-scaled fp4 (e2m1) MFMA per tap pair -- w*x ~ f16(w)*f16(x) + 2^(Ew+Ex-11) [fp4(rw 2^11/2^Ew)
  *      fp4(f16 x/2^Ex) + fp4(f16 w/2^Ew) fp4(rx 2^11/2^Ex)], rw / rx the residuals, 2^Ew / 2^Ex E8M0 block scales per (output channel, tap, 16 input
- *      channels) / per (pixel, 16 channels) chosen so that the block's largest f16 part maps into [2, 4): 14 instead of 19 matrix units per chunk.  The
+ *      channels) / per (pixel, 16 channels) = the smallest power of two that does not saturate fp4 (the block's largest f16 part maps into [2, 3) or [4, 6]): 14 instead of 19 matrix units per chunk.  The
  *      activations' stored format does not change (the loader waves derive the fp4 granule and scale byte of a pixel from its three stored granules);
- *      the weights come from wsu_conv3x3_pack_f4 (wsu_conv3x3_packed_f4_bytes).  MAE of the unet_2 output ~2.5e-5 instead of 4e-6. */
+ *      the weights come from wsu_conv3x3_pack_f4 (wsu_conv3x3_packed_f4_bytes).  MAE of the unet_2 output ~2.1e-5 instead of 4e-6. */
 size_t wsu_conv3x3_packed_f4_bytes(int cin, int cout);
 int wsu_conv3x3_pack_f4(const float* w_oihw, void* w_packed, int cin, int cout, void* stream);
 int wsu_conv3x3_pl_fwd(const void* x1, const void* x2, const void* w_packed, const float* bias, void* y, void* y_pool,

@@ -287,9 +287,11 @@ def _q4_blocks(hpart, res2048, dim):
     blk = shp[:dim] + [shp[dim] // 16, 16] + shp[dim + 1:]
     hv, rv = hpart.reshape(blk), res2048.reshape(blk)
     amax = hv.abs().amax(dim=dim + 1, keepdim=True)
-    # E = exponent field of the largest |f16| - 15 - 1 (zero / subnormal blocks: field 0)
+    # E = exponent field of the largest |f16| - 15 - 1 (zero / subnormal blocks: field 0), one less when that element's mantissa is <= 1.5
+    # (wsu_q4_block_exp: largest / 2^E in [2, 3) or [4, 6])
     ef = torch.where(amax >= 2.0 ** -14, torch.floor(torch.log2(amax.clamp_min(1e-30))) + 15, torch.zeros_like(amax))
-    sc = torch.exp2(ef - 16)
+    finer = (ef > 0) & (amax <= 1.5 * torch.exp2(ef - 15))
+    sc = torch.exp2(ef - 16 - finer.to(ef.dtype))
     return (_fp4(hv / sc) * sc).reshape(shp), (_fp4(rv / sc) * sc / 2048.0).reshape(shp)
 
 

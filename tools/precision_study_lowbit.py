@@ -45,7 +45,10 @@ HW_RULE = False          # True: the scale rule a loader can afford -- 2^(floor(
 def block_scale(amax, fmt):
     """E8M0 scale 2^E with amax / 2^E <= the format's largest value (no saturation), as large a use of the range as a power of two allows"""
     if HW_RULE:
-        return torch.exp2(torch.floor(torch.log2(amax.clamp_min(2.0 ** -14))) - 1)
+        e = torch.floor(torch.log2(amax.clamp_min(2.0 ** -14)))
+        if HW_RULE == 2:     # one compare more: a block whose largest f16 has a mantissa <= 1.5 takes the next smaller scale (amax / scale in [4, 6] instead of [2, 3])
+            return torch.exp2(e - 1 - (amax <= 1.5 * torch.exp2(e)).to(amax.dtype))
+        return torch.exp2(e - 1)
     vmax = FORMATS[fmt][2]
     return torch.exp2(torch.ceil(torch.log2(amax.clamp_min(1e-30) / vmax)))
 
@@ -145,12 +148,12 @@ def main():
         ref = forward(x.double(), {k: v.double() for k, v in sd.items()}, None).float()
         print(f"unet_2 'he' weights, {batch} x {size} x {size}: output mean {ref.mean():.4f} std {ref.std():.4f}")
         global HW_RULE
-        for fmt, hw in (("e4m3", False), ("e2m3", False), ("e3m2", False), ("e2m1", False), ("e2m1", True), ("e2m3", True)):
+        for fmt, hw in (("e4m3", False), ("e2m3", False), ("e3m2", False), ("e2m1", False), ("e2m1", True), ("e2m1", 2), ("e2m3", True)):
             t0 = time.time()
             HW_RULE = hw
             y = forward(x, sd, fmt)
             d = (y - ref).abs()
-            what = " (fixed scales, today)" if fmt == "e4m3" else " (block scales, exponent-field rule, stored residuals)" if hw else " (block scales)"
+            what = " (fixed scales, today)" if fmt == "e4m3" else " (block scales, exponent-field rule + mantissa test, stored residuals)" if hw == 2 else " (block scales, exponent-field rule, stored residuals)" if hw else " (block scales)"
             print(f"  cross terms in {fmt:5s}{what}: MAE {d.mean().item():.3e}  max {d.max().item():.3e}   [{time.time() - t0:.0f} s]", flush=True)
 
 

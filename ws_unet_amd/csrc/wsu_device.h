@@ -191,13 +191,19 @@ __device__ __forceinline__ u32x2 wsu_f16x8_to_fp8(const u32x4& h) {
     return mk_u2(__builtin_bit_cast(uint32_t, lo), __builtin_bit_cast(uint32_t, hi));
 }
 // ---- block-scaled fp4 (e2m1) cross terms ("Q4", round 3; semantics probed on the device: tools/fp4_probe.hip) -------------------------------------
-// A block = the 16 channels of one (pixel, chunk) resp. one (output channel, tap, chunk); its E8M0 scale is 2^E with E = (exponent of the block's
-// largest |f16 part|) - 1, so that value / 2^E lies in [2, 4) for the largest element (no saturation: fp4 reaches 6); both halves of a block
+// A block = the 16 channels of one (pixel, chunk) resp. one (output channel, tap, chunk); its E8M0 scale is 2^E, the smallest power of two
+// with (largest |f16 part|) / 2^E <= 6 = fp4's largest value (wsu_q4_block_exp: the largest element lands in [2, 3) or [4, 6]); both halves of a block
 // share it -- the copy c = f16 part and the residual pre-scaled by 2^11 (|residual| <= 2^-11 |value|).  v_cvt_scalef32_pk_fp4_f16 / _f32
 // return fp4(x / scale), round to nearest even, saturating, low nibble first; the MFMA multiplies a lane's 32 nibbles by 2^(scale byte - 127).
 typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
 typedef __attribute__((ext_vector_type(2))) unsigned short u16x2_t;
-__device__ __forceinline__ int wsu_q4_block_exp(uint32_t max_abs_f16_bits) { return (int)(max_abs_f16_bits >> 10) - 16; }     // exponent field - 15 - 1
+// block exponent E of a block whose largest |f16| has the bit pattern b: exponent field - 15 - 1 (largest / 2^E in [2, 4)), and one binade finer when
+// that element's mantissa is <= 1.5 (largest / 2^E in [4, 6], 6 = fp4's largest value): the smallest power-of-two scale that does not saturate --
+// every other element of the block gets a grid twice as fine in ~half of the blocks (MAE of the whole net 2.54e-5 -> 2.08e-5, profiles/r03/f16f4p.md)
+__device__ __forceinline__ int wsu_q4_block_exp(uint32_t b) {
+    const int ef = (int)(b >> 10);
+    return ef - 16 - ((ef > 0 && (b & 0x3FFu) <= 0x200u) ? 1 : 0);
+}
 __device__ __forceinline__ float wsu_pow2f(int e) { return __builtin_bit_cast(float, (uint32_t)(e + 127) << 23); }
 // largest |f16| bit pattern of the 16 values of two granules
 __device__ __forceinline__ uint32_t wsu_f16x16_max_abs_bits(const u32x4& h0, const u32x4& h1) {
