@@ -18,7 +18,7 @@ Precision modes (``mode=`` or env ``WSU_MODE``):
                                                    pure LDS-DMA and one persistent workgroup per CU pipelines it across chunks and tiles
                                                    (csrc/conv3x3_pl.hip, planar.hip); same values as 'f16f8' up to the accumulation order
   'f16f4p'  (DEFAULT since round 3) 'f16f8p' storage; the 3x3 convs multiply both cross terms as ONE block-scaled fp4 (e2m1) operand pair per tap
-            pair (14 instead of 19 matrix units per chunk; include/wsu.h x_residual = 2): MAE 2.5e-5 (the gate is 1e-4) instead of 4e-6, 14 % more
+            pair (14 instead of 19 matrix units per chunk; include/wsu.h x_residual = 2): MAE 2.1e-5 (the gate is 1e-4) instead of 4e-6, 14 % more
             images/s; training forwards and the transposed convs keep the e4m3 arithmetic (profiles/r03/f16f4p.md)
   'f16f8q'  'f16f8p' with ONE cross term (the weights' residual) on the first conv of every decoder block: MAE ~4e-5 instead of 4e-6
   'f16f8'   f16 products + fp8 cross terms      -- f16(w)*f16(x) exactly, the two residual cross terms on the block-scaled fp8
