@@ -227,7 +227,7 @@ def test_mae_gate_512_batch():
     assert maes["bf16x3"] <= 1e-4                               # the north-star tolerance
     assert maes["f16f8"] <= 2e-5                                # measured 4e-6, 25x inside the gate
     assert maes["f16f8p"] <= 2e-5                               # planar storage, the e4m3 cross terms: measured 4e-6
-    assert maes["f16f4p"] <= 5e-5                               # the DEFAULT mode (planar storage, block-scaled fp4 cross terms): measured 2.5e-5; gate 1e-4
+    assert maes["f16f4p"] <= 5e-5                               # the DEFAULT mode (planar storage, block-scaled fp4 cross terms): measured 2.1e-5; gate 1e-4
     assert maes["bf16"] <= 1e-2
 
 
