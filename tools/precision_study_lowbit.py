@@ -94,6 +94,9 @@ def split_w(w, fmt):
     return h, cq.view(co, -1, kh, kw)[:, :ci], (rq / 2048.0).view(co, -1, kh, kw)[:, :ci]
 
 
+LAYER_FMT = {}           # per-layer override of the cross-term format (sensitivity study: `--per-layer`)
+
+
 def forward(x, sd, fmt):
     def stored(t):                      # what the planar format keeps of an activation: f16 + e4m3 residual
         if fmt is None:
@@ -107,8 +110,9 @@ def forward(x, sd, fmt):
         if fmt is None or n == "e11":
             y = F.conv2d(vp, w, b)
         else:
-            xh, xc, xr = split_x(vp, fmt)
-            wh, wc, wr = split_w(w, fmt)
+            f = LAYER_FMT.get(n, fmt)
+            xh, xc, xr = split_x(vp, f)
+            wh, wc, wr = split_w(w, f)
             y = F.conv2d(xh, wh, b) + F.conv2d(xc, wr) + F.conv2d(xr, wc)
         return stored(F.relu(y))
 
@@ -131,15 +135,17 @@ def forward(x, sd, fmt):
     if fmt is None:
         y = F.conv2d(vp, w, b)
     else:
-        xh, xc, xr = split_x(vp, fmt)
-        wh, wc, wr = split_w(w, fmt)
+        f = LAYER_FMT.get("d42", fmt)
+        xh, xc, xr = split_x(vp, f)
+        wh, wc, wr = split_w(w, f)
         y = F.conv2d(xh, wh, b) + F.conv2d(xc, wr) + F.conv2d(xr, wc)
     return torch.sigmoid(F.conv2d(F.relu(y), sd["outconv.weight"], sd["outconv.bias"]))     # the head reads the fp32 accumulators
 
 
 def main():
-    batch = int(sys.argv[1]) if len(sys.argv) > 1 else 2
-    size = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+    pos = [a for a in sys.argv[1:] if not a.startswith("--")]
+    batch = int(pos[0]) if len(pos) > 0 else 2
+    size = int(pos[1]) if len(pos) > 1 else 256
     torch.set_num_threads(8)
     sd = {k: torch.from_numpy(v) for k, v in formula.formula_state_dict(2, "he").items()}
     u8 = formula.synthetic_images(batch, size, size, seed=1000)
@@ -155,6 +161,16 @@ def main():
             d = (y - ref).abs()
             what = " (fixed scales, today)" if fmt == "e4m3" else " (block scales, exponent-field rule + mantissa test, stored residuals)" if hw == 2 else " (block scales, exponent-field rule, stored residuals)" if hw else " (block scales)"
             print(f"  cross terms in {fmt:5s}{what}: MAE {d.mean().item():.3e}  max {d.max().item():.3e}   [{time.time() - t0:.0f} s]", flush=True)
+        if "--per-layer" in sys.argv:       # the product's fp4 arithmetic with ONE layer (or only one layer) kept in e4m3: where the 2.1e-5 comes from
+            HW_RULE = 2
+            layers = ["e12", "e21", "e22", "e31", "e32", "d31", "d32", "d41", "d42"]
+            for only in (False, True):
+                for L in layers:
+                    LAYER_FMT.clear()
+                    LAYER_FMT.update({k: "e4m3" for k in layers if k != L} if only else {L: "e4m3"})
+                    d = (forward(x, sd, "e2m1") - ref).abs()
+                    print(f"  fp4 {'ONLY in' if only else 'everywhere but'} {L}: MAE {d.mean().item():.3e}", flush=True)
+            LAYER_FMT.clear()
 
 
 if __name__ == "__main__":
