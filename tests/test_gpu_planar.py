@@ -417,7 +417,8 @@ def test_conv3x3_pl_q4_random_shapes():
     from ws_unet_amd import ops
     rng = np.random.default_rng(20261004)
     g = torch.Generator().manual_seed(5)
-    for _ in range(12):
+    import os
+    for _ in range(int(os.environ.get("WSU_TEST_SWEEP", "12"))):       # (WSU_TEST_SWEEP=300: the one-off sweep recorded in profiles/r03/f16f4p.md)
         n = int(rng.integers(1, 4)); h = int(rng.integers(2, 70)); w = int(rng.integers(2, 90))
         c1 = 16 * int(rng.integers(1, 7)); c2 = 16 * int(rng.integers(0, 4)); cout = 64 * int(rng.integers(1, 4))
         pool = bool(rng.integers(0, 2)) and h % 2 == 0 and w % 2 == 0
