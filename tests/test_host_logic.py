@@ -187,6 +187,27 @@ def test_native_png_reader_matches_pil(tmp_path):
     assert read_luma_batch([]).shape[0] == 0
 
 
+@pytest.mark.parametrize("depth", [None, 3])
+def test_python_iterator_announces_the_next_file(tmp_path, depth):
+    """iterator='python': a fn with a `lookahead` attribute is told row i + 1's file before it runs on row i (the per-image evaluate API decodes
+    it on a helper thread meanwhile); rows, order and results are those of the plain loop."""
+    make_syn(tmp_path)
+    log = []
+
+    def fn(fname, **kw):
+        log.append(("run", Path(fname).name))
+        return {**kw, "fname": str(fname)}
+    fn.lookahead = lambda f: log.append(("ahead", Path(f).name))
+    if depth:
+        fn.lookahead_depth = depth                                             # rows i + 1 .. i + depth are announced before row i runs
+    df = fabrika.precovers(iterator="python", convert_to="pandas", ignore_missing=False)(fn)(tmp_path)
+    pd.testing.assert_frame_equal(df, cover_it(tmp_path))
+    runs = [n for k, n in log if k == "run"]
+    assert [n for k, n in log if k == "ahead"] == runs[1:]                       # every file but the first, in order
+    for i, name in enumerate(runs[1:]):
+        assert log.index(("ahead", name)) < log.index(("run", runs[max(0, i + 1 - (depth or 1))]))   # announced before the row `depth` in front of it runs
+
+
 def test_batched_iterator_prefetch_runs_one_chunk_ahead(tmp_path):
     (tmp_path / "images").mkdir()
     names = [f"images/{i}.png" for i in range(7)]

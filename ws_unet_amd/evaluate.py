@@ -132,15 +132,15 @@ def predict_unet(
         # pinned buffer) instead of PIL -- the same plane `imread4_f32(fname)[..., 3]` holds (tests/test_host_logic.py), 2.5x less host
         # time per image; files it does not support fall back to PIL inside read_luma_batch
         from .imread import png_shape
-        if png_shape(str(fname)) == (512, 512):
-            planes = load_planes_u8([fname])
-            if planes is not None:
-                x_u8 = planes.to(_model_device(model), non_blocking=True)
-                mark_uploaded(planes)
+        ahead = _AHEAD["pending"].pop(str(fname), None)      # decoded one row ahead by the iterator's lookahead (predict_unet_cover / _stego)
+        planes = ahead.result() if ahead is not None else (load_planes_u8([fname]) if png_shape(str(fname)) == (512, 512) else None)
+        if planes is not None:
+            x_u8 = planes.to(_model_device(model), non_blocking=True)
+            mark_uploaded(planes)
+            beta, l1 = predict_u8_batch(x_u8, model)
+            if range_fallback(model):
                 beta, l1 = predict_u8_batch(x_u8, model)
-                if range_fallback(model):
-                    beta, l1 = predict_u8_batch(x_u8, model)
-                return {**kw, "beta_hat": np.float32(beta[0].item()), "l1": np.float32(l1[0].item())}
+            return {**kw, "beta_hat": np.float32(beta[0].item()), "l1": np.float32(l1[0].item())}
     x = imread(fname)[..., 3:]
     if isinstance(model, torch.nn.Module) and hasattr(model, "forward_features") and x.shape[:2] == (512, 512):
         xi = np.ascontiguousarray(x[..., 0])
@@ -158,14 +158,40 @@ def predict_unet(
     return {**kw, "beta_hat": beta_hat, "l1": l1_hat}
 
 
-@fabrika.precovers(iterator="python", convert_to="pandas", ignore_missing=False, n_jobs=-1)
-def predict_unet_cover(*args, **kw):
+# ---- files ahead for the per-image API: while predict_unet works on row i (upload, forward, two scalars back: ~0.7 ms), helper threads decode
+# the files of rows i + 1 .. i + 3 into the pinned ring -- one decode (~2.2 ms) is longer than everything else of a row (reference: serial,
+# evaluate.py:142-149)
+_AHEAD_DEPTH = 3
+_AHEAD = {"pool": None, "pending": {}}
+
+
+def _decode_ahead(path: str):
+    from .imread import png_shape
+    return load_planes_u8([path]) if png_shape(path) == (512, 512) else None
+
+
+def _lookahead(fname) -> None:
+    if _AHEAD["pool"] is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _AHEAD["pool"] = ThreadPoolExecutor(max_workers=_AHEAD_DEPTH)
+    pend = _AHEAD["pending"]
+    while len(pend) > _AHEAD_DEPTH:                          # rows that were announced and never asked for
+        pend.pop(next(iter(pend))).cancel()
+    pend[str(fname)] = _AHEAD["pool"].submit(_decode_ahead, str(fname))
+
+
+def _predict_unet_cover(*args, **kw):
     return predict_unet(*args, **kw)
 
 
-@fabrika.stego_spatial(iterator="python", convert_to="pandas", ignore_missing=False, n_jobs=-1)
-def predict_unet_stego(*args, **kw):
+def _predict_unet_stego(*args, **kw):
     return predict_unet(*args, **kw)
+
+
+_predict_unet_cover.lookahead = _predict_unet_stego.lookahead = _lookahead
+_predict_unet_cover.lookahead_depth = _predict_unet_stego.lookahead_depth = _AHEAD_DEPTH
+predict_unet_cover = fabrika.precovers(iterator="python", convert_to="pandas", ignore_missing=False, n_jobs=-1)(_predict_unet_cover)
+predict_unet_stego = fabrika.stego_spatial(iterator="python", convert_to="pandas", ignore_missing=False, n_jobs=-1)(_predict_unet_stego)
 
 
 # ---- batched device path ------------------------------------------------------------------------------
@@ -197,6 +223,8 @@ def predict_u8_batch(x_u8: torch.Tensor, model: torch.nn.Module):
 
 
 _PINNED = {}
+_NBUF = 6
+_PINNED_LOCK = __import__("threading").Lock()
 
 
 def load_planes_u8(fnames, imread: typing.Callable = imread4_u8) -> typing.Optional[torch.Tensor]:
@@ -208,15 +236,16 @@ def load_planes_u8(fnames, imread: typing.Callable = imread4_u8) -> typing.Optio
         from .imread import png_shape, read_luma_batch
         hw = png_shape(fnames[0]) or imread4_u8(fnames[0]).shape[:2]
         key = (len(fnames), hw[0], hw[1])
-        if key not in _PINNED:
-            if len(_PINNED) > 8:
-                _PINNED.clear()
-            pin = torch.cuda.is_available()
-            _PINNED[key] = {"bufs": [torch.empty(key, dtype=torch.uint8, pin_memory=pin) for _ in range(3)], "next": 0,
-                            "uploaded": [None, None, None]}
-        slot = _PINNED[key]
-        i = slot["next"]                                     # three buffers: chunk k+1 is decoded while chunk k is uploaded and chunk
-        slot["next"] = (i + 1) % 3                           # k-1 may still wait in the stream (submit / collect pipelining)
+        with _PINNED_LOCK:                                    # (the per-image lookahead decodes on a helper thread beside the caller's own reads)
+            if key not in _PINNED:
+                if len(_PINNED) > 8:
+                    _PINNED.clear()
+                pin = torch.cuda.is_available()
+                _PINNED[key] = {"bufs": [torch.empty(key, dtype=torch.uint8, pin_memory=pin) for _ in range(_NBUF)], "next": 0,
+                                "uploaded": [None] * _NBUF}
+            slot = _PINNED[key]
+            i = slot["next"]                                 # a ring: chunk k+1 is decoded while chunk k is uploaded and chunk k-1 may still wait
+            slot["next"] = (i + 1) % _NBUF                   # in the stream (submit / collect pipelining); the per-image API decodes three rows ahead
         if slot["uploaded"][i] is not None:                  # the upload that last read this buffer (mark_uploaded)
             slot["uploaded"][i].synchronize()
             slot["uploaded"][i] = None
