@@ -17,7 +17,7 @@ from ws_unet_amd.ws import estimate  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=32)
 ap.add_argument("--steps", type=int, default=10)
-ap.add_argument("--mode", default="f16f8p")
+ap.add_argument("--mode", default=None, help="precision mode of the predictor (default: the package default, f16f4p)")
 ap.add_argument("--correct-bias", action="store_true")
 a = ap.parse_args()
 dev = "cuda"
@@ -47,6 +47,6 @@ y = torch.rand(a.batch, 512, 512, device=dev)
 t_stat = timed(lambda: ops.ws_attack(x, y, mean_filter=AVG, weighted=1), 50)
 npx = a.batch * 512 * 512
 print(json.dumps({"metric": "WS attack images/s (UNet predictor + weighted statistic)", "value": a.batch / t_unet,
-                  "ms_per_batch": t_unet * 1e3, "batch": a.batch, "mode": a.mode, "correct_bias": a.correct_bias,
+                  "ms_per_batch": t_unet * 1e3, "batch": a.batch, "mode": m.mode, "correct_bias": a.correct_bias,
                   "filter_KB_images_per_s": a.batch / t_kb, "stat_call_us": t_stat * 1e6,
                   "stat_GBps_algorithmic": npx * 5 / t_stat / 1e9}))

@@ -11,6 +11,6 @@ cp $G/pmc_fetch/bench_counter_collection.csv $P/pmc_bench_FETCH_SIZE.csv; cp $G/
 cp $G/pmc_conv3x3_traffic.json $P/; cp $S/sq_counters.json $P/; cp $S/summary.md $P/sq_counters_final.md
 cp $G/kt_train/train_kernel_stats.csv $P/train_b64_kernel_stats.csv; cp $G/train_step_launches.log $P/train_step_launches.log
 grep -h "^{" $G/evaluate_loop.log | tail -1 > /tmp/ev.json && [ -s /tmp/ev.json ] && (grep -v "^{" $P/evaluate_loop.json.log | head -1; cat /tmp/ev.json) > /tmp/ev2 && cp /tmp/ev2 $P/evaluate_loop.json.log
-grep -h "^{" $G/ws_attack.log | tail -1 > /tmp/wa.json && [ -s /tmp/wa.json ] && cp /tmp/wa.json $P/ws_attack_bench.json.log
+grep -h "^{" $G/ws_attack.log > /tmp/wa.json && [ -s /tmp/wa.json ] && cp /tmp/wa.json $P/ws_attack_bench.json.log
 python tools/per_layer_table.py $P/bench_n1.json.log > $P/per_layer.md
 grep blob $P/pmc_conv3x3_traffic.json; git hash-object ws_unet_amd/csrc/conv3x3_pl.hip
