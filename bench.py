@@ -215,7 +215,7 @@ def git_blob_sha1(path: Path) -> str:
     return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
 
 
-def pmc_traffic(args, algorithmic_bytes_per_launch):
+def pmc_traffic(args, algorithmic_bytes_per_launch, kernel=None):
     """HBM bytes per conv3x3 launch from the PMC counters.  They cannot be read from inside this process (rocprofv3 has to
     wrap it), so the number comes from the committed summary of two `rocprofv3 --pmc` passes of THIS command (FETCH_SIZE and
     WRITE_SIZE separately, FETCH_SIZE doubled on gfx950; tools/pmc_traffic.py), and only when workload, mode AND the git blob
@@ -234,6 +234,9 @@ def pmc_traffic(args, algorithmic_bytes_per_launch):
     if pmc.get("mode", "bf16x3") != args.mode:
         out["traffic_note"] = f"summary is for mode {pmc.get('mode')}"
         return out
+    if kernel is not None and not str(pmc.get("kernel", "")).startswith(kernel):
+        out["traffic_note"] = f"summary is for kernel {pmc.get('kernel')} (this mode runs {kernel}; re-run tools/profile_round.sh)"
+        return out
     if pmc.get("kernel_source_blob") != here:
         out["traffic_note"] = (f"stale: counters were collected on {src.name} blob {pmc.get('kernel_source_blob')}, "
                                f"this tree has {here} (re-run tools/profile_round.sh)")
@@ -243,7 +246,7 @@ def pmc_traffic(args, algorithmic_bytes_per_launch):
     return out
 
 
-def sq_counters(args):
+def sq_counters(args, ckey="conv3x3_pl"):
     """Matrix-pipe busy fraction of the dominant kernel from the SQ counters (SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES; rocprofv3 has to wrap
     the process, so the number comes from the committed summary of tools/profile_sq.sh -> tools/pmc_sq.py --json, and only when the git blob
     of the kernel source it was collected on equals this tree's -- like `traffic`)."""
@@ -254,12 +257,12 @@ def sq_counters(args):
         return None
     with open(cands[-1]) as f:
         sq = json.load(f)
-    src = ROOT / "ws_unet_amd" / "csrc" / "conv3x3_pl.hip"
+    src = ROOT / "ws_unet_amd" / "csrc" / (ckey + ".hip")
     out = {"source": str(cands[-1].relative_to(ROOT))}
-    if sq.get("meta", {}).get("kernel_source_blobs", {}).get("conv3x3_pl.hip") != git_blob_sha1(src):
-        out["note"] = "stale: the counters were collected on another revision of conv3x3_pl.hip (re-run tools/profile_sq.sh)"
+    if sq.get("meta", {}).get("kernel_source_blobs", {}).get(ckey + ".hip") != git_blob_sha1(src):
+        out["note"] = f"stale: the counters were collected on another revision of {ckey}.hip (re-run tools/profile_sq.sh)"
         return out
-    k = sq["kernels"].get("conv3x3_pl_kernel", {}).get("fwd1")
+    k = sq["kernels"].get(ckey + "_kernel", {}).get("fwd1")
     if k:
         out.update({"mfma_busy": k.get("mfma_busy"), "mfma_busy_time_based": k.get("mfma_busy_t"), "clock_GHz_profiled": k.get("clock_GHz"),
                     "wave_wait_any_share": k.get("sq_wait_any_share"), "wave_wait_inst_share": k.get("sq_wait_inst_any_share"),
@@ -457,10 +460,11 @@ def main():
     result = None
     if rank == 0:
         ks = timer.summary()
-        conv = ks["conv3x3_pl"] if "conv3x3_pl" in ks else ks["conv3x3"]
+        ckey = next(k for k in ("conv3x3_q", "conv3x3_pl", "conv3x3") if k in ks)     # the 3x3 conv kernel of this mode ('f16f4p': csrc/conv3x3_q.hip)
+        conv = ks[ckey]
         achieved = conv["flops"] / (conv["total_ms"] * 1e-3)
         roofline = {
-            "bound": "mfma", "kernel": "conv3x3_pl_kernel" if "conv3x3_pl" in ks else "conv3x3_kernel", "achieved": achieved / 1e12, "peak": PEAK[args.mode] / 1e12,
+            "bound": "mfma", "kernel": ckey + "_kernel", "achieved": achieved / 1e12, "peak": PEAK[args.mode] / 1e12,
             "unit": "TFLOP/s", "frac": achieved / PEAK[args.mode], "traffic": None,
             "avg_launch_ms": conv["avg_ms"], "launches": conv["launches"],
             "algorithmic_gflop_per_launch": conv["flops"] / conv["launches"] / 1e9,
@@ -476,8 +480,8 @@ def main():
             roofline["mfma_issue"] = {"units_per_product": units, "tflops_equivalent": achieved * units / 1e12,
                                       "frac_of_peak": achieved * units / PEAK[args.mode],
                                       "note": "matrix-pipe time actually issued (split terms included) against the same dense bf16 peak"}
-        roofline.update(pmc_traffic(args, conv["bytes"] / conv["launches"]))
-        busy = sq_counters(args)
+        roofline.update(pmc_traffic(args, conv["bytes"] / conv["launches"], ckey + "_kernel"))
+        busy = sq_counters(args, ckey)
         if busy is not None and "mfma_issue" in roofline:
             roofline["mfma_busy"] = busy
         roofline["per_layer"] = per_layer_roofline(timer, args.mode)

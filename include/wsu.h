@@ -160,6 +160,25 @@ int wsu_conv3x3_pl_fwd(const void* x1, const void* x2, const void* w_packed, con
  *      wsu_conv3x3_pl_bwd_data) instead of the 2 bytes per element of y's f16 planes.  Rows beyond h / columns beyond w are not written. */
 size_t wsu_relu_mask_bytes(int n, int c, int h, int w);
 
+/* ---- K1q (round 4): the forward conv of the DEFAULT inference mode 'f16f4p' on planar Q tensors ("F16F4P" storage; csrc/conv3x3_q.hip).
+ *      The arithmetic is x_residual = 2's: w*x ~ f16(w)*f16(x) + both residual cross terms as ONE block-scaled fp4 (e2m1) MFMA per tap pair.  What changed is
+ *      WHO makes the fp4 operands: a planar Q tensor stores, per image and 16-channel chunk,
+ *          plane 0 = f16 ch 0-7, plane 1 = f16 ch 8-15, plane 2 = Q   as [H][W][16 B] each, then the scale plane S,
+ *      Q = per pixel 32 fp4 nibbles: nibble i = fp4(f16 part of channel i / 2^E), nibble 16 + i = fp4((x - f16 x) * 2^11 / 2^E) (low nibble first, round to
+ *      nearest even, saturating), 2^E = the smallest power of two with (largest |f16 part| of the 16 channels) / 2^E <= 6; S = one byte E + 127 per pixel in
+ *      16 x 32-pixel tile blocks [ceil(H/16)][ceil(W/32)][16][32] (a conv tile's scale bytes are one 512-byte run; rows / columns beyond the image are
+ *      padding).  A chunk is 48 H W + 512 ceil(H/16) ceil(W/32) bytes (3.06 B per element; wsu_planar_q_bytes).  The PRODUCING epilogue writes all of it
+ *      from its fp32 values (residual nibbles from the exact residual; round 3's loader waves re-rounded a stored e4m3 residual), so the consumer's loader
+ *      waves only issue LDS-DMA.  y_format (this entry point, wsu_convt2x2_pl_fwd, wsu_conv3x3_first_pl_fwd): WSU_PLANAR_Q, or WSU_PLANAR_A = the
+ *      e4m3-residual F16F8P format above (what the transposed conv and every training kernel read).  Weights: wsu_conv3x3_pack_f4.
+ *      Replaces the same reference lines as wsu_conv3x3_pl_fwd (unet.py:141-189). */
+#define WSU_PLANAR_A 0
+#define WSU_PLANAR_Q 1
+size_t wsu_planar_q_bytes(int n, int c, int h, int w);
+int wsu_conv3x3_q_fwd(const void* x1, const void* x2, const void* w_packed_f4, const float* bias, void* y, void* y_pool,
+                      const float* head_w, const float* head_b, float* head_out, float* head_logit, int head_cout,
+                      int n, int h, int w, int c1, int c2, int cout, int relu, int y_format, unsigned* range_flag, void* stream);
+
 /* ---- K1p + K0p fused: e11 -> e12 (-> pool) of the planar path in one launch for single-plane inputs (unet.py:141-144).  The loader waves of
  *      the persistent kernel compute e11's 64 channels from the image straight into the LDS stages (instead of fetching them); bitwise the
  *      result of wsu_conv3x3_first_pl_fwd followed by wsu_conv3x3_pl_fwd, and xe11 never reaches HBM.  img (N,1,H,W) fp32, w1 (64,1,3,3),
@@ -228,11 +247,12 @@ int wsu_conv3x3_first_pl_bwd_weight(const void* g, const float* img, float* dw, 
 /* ---- K3p / K0p: the other two kernels of the planar (F16F8P) inference path (csrc/planar.hip).
  *      wsu_convt2x2_pl_fwd: nn.ConvTranspose2d(k2, s2) + bias (unet.py:125,130,177,183), x: cin channels at (h, w) planar -> y: cout channels at
  *      (2h, 2w) planar; weights from wsu_convt2x2_pack(mode F16F8); cin a multiple of 32, cout of 64.
- *      wsu_conv3x3_first_pl_fwd: the first layer e11 (unet.py:82,141), x_nchw (N, cin <= 8, H, W) fp32 -> y: cout (multiple of 16) channels planar. */
+ *      wsu_conv3x3_first_pl_fwd: the first layer e11 (unet.py:82,141), x_nchw (N, cin <= 8, H, W) fp32 -> y: cout (multiple of 16) channels planar.
+ *      y_format (round 4): WSU_PLANAR_A (the format above) or WSU_PLANAR_Q (K1q; the inputs of the transposed conv stay WSU_PLANAR_A). */
 int wsu_convt2x2_pl_fwd(const void* x, const void* w_packed, const float* bias, void* y, int n, int h, int w, int cin, int cout,
-                        unsigned* range_flag, void* stream);
+                        int y_format, unsigned* range_flag, void* stream);
 int wsu_conv3x3_first_pl_fwd(const float* x_nchw, const float* w_oihw, const float* bias, void* y, int n, int h, int w, int cin, int cout,
-                             int relu, unsigned* range_flag, unsigned char* relu_mask_out, void* stream);
+                             int relu, int y_format, unsigned* range_flag, unsigned char* relu_mask_out, void* stream);
 
 /* ---- first layer: conv3x3 reflect on a few input planes given as NCHW fp32 (the model input).
  *      Replaces e11 (unet.py:82,141).  cin <= 8, cout multiple of 8.  w is plain OIHW fp32. */

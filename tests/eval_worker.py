@@ -1,5 +1,5 @@
 """One rank of tests/test_gpu_dp.py::test_two_rank_sharded_evaluate (a fresh process per rank:
-`python eval_worker.py RANK WORLD PORT DATASET OUT.csv [MODE]`).  Two of these share the box's single GPU over gloo and run the REAL
+`python eval_worker.py RANK WORLD PORT DATASET OUT.csv [MODE [TRIP_RANK]]`).  Two of these share the box's single GPU over gloo and run the REAL
 `evaluate.predict_unet_sharded` (BASELINE.json configs[3]: rows split contiguously over the ranks, results all-gathered, every rank
 returns the full table in fabrika order) in the default mode."""
 import os
@@ -18,9 +18,16 @@ def main():
     from ws_unet_amd import evaluate, parallel
     from gpu_util import gpu_model
     parallel.init_from_env("gloo")
+    trip = int(sys.argv[7]) if len(sys.argv) > 7 else -1
     model = gpu_model(2, "he", mode, drop_rate=0.)
+    if rank == trip:
+        # only THIS rank's shard "overflows": its range flag is set before its first forward, so its model's own first-forward look
+        # switches it to 'bf16x3s' mid-pass while the other rank stays planar -- the end-of-pass collective look must bring everybody along
+        model._range_flag_tensor(torch.device("cuda")).fill_(1)
     cov = evaluate.predict_unet_sharded(dataset, model, batch_size=2)
     st = evaluate.predict_unet_sharded(dataset, model, stego_method="LSBR", batch_size=2)
+    if trip >= 0:
+        assert model.mode == "bf16x3s", model.mode
     cov.to_csv(out + ".cover.csv", index=False)
     st.to_csv(out + ".stego.csv", index=False)
     torch.distributed.barrier()

@@ -113,3 +113,87 @@ def planar_decode(t: torch.Tensor, lo_scale: float = 4096.0, f16_only: bool = Fa
     hi = torch.stack([raw[:, :, 0], raw[:, :, 1]], dim=-2).contiguous().view(torch.float16).reshape(n, nch, h, w, 16).float()
     lo = 0.0 if f16_only else raw[:, :, 2].contiguous().view(torch.float8_e4m3fn).float() / lo_scale
     return (hi + lo).permute(0, 1, 4, 2, 3).reshape(n, nch * 16, h, w).cpu()
+
+
+# ---- planar Q storage ('F16F4P', round 4): test-side restatement of include/wsu.h K1q ---------------------------------------------------------
+_FP4_VALUES = torch.tensor([0.0, 0.5, 1.0, 1.5, 2.0, 3.0, 4.0, 6.0])
+
+
+def fp4_codes(v: torch.Tensor) -> torch.Tensor:
+    """fp32 -> e2m1 codes (uint8, bit 3 = sign, bits 0-2 = index into {0, .5, 1, 1.5, 2, 3, 4, 6}): round to nearest even, saturating
+    (v_cvt_scalef32_pk_fp4_*, tools/fp4_probe.hip)."""
+    a = v.abs().double()
+    e = torch.floor(torch.log2(a.clamp_min(1e-30))).clamp(0, 2)
+    step = torch.exp2(e - 1)
+    q = (torch.round(a / step) * step).clamp_max(6.0)                           # torch.round: half to even = even mantissa on this grid
+    idx = torch.bucketize(q.float(), _FP4_VALUES.to(q.device))                  # exact grid values -> their index
+    return (idx.to(torch.uint8) | ((v < 0) | ((v == 0) & (torch.signbit(v)))).to(torch.uint8) * 8)
+
+
+def fp4_values(codes: torch.Tensor) -> torch.Tensor:
+    mag = _FP4_VALUES.to(codes.device)[(codes & 7).long()]
+    return torch.where((codes & 8) != 0, -mag, mag)
+
+
+def q_block_exp(amax: torch.Tensor) -> torch.Tensor:
+    """E of a block whose largest |f16 part| is amax (wsu_q4_block_exp): exponent field - 16, one less when the largest / 2^E would lie in [2, 3]."""
+    ef = torch.where(amax >= 2.0 ** -14, torch.floor(torch.log2(amax.clamp_min(1e-30))) + 15, torch.zeros_like(amax))
+    finer = (ef > 0) & (amax <= 1.5 * torch.exp2(ef - 15))
+    return ef - 16 - finer.to(ef.dtype)
+
+
+def _q_sblock_index(h, w, device):
+    """index of pixel (y, x)'s scale byte inside a chunk's scale plane: 16 x 32-pixel tile blocks"""
+    yy, xx = torch.meshgrid(torch.arange(h, device=device), torch.arange(w, device=device), indexing="ij")
+    tx = (w + 31) // 32
+    return ((yy // 16) * tx + xx // 32) * 512 + (yy % 16) * 32 + xx % 32
+
+
+def planar_q_parts(x_nchw: torch.Tensor):
+    """fp32 NCHW -> the pieces of its planar Q encoding, per (n, chunk, h, w, 16): f16 parts, hi codes, residual codes; per (n, chunk, h, w): E."""
+    x = x_nchw.float()
+    n, c, h, w = x.shape
+    xc = x.reshape(n, c // 16, 16, h, w).permute(0, 1, 3, 4, 2).contiguous()
+    hi = xc.to(torch.float16)
+    res = xc - hi.float()
+    e = q_block_exp(hi.float().abs().amax(dim=-1))
+    sc = torch.exp2(e)[..., None]
+    return hi, fp4_codes(hi.float() / sc), fp4_codes(res * 2048.0 / sc), e
+
+
+def planar_q_encode(x_nchw: torch.Tensor):
+    """fp32 NCHW (any device) -> ops.PlanarQ on the device, as a producing epilogue writes it."""
+    x = x_nchw.to(DEV).float()
+    n, c, h, w = x.shape
+    hi, ch, cr, e = planar_q_parts(x)
+    hb = hi.view(torch.uint8).reshape(n, c // 16, h, w, 2, 16)
+    codes = torch.cat([ch, cr], dim=-1)                                         # 32 nibbles per (pixel, chunk): hi 0-15, residual 0-15
+    q = (codes[..., 0::2] | (codes[..., 1::2] << 4)).to(torch.uint8)             # low nibble first
+    out = ops.PlanarQ.empty(n, c, h, w, x.device)
+    out.data.zero_()
+    hw = h * w
+    flat = out.data
+    flat[:, :, 0:16 * hw] = hb[..., 0, :].reshape(n, c // 16, -1)
+    flat[:, :, 16 * hw:32 * hw] = hb[..., 1, :].reshape(n, c // 16, -1)
+    flat[:, :, 32 * hw:48 * hw] = q.reshape(n, c // 16, -1)
+    sidx = (48 * hw + _q_sblock_index(h, w, x.device)).reshape(-1)
+    flat[:, :, sidx] = (e + 127).to(torch.uint8).reshape(n, c // 16, -1)
+    return out
+
+
+def planar_q_decode(t, parts: bool = False):
+    """ops.PlanarQ -> fp32 NCHW on the CPU: f16 part + fp4 residual * 2^(E - 11) (the residual carries ~2.5 bits: a Q tensor holds less than the
+    e4m3-residual format -- exactly what the fp4 conv multiplies).  parts=True: also (f16 parts, hi codes, residual codes, E)."""
+    n, c, h, w = t.n, t.c, t.h, t.w
+    nch, hw = c // 16, h * w
+    raw = t.data.detach()
+    h0 = raw[:, :, 0:16 * hw].reshape(n, nch, h, w, 16)
+    h1 = raw[:, :, 16 * hw:32 * hw].reshape(n, nch, h, w, 16)
+    hi = torch.stack([h0, h1], dim=-2).contiguous().view(torch.float16).reshape(n, nch, h, w, 16)
+    q = raw[:, :, 32 * hw:48 * hw].reshape(n, nch, h, w, 16)
+    codes = torch.stack([q & 15, q >> 4], dim=-1).reshape(n, nch, h, w, 32)
+    sidx = (48 * hw + _q_sblock_index(h, w, raw.device)).reshape(-1)
+    e = raw[:, :, sidx].reshape(n, nch, h, w).float() - 127
+    val = hi.float() + fp4_values(codes[..., 16:]) * torch.exp2(e - 11)[..., None]
+    val = val.permute(0, 1, 4, 2, 3).reshape(n, c, h, w).cpu()
+    return (val, hi, codes[..., :16], codes[..., 16:], e) if parts else val

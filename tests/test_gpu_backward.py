@@ -213,8 +213,9 @@ def test_adamw_and_train_step_golden(golden):
         np.testing.assert_allclose(p.detach().cpu().numpy(), q.detach().cpu().numpy(), rtol=0, atol=5e-7, err_msg=k)
 
 
-def test_training_reduces_loss_and_checkpoints(tmp_path):
-    model = gpu_model(1, "default", "f32")
+@pytest.mark.parametrize("mode", ["f32", None])
+def test_training_reduces_loss_and_checkpoints(tmp_path, mode):
+    model = gpu_model(1, "default", mode)                       # None: the default inference mode, trained in its planar arithmetic
     cfg = {"network": "unet_1", "alpha": "0.400", "grayscale": True, "loss": "l1ws", "loss_lambda": 0.25,
            "learning_rate": 0.0001, "drop_rate": 0.0, "demosaic": None, "demosaic_oracle": False, "channel": [0]}
     assert create_run_name({**cfg, "network": "unet_2"}) == "unet_2-alpha_0.400_grayscale_l1ws_0.25_lr_0.0001_"   # published run dir suffix
@@ -304,8 +305,10 @@ def test_pair_loader_feeds_the_trainer_from_png_files(tmp_path):
     assert len(tl) == 3 and tl[-1] < tl[0] and all(np.isfinite(tl))
 
 
-def test_train_driver_replays_a_published_style_config(tmp_path):
-    """ws_unet_amd.train.train(): run directory layout, config.json keys, checkpoints, weight-only resume (detector/train.py:143-304)."""
+@pytest.mark.parametrize("mode", ["f32", None])
+def test_train_driver_replays_a_published_style_config(tmp_path, mode):
+    """ws_unet_amd.train.train(): run directory layout, config.json keys, checkpoints, weight-only resume (detector/train.py:143-304) -- in
+    exact f32 and with `mode` unset: the default inference mode and its planar training arithmetic (what bench.py's train_step leg times)."""
     import json
     from PIL import Image
     from ws_unet_amd import train as train_mod
@@ -326,7 +329,7 @@ def test_train_driver_replays_a_published_style_config(tmp_path):
     (data / "split_va.csv").write_text(split([4, 5]))
     cfg = {"dataset": str(data), "output_dir": str(tmp_path / "runs"), "network": "unet_1", "stego_method": "LSBR", "alpha": "0.400",
            "loss": "l1ws", "batch_size": 4, "num_epochs": 2, "patience": 5, "learning_rate": 1e-3, "drop_rate": 0.0, "seed": 7,
-           "SLURM_JOB_ID": "42", "mode": "f32"}
+           "SLURM_JOB_ID": "42", **({"mode": mode} if mode else {})}
     best = train_mod.train(cfg)
     runs = list((tmp_path / "runs" / "LSBR").iterdir())
     assert len(runs) == 1 and runs[0].name.split("-", 2)[1] == "42"

@@ -144,3 +144,36 @@ def test_two_rank_sharded_evaluate(tmp_path):
         np.testing.assert_allclose(got_s["l1"].to_numpy(float), ref_s["l1"].to_numpy(float), atol=2e-5)
     a, b = pd.read_csv(outs[0] + ".cover.csv"), pd.read_csv(outs[1] + ".cover.csv")
     np.testing.assert_array_equal(a["beta_hat"].to_numpy(), b["beta_hat"].to_numpy())      # every rank holds the same table
+
+
+def test_two_rank_sharded_evaluate_one_rank_overflows(tmp_path):
+    """only rank 0's shard trips the +-448 range flag (its model switches to 'bf16x3s' by its own first-forward look in the
+    middle of the pass).  The end-of-pass decision is collective on EVERY rank whatever its local mode: nobody hangs in a mismatched
+    all-reduce, both ranks finish in 'bf16x3s' and both hold the single-rank 'bf16x3s' table."""
+    import pandas as pd
+    from test_gpu_evaluate import _make_dataset
+    from ws_unet_amd import evaluate
+    data = tmp_path / "data"
+    data.mkdir()
+    _make_dataset(data)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    outs = [str(tmp_path / f"rank{r}") for r in range(2)]
+    procs = [subprocess.Popen([sys.executable, str(HERE / "eval_worker.py"), str(r), "2", str(port), str(data), outs[r], "default", "0"],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    logs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=420)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            pytest.fail("sharded-evaluate ranks dead-locked (mismatched collective)")
+        logs.append(o)
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+    model = gpu_model(2, "he", "bf16x3s", drop_rate=0.)
+    ref_c = evaluate.predict_unet_cover(data, model=model, progress_on=False)
+    for r in range(2):
+        got_c = pd.read_csv(outs[r] + ".cover.csv")
+        assert got_c["name"].tolist() == ref_c["name"].tolist()
+        np.testing.assert_allclose(got_c["beta_hat"].to_numpy(float), ref_c["beta_hat"].to_numpy(float), atol=2e-6)
+        np.testing.assert_allclose(got_c["l1"].to_numpy(float), ref_c["l1"].to_numpy(float), atol=2e-6)

@@ -227,16 +227,26 @@ def test_fused_first_layer_pl_is_bitwise_the_two_kernels(shape):
             assert torch.equal(a_, b_)
 
 
-def test_unet_planar_with_fused_first_layer():
-    """model.fuse_first_planar: same output as the unfused planar path bit for bit, and the range flag also sees the (never stored) xe11."""
+@pytest.mark.parametrize("mode", ["f16f8p", "f16f4p"])
+def test_unet_planar_with_fused_first_layer(mode):
+    """model.fuse_first_planar: same output as the unfused planar path bit for bit, and the range flag also sees the (never stored) xe11.
+    In the default mode 'f16f4p' the switch is ignored (the fused kernel multiplies e4m3 cross terms and reads the e4m3 weight
+    packing -- handed the fp4 packing it computed wrong activations and read past the buffer; ops.conv3x3_pl_fused_first now checks the size)."""
     from gpu_util import gpu_model, images01
+    from ws_unet_amd import ops
     _, x = images01(2, 64, 96, seed=12)
-    m = gpu_model(2, "he", "f16f8p")
+    m = gpu_model(2, "he", mode)
+    if mode == "f16f4p":
+        w = torch.zeros((64, 64, 3, 3), device=DEV)
+        with pytest.raises(AssertionError, match="pack_conv3x3"):
+            ops.conv3x3_pl_fused_first(x.to(DEV), m.e11.weight, None, ops.pack_conv3x3_f4(w), None, 64)
     with torch.no_grad():
         y0 = m(x.to(DEV))
         m.fuse_first_planar = True
         y1 = m(x.to(DEV))
     assert torch.equal(y0, y1)
+    if mode == "f16f4p":
+        return
     big = gpu_model(1, "he", "f16f8p")
     big.fuse_first_planar = True
     with torch.no_grad():

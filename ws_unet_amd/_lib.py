@@ -52,7 +52,9 @@ SIGNATURES = {
     "wsu_conv3x3_pl_fwd": (c_int, [_P] * 10 + [c_int] * 9 + [_P, _P, _P]),
     "wsu_relu_mask_bytes": (c_size_t, [c_int] * 4),
     "wsu_conv3x3_pl_fused_first_fwd": (c_int, [_P] * 7 + [c_int] * 5 + [_P, _P]),
-    "wsu_convt2x2_pl_fwd": (c_int, [_P, _P, _P, _P] + [c_int] * 5 + [_P, _P]),
+    "wsu_convt2x2_pl_fwd": (c_int, [_P, _P, _P, _P] + [c_int] * 6 + [_P, _P]),
+    "wsu_planar_q_bytes": (c_size_t, [c_int] * 4),
+    "wsu_conv3x3_q_fwd": (c_int, [_P] * 10 + [c_int] * 9 + [_P, _P]),
     "wsu_conv3x3_packed_f4_bytes": (c_size_t, [c_int] * 2),
     "wsu_conv3x3_pack_f4": (c_int, [_P, _P, c_int, c_int, _P]),
     "wsu_conv3x3_pl_bwd_data_workspace_bytes": (c_size_t, [c_int] * 5),
@@ -68,7 +70,7 @@ SIGNATURES = {
     "wsu_chansum_pl_workspace_bytes": (c_size_t, [c_int]),
     "wsu_colsum_pl": (c_int, [_P, _P, _P, c_size_t] + [c_int] * 5 + [_P]),
     "wsu_conv3x3_first_pl_bwd_weight": (c_int, [_P] * 5 + [c_size_t] + [c_int] * 5 + [_P]),
-    "wsu_conv3x3_first_pl_fwd": (c_int, [_P, _P, _P, _P] + [c_int] * 6 + [_P, _P, _P]),
+    "wsu_conv3x3_first_pl_fwd": (c_int, [_P, _P, _P, _P] + [c_int] * 7 + [_P, _P, _P]),
     "wsu_conv3x3_first_fwd": (c_int, [_P, _P, _P, _P] + [c_int] * 7 + [_P]),
     "wsu_maxpool2x2_fwd": (c_int, [_P, _P, _P] + [c_int] * 5 + [_P]),
     "wsu_convt2x2_fwd": (c_int, [_P, _P, _P, _P] + [c_int] * 6 + [_P]),

@@ -31,6 +31,23 @@ __device__ __forceinline__ void store_chunk_px(const f32x4& X, const f32x4& Y, c
     }
 }
 
+// Planar Q output (round 4, wsu_device.h "planar Q storage"): TWO pixels of a lane (X0 / Y0, X1 / Y1: the same channels as above) -> their f16 granules (all
+// lanes, plane hh), then lanes 0-31 store pixel 0's Q granule and scale byte, lanes 32-63 pixel 1's.  `chunk`: the (image, output chunk)'s first byte;
+// off0 / off1: the pixels' byte offsets inside a 16-byte plane; soff0 / soff1: their scale bytes' offsets inside the scale plane.
+__device__ __forceinline__ void store_chunk_pair_q(const f32x4& X0, const f32x4& Y0, const f32x4& X1, const f32x4& Y1, char* chunk, size_t plane_bytes,
+                                                   size_t off0, size_t off1, unsigned soff0, unsigned soff1, int hh, bool ok) {
+    u32x4 g0, g1; uint32_t dh0, dr0, sb0, dh1, dr1, sb1;
+    wsu_q4_pre(X0, Y0, g0, dh0, dr0, sb0);
+    wsu_q4_pre(X1, Y1, g1, dh1, dr1, sb1);
+    const u32x4 qg = wsu_q4_pair(dh0, dr0, dh1, dr1);
+    if (ok) {
+        *reinterpret_cast<u32x4*>(chunk + hh * plane_bytes + off0) = g0;
+        *reinterpret_cast<u32x4*>(chunk + hh * plane_bytes + off1) = g1;
+        *reinterpret_cast<u32x4*>(chunk + 2 * plane_bytes + (hh ? off1 : off0)) = qg;
+        *reinterpret_cast<unsigned char*>(chunk + 3 * plane_bytes + (hh ? soff1 : soff0)) = (unsigned char)(hh ? sb1 : sb0);
+    }
+}
+
 // =====================================================================================================================================
 // K3p.  y[n, 2i+a, 2j+b, co] = bias[co] + sum_ci x[n, i, j, ci] * w[ci, co, a, b]: four 1-tap GEMMs that share their B operand.
 // Tile = 4 x 32 INPUT pixels x 64 co x 4 sub-positions.  Matrix wave w: output-row parity a = w & 1, input rows 2 (w>>1 & 1) + {0, 1}, output
@@ -62,6 +79,7 @@ struct CtpArgs {
     int n, h, w, cin, cout;
     int tiles_x, tiles_y, ncb, nst;                       // nst = steps per tile = cin / 32
     int ntiles;
+    int yq;                                               // 1: y is a planar Q tensor (the 3x3 convs of mode 'f16f4p' read it), 0: the e4m3-residual format
 };
 
 struct CtTile { int n, y0, x0, cb; };
@@ -233,16 +251,24 @@ __global__ __launch_bounds__(ct::NT) void convt2x2_pl_kernel(const CtpArgs a) {
                 for (int q = 0; q < 2; ++q) {
                     const int irow = cur.y0 + 2 * half + q;
                     const bool ok = irow < a.h && icol < a.w;
-                    char* dst = a.y + ((((size_t)cur.n * nco + oc) * HBM_PLANES) * ohw + (size_t)(2 * irow + pa) * ow + 2 * icol) * 16;
+                    f32x4 X[2], Y[2];
 #pragma unroll
-                    for (int b = 0; b < 2; ++b) {
-                        f32x4 X, Y;
+                    for (int b = 0; b < 2; ++b)
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            X[e] = acc[b][q][8 * cp + e] + bx[e]; Y[e] = acc[b][q][8 * cp + 4 + e] + by[e];
-                            vmax = fmaxf(vmax, fmaxf(fabsf(X[e]), fabsf(Y[e])));
+                            X[b][e] = acc[b][q][8 * cp + e] + bx[e]; Y[b][e] = acc[b][q][8 * cp + 4 + e] + by[e];
+                            vmax = fmaxf(vmax, fmaxf(fabsf(X[b][e]), fabsf(Y[b][e])));
                         }
-                        store_chunk_px(X, Y, dst + b * 16, ohw * 16, hh, ok);
+                    if (a.yq) {                                      // (wave-uniform) the lane's two output pixels are a pair of the Q format's epilogue
+                        const int orow = 2 * irow + pa, ocol = 2 * icol;
+                        char* chunk = a.y + ((size_t)cur.n * nco + oc) * wsu_q_chunk_bytes(oh, ow);
+                        const size_t off = ((size_t)orow * ow + ocol) * 16;
+                        const int otx = (ow + 31) >> 5;
+                        store_chunk_pair_q(X[0], Y[0], X[1], Y[1], chunk, ohw * 16, off, off + 16, wsu_q_soff(orow, ocol, otx), wsu_q_soff(orow, ocol + 1, otx), hh, ok);
+                    } else {
+                        char* dst = a.y + ((((size_t)cur.n * nco + oc) * HBM_PLANES) * ohw + (size_t)(2 * irow + pa) * ow + 2 * icol) * 16;
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) store_chunk_px(X[b], Y[b], dst + b * 16, ohw * 16, hh, ok);
                     }
                 }
             }
@@ -514,7 +540,7 @@ __global__ void pack_convt_dgrad_pl_kernel(const float* __restrict__ w, char* __
 // time from tap-major weights in LDS; fp32 FMAs in the tap order of conv3x3_first_kernel (pointwise.hip), so the values before encoding are
 // bitwise those of the NHWC first-layer kernel.  HBM-write bound: 4 bytes per output element.
 // =====================================================================================================================================
-struct FirstPlArgs { const float* x; const float* w; const float* b; char* y; unsigned* range_flag; int n, h, w_, cin, cout, relu; unsigned char* relu_mask_out; };
+struct FirstPlArgs { const float* x; const float* w; const float* b; char* y; unsigned* range_flag; int n, h, w_, cin, cout, relu; unsigned char* relu_mask_out; int yq; };
 
 __global__ __launch_bounds__(256) void first_pl_kernel(const FirstPlArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -568,8 +594,20 @@ __global__ __launch_bounds__(256) void first_pl_kernel(const FirstPlArgs a) {
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) vmax = fmaxf(vmax, fabsf(v[g][e]));
-                wsu_split4_f16r8(v[g], WSU_F8_XLO_DIV, h[2 * g], h[2 * g + 1], lo[g]);
             }
+            if (a.yq) {                                                  // planar Q output: f16 | f16 | Q | scale byte (wsu_device.h)
+                u32x4 h0, h1, qg; uint32_t sb;
+                wsu_q4_encode16(v, h0, h1, qg, sb);
+                char* chunk = a.y + ((size_t)img * nco + oc) * wsu_q_chunk_bytes(a.h, a.w_);
+                char* dq = chunk + ((size_t)y * a.w_ + x) * 16;
+                *reinterpret_cast<u32x4*>(dq) = h0;
+                *reinterpret_cast<u32x4*>(dq + hw * 16) = h1;
+                *reinterpret_cast<u32x4*>(dq + 2 * hw * 16) = qg;
+                *reinterpret_cast<unsigned char*>(chunk + 3 * hw * 16 + wsu_q_soff(y, x, (a.w_ + 31) >> 5)) = (unsigned char)sb;
+                continue;
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) wsu_split4_f16r8(v[g], WSU_F8_XLO_DIV, h[2 * g], h[2 * g + 1], lo[g]);
             char* dst = a.y + ((((size_t)img * nco + oc) * 3) * hw + (size_t)y * a.w_ + x) * 16;
             *reinterpret_cast<u32x4*>(dst) = mk_u4(h[0], h[1], h[2], h[3]);
             *reinterpret_cast<u32x4*>(dst + hw * 16) = mk_u4(h[4], h[5], h[6], h[7]);
@@ -591,7 +629,8 @@ extern "C" {
 // K3p: transposed 2x2 stride-2 conv + bias on planar F16F8P activations.  x: cin channels at (h, w); y: cout channels at (2h, 2w); weights from
 // wsu_convt2x2_pack(mode F16F8).  cin a multiple of 32, cout of 64.
 int wsu_convt2x2_pl_fwd(const void* x, const void* w_packed, const float* bias, void* y, int n, int h, int w, int cin, int cout,
-                        unsigned* range_flag, void* stream) {
+                        int y_format, unsigned* range_flag, void* stream) {
+    WSU_REQUIRE(y_format == WSU_PLANAR_A || y_format == WSU_PLANAR_Q, "convt2x2_pl: y_format must be WSU_PLANAR_A or WSU_PLANAR_Q");
     WSU_REQUIRE(x && w_packed && y, "convt2x2_pl: null pointer");
     WSU_REQUIRE(n > 0 && h > 0 && w > 0, "convt2x2_pl: bad shape n=%d h=%d w=%d", n, h, w);
     WSU_REQUIRE(cin > 0 && cin % 32 == 0, "convt2x2_pl: cin=%d must be a multiple of 32", cin);
@@ -599,7 +638,7 @@ int wsu_convt2x2_pl_fwd(const void* x, const void* w_packed, const float* bias, 
     WSU_REQUIRE((long long)h * w * 96 < 0xFFFFFFF0LL, "convt2x2_pl: h*w too large (two input chunks and one output plane triple must stay below 4 GiB)");
     CtpArgs a;
     a.x = (const char*)x; a.wp = (const char*)w_packed; a.bias = bias; a.y = (char*)y; a.range_flag = range_flag;
-    a.n = n; a.h = h; a.w = w; a.cin = cin; a.cout = cout;
+    a.n = n; a.h = h; a.w = w; a.cin = cin; a.cout = cout; a.yq = y_format == WSU_PLANAR_Q ? 1 : 0;
     a.tiles_x = (w + ct::TW - 1) / ct::TW; a.tiles_y = (h + ct::TH - 1) / ct::TH; a.ncb = cout / WSU_COB; a.nst = cin / 32;
     const long long nt = (long long)n * a.tiles_x * a.tiles_y * a.ncb;
     WSU_REQUIRE(nt > 0 && nt < 0x3FFFFFFFLL, "convt2x2_pl: %lld tiles out of range", nt);
@@ -661,11 +700,14 @@ int wsu_convt2x2_pl_bwd_data(const void* dy, const void* w_packed_dgrad, void* d
 
 // K0p: first layer into planar storage.  x_nchw: (N, cin, H, W) fp32, cin 1..8; w_oihw: (cout, cin, 3, 3); cout a multiple of 16 (<= 128).
 int wsu_conv3x3_first_pl_fwd(const float* x_nchw, const float* w_oihw, const float* bias, void* y, int n, int h, int w, int cin, int cout,
-                             int relu, unsigned* range_flag, unsigned char* relu_mask_out, void* stream) {
+                             int relu, int y_format, unsigned* range_flag, unsigned char* relu_mask_out, void* stream) {
+    WSU_REQUIRE(y_format == WSU_PLANAR_A || y_format == WSU_PLANAR_Q, "conv3x3_first_pl: y_format must be WSU_PLANAR_A or WSU_PLANAR_Q");
+    WSU_REQUIRE(!(relu_mask_out && y_format == WSU_PLANAR_Q), "conv3x3_first_pl: relu_mask_out belongs to the training forward (format WSU_PLANAR_A)");
+    WSU_REQUIRE((long long)h * w * 50 < 0xFFFFFFF0LL, "conv3x3_first_pl: h*w too large");
     WSU_REQUIRE(x_nchw && w_oihw && y, "conv3x3_first_pl: null pointer");
     WSU_REQUIRE(n > 0 && h >= 2 && w >= 2 && cin >= 1 && cin <= 8 && cout > 0 && cout % 16 == 0 && cout <= 128, "conv3x3_first_pl: bad shape");
     WSU_REQUIRE(!relu_mask_out || (long long)n * (cout / 8) * wsu_mask_hp(h) * wsu_mask_wp(w) < 0x7FFFFFF0LL, "conv3x3_first_pl: mask plane too large");
-    FirstPlArgs a{x_nchw, w_oihw, bias, (char*)y, range_flag, n, h, w, cin, cout, relu, relu_mask_out};
+    FirstPlArgs a{x_nchw, w_oihw, bias, (char*)y, range_flag, n, h, w, cin, cout, relu, relu_mask_out, y_format == WSU_PLANAR_Q ? 1 : 0};
     const long long total = (long long)n * h * w;
     const unsigned nblk = (unsigned)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
     const size_t lds = ((size_t)cin * 9 * cout + cout) * sizeof(float);

@@ -245,10 +245,102 @@ __device__ __forceinline__ u32x4 wsu_q4_encode_x(const u32x4& h0, const u32x4& h
     // stored residual byte = e4m3((x - f16 x) * 2^12): (x - f16 x) * 2^11 = byte value / 2
     return mk_u4(wsu_f16x8_to_fp4(h0, sc), wsu_f16x8_to_fp4(h1, sc), wsu_fp8x8_to_fp4(res.x, res.y, 0.5f, sc), wsu_fp8x8_to_fp4(res.z, res.w, 0.5f, sc));
 }
+// ---- planar Q storage ("F16F4P" tensors, round 4; layout: include/wsu.h): the PRODUCER emits what the fp4 conv multiplies -----------------------
+// Per (image, 16-channel chunk): planes f16 ch 0-7 | f16 ch 8-15 | Q (the 16-byte granule above) as [H][W][16 B], then the E8M0 scale bytes as
+// 16 x 32-pixel tile blocks [ceil(H/16)][ceil(W/32)][16][32] (a conv tile's 512 scale bytes are one contiguous run; its halo is gathered per lane).
+__host__ __device__ inline size_t wsu_q_sblocks(int h, int w) { return (size_t)((h + 15) >> 4) * (size_t)((w + 31) >> 5); }
+__host__ __device__ inline size_t wsu_q_chunk_bytes(int h, int w) { return (size_t)48 * h * w + 512 * wsu_q_sblocks(h, w); }
+// byte offset of pixel (y, x)'s scale byte inside the scale plane of a chunk
+__device__ __forceinline__ unsigned wsu_q_soff(int y, int x, int tiles_x) {
+    return (unsigned)(((y >> 4) * tiles_x + (x >> 5)) * 512 + (y & 15) * 32 + (x & 31));
+}
+__device__ __forceinline__ void wsu_swap32(uint32_t& upper_of, uint32_t& lower_of) {     // lanes 32-63 of `upper_of` <-> lanes 0-31 of `lower_of`
+    const auto r = __builtin_amdgcn_permlane32_swap(upper_of, lower_of, false, false);
+    upper_of = r[0]; lower_of = r[1];
+}
+// Accumulator-layout producer (the MFMA epilogues): this lane holds X = channels 4 hh + 0..3 and Y = channels 8 + 4 hh + 0..3 of one pixel's
+// 16-channel chunk (hh = lane >> 5), lane ^ 32 the other eight.  Out: g = the f16 granule this lane stores to plane hh (lanes 0-31: ch 0-7,
+// lanes 32-63: ch 8-15, as the e4m3 format's epilogues arrange it); dhi / dres = this lane's eight fp4 nibbles of the f16 parts / of the
+// residuals (x - f16 x) * 2^11, both as [X: 16 bits | Y: 16 bits] and both divided by the block scale 2^E; sb = E + 127 (equal in both lanes).
+// The residual nibbles come from the exact fp32 residual (the loaders of round 3 re-rounded the stored e4m3 residual).
+__device__ __forceinline__ void wsu_q4_pre(const f32x4& X, const f32x4& Y, u32x4& g, uint32_t& dhi, uint32_t& dres, uint32_t& sb) {
+    const f32x2 xa = {X[0], X[1]}, xb = {X[2], X[3]}, ya = {Y[0], Y[1]}, yb = {Y[2], Y[3]};
+    uint32_t xh0 = __builtin_bit_cast(uint32_t, __builtin_convertvector(xa, f16x2)), xh1 = __builtin_bit_cast(uint32_t, __builtin_convertvector(xb, f16x2));
+    uint32_t yh0 = __builtin_bit_cast(uint32_t, __builtin_convertvector(ya, f16x2)), yh1 = __builtin_bit_cast(uint32_t, __builtin_convertvector(yb, f16x2));
+    const float r0 = wsu_sub_f16_lo(X[0], xh0), r1 = wsu_sub_f16_hi(X[1], xh0), r2 = wsu_sub_f16_lo(X[2], xh1), r3 = wsu_sub_f16_hi(X[3], xh1);
+    const float r4 = wsu_sub_f16_lo(Y[0], yh0), r5 = wsu_sub_f16_hi(Y[1], yh0), r6 = wsu_sub_f16_lo(Y[2], yh1), r7 = wsu_sub_f16_hi(Y[3], yh1);
+    // largest |f16| of the block: eight values here, eight in the partner lane
+    u16x2_t m = __builtin_elementwise_max(__builtin_bit_cast(u16x2_t, xh0 & 0x7FFF7FFFu), __builtin_bit_cast(u16x2_t, xh1 & 0x7FFF7FFFu));
+    m = __builtin_elementwise_max(m, __builtin_bit_cast(u16x2_t, yh0 & 0x7FFF7FFFu));
+    m = __builtin_elementwise_max(m, __builtin_bit_cast(u16x2_t, yh1 & 0x7FFF7FFFu));
+    uint32_t mw = __builtin_bit_cast(uint32_t, m), mp = mw;
+    wsu_swap32(mw, mp);                                                   // one of (mw, mp) is now the partner's, the other this lane's
+    m = __builtin_elementwise_max(__builtin_bit_cast(u16x2_t, mw), __builtin_bit_cast(u16x2_t, mp));
+    const int e = wsu_q4_block_exp(m.x > m.y ? m.x : m.y);
+    const float sc = wsu_pow2f(e), scr = wsu_pow2f(e - 11);
+    sb = (uint32_t)(e + 127);
+    uint32_t dh = 0, dr = 0;
+    asm volatile("v_cvt_scalef32_pk_fp4_f16 %0, %1, %2" : "+v"(dh) : "v"(xh0), "v"(sc));
+    asm volatile("v_cvt_scalef32_pk_fp4_f16 %0, %1, %2 op_sel:[0,0,1,0]" : "+v"(dh) : "v"(xh1), "v"(sc));
+    asm volatile("v_cvt_scalef32_pk_fp4_f16 %0, %1, %2 op_sel:[0,0,0,1]" : "+v"(dh) : "v"(yh0), "v"(sc));
+    asm volatile("v_cvt_scalef32_pk_fp4_f16 %0, %1, %2 op_sel:[0,0,1,1]" : "+v"(dh) : "v"(yh1), "v"(sc));
+    dr = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(dr, r0, r1, scr, 0);
+    dr = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(dr, r2, r3, scr, 1);
+    dr = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(dr, r4, r5, scr, 2);
+    dr = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(dr, r6, r7, scr, 3);
+    dhi = dh; dres = dr;
+    wsu_swap32(xh0, yh0); wsu_swap32(xh1, yh1);                            // lanes 0-31: f16 ch 0-7, lanes 32-63: f16 ch 8-15
+    g = mk_u4(xh0, xh1, yh0, yh1);
+}
+// Q granules of TWO pixels from their nibble words: lanes 0-31 return pixel 0's granule, lanes 32-63 pixel 1's (one exchange serves both: a
+// lower lane needs its partner's words of pixel 0, an upper lane its partner's words of pixel 1).
+__device__ __forceinline__ u32x4 wsu_q4_pair(uint32_t dhi0, uint32_t dres0, uint32_t dhi1, uint32_t dres1) {
+    wsu_swap32(dhi0, dhi1); wsu_swap32(dres0, dres1);                      // every lane: word 0 = channels 0-3 | 8-11, word 1 = channels 4-7 | 12-15 of ITS pixel
+    return mk_u4(__builtin_amdgcn_perm(dhi1, dhi0, 0x05040100u), __builtin_amdgcn_perm(dhi1, dhi0, 0x07060302u),
+                 __builtin_amdgcn_perm(dres1, dres0, 0x05040100u), __builtin_amdgcn_perm(dres1, dres0, 0x07060302u));
+}
+// ... of ONE pixel: valid in lanes 0-31
+__device__ __forceinline__ u32x4 wsu_q4_single(uint32_t dhi, uint32_t dres) {
+    uint32_t ph = dhi, pr = dres;
+    wsu_swap32(dhi, ph); wsu_swap32(dres, pr);                             // lanes 0-31: ph / pr = the partner's words
+    return mk_u4(__builtin_amdgcn_perm(ph, dhi, 0x05040100u), __builtin_amdgcn_perm(ph, dhi, 0x07060302u),
+                 __builtin_amdgcn_perm(pr, dres, 0x05040100u), __builtin_amdgcn_perm(pr, dres, 0x07060302u));
+}
+// Pixel-per-thread producer (first layer): all 16 channels of a (pixel, chunk) in one thread -> the three granules and the scale byte
+__device__ __forceinline__ void wsu_q4_encode16(const f32x4 (&v)[4], u32x4& h0, u32x4& h1, u32x4& q, uint32_t& sb) {
+    uint32_t h[8]; float r[16];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const f32x2 a = {v[k][0], v[k][1]}, b = {v[k][2], v[k][3]};
+        h[2 * k] = __builtin_bit_cast(uint32_t, __builtin_convertvector(a, f16x2)); h[2 * k + 1] = __builtin_bit_cast(uint32_t, __builtin_convertvector(b, f16x2));
+        r[4 * k] = wsu_sub_f16_lo(v[k][0], h[2 * k]); r[4 * k + 1] = wsu_sub_f16_hi(v[k][1], h[2 * k]);
+        r[4 * k + 2] = wsu_sub_f16_lo(v[k][2], h[2 * k + 1]); r[4 * k + 3] = wsu_sub_f16_hi(v[k][3], h[2 * k + 1]);
+    }
+    h0 = mk_u4(h[0], h[1], h[2], h[3]); h1 = mk_u4(h[4], h[5], h[6], h[7]);
+    const int e = wsu_q4_block_exp(wsu_f16x16_max_abs_bits(h0, h1));
+    const float sc = wsu_pow2f(e), scr = wsu_pow2f(e - 11);
+    sb = (uint32_t)(e + 127);
+    uint32_t q2 = 0, q3 = 0;
+    q2 = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(q2, r[0], r[1], scr, 0); q2 = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(q2, r[2], r[3], scr, 1);
+    q2 = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(q2, r[4], r[5], scr, 2); q2 = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(q2, r[6], r[7], scr, 3);
+    q3 = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(q3, r[8], r[9], scr, 0); q3 = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(q3, r[10], r[11], scr, 1);
+    q3 = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(q3, r[12], r[13], scr, 2); q3 = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(q3, r[14], r[15], scr, 3);
+    q = mk_u4(wsu_f16x8_to_fp4(h0, sc), wsu_f16x8_to_fp4(h1, sc), q2, q3);
+}
 // fp4 cross-term MFMA: one granule per operand, per-lane E8M0 scale bytes
+#ifndef WSU_PROBE16
+#define WSU_PROBE16 0           // timing-only build (make qprobe16; results are wrong): every 32x32 matrix instruction of conv3x3_q.hip as TWO 16x16 instructions
+#endif                          // of the same cycles and products on the same operand registers -- what the 16x16x32 / 16x16x128 shapes would buy at no padding
 __device__ __forceinline__ void wsu_mfma_q4(const u32x4& a, const u32x4& b, int scale_a, int scale_b, f32x16& acc) {
     const i32x8 av = {(int)a.x, (int)a.y, (int)a.z, (int)a.w, 0, 0, 0, 0}, bv = {(int)b.x, (int)b.y, (int)b.z, (int)b.w, 0, 0, 0, 0};
+#if WSU_PROBE16
+    f32x4 c0 = {acc[0], acc[1], acc[2], acc[3]}, c1 = {acc[8], acc[9], acc[10], acc[11]};
+    c0 = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(av, bv, c0, 4, 4, 0, scale_a, 0, scale_b);
+    c1 = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(av, bv, c1, 4, 4, 0, scale_a, 0, scale_b);
+    acc[0] = c0[0]; acc[1] = c0[1]; acc[2] = c0[2]; acc[3] = c0[3]; acc[8] = c1[0]; acc[9] = c1[1]; acc[10] = c1[2]; acc[11] = c1[3];
+#else
     acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, acc, 4, 4, 0, scale_a, 0, scale_b);
+#endif
 }
 
 // the same for a stored GRADIENT granule: e4m3(g * 4)
@@ -268,7 +360,14 @@ __device__ __forceinline__ u32x2 wsu_f16x8_to_fp8_grad(const u32x4& h) {
 // 4-7 block 1; inside a block lanes 0-31 hold k = 0..15 and lanes 32-63 k = 16..31; block b is scaled by byte 0 of the scale registers of
 // lanes 32b .. 32b+31 -> a lane passes (hh ? block-1 scale : block-0 scale).
 __device__ __forceinline__ void wsu_mfma_f16(const u32x4& a, const u32x4& b, f32x16& acc) {
+#if WSU_PROBE16
+    f32x4 c0 = {acc[4], acc[5], acc[6], acc[7]}, c1 = {acc[12], acc[13], acc[14], acc[15]};
+    c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c1, 0, 0, 0);
+    acc[4] = c0[0]; acc[5] = c0[1]; acc[6] = c0[2]; acc[7] = c0[3]; acc[12] = c1[0]; acc[13] = c1[1]; acc[14] = c1[2]; acc[15] = c1[3];
+#else
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
+#endif
 }
 __device__ __forceinline__ void wsu_mfma_f8x2(const u32x4& a_blk0, const u32x4& a_blk1, const u32x4& b_blk0, const u32x4& b_blk1,
                                               int scale_a, int scale_b, f32x16& acc) {

@@ -44,22 +44,32 @@ def range_fallback(model, collective: bool = False) -> bool:
     switch the model to 'bf16x3s' (fp32-range storage) and return True -- the caller recomputes what it computed since the last look.
     The evaluate drivers call this once per data-set pass (one sync per pass), the per-image functions once per image (they synchronise
     on their result anyway).  `collective`: OR the flag over the ranks first (every rank of a sharded pass takes the same decision)."""
-    if getattr(model, "mode", None) not in ("f16f8p", "f16f8q", "f16f4p") or not hasattr(model, "range_exceeded"):
-        return False
+    planar = getattr(model, "mode", None) in ("f16f8p", "f16f8q", "f16f4p") and hasattr(model, "range_exceeded")
     if collective:
+        # EVERY rank enters the all-reduce, whatever its local state (a rank that skipped it while the others entered would hang the job
+        # or pair with a later collective).  A rank whose model already left the planar modes by a look of its OWN that the other ranks
+        # have not seen yet (UNet.forward_features' first-forward look, a per-image call before the pass: `_range_switched` without
+        # `_range_switch_synced`) contributes 1: the others follow and everybody recomputes, in the same arithmetic.
         from . import parallel
-        rf = getattr(model, "_range_flag", None)
-        if rf is None:
-            rf = model._range_flag_tensor(_model_device(model))
-        hit = parallel.any_rank_flag(rf)
+        if not hasattr(model, "_range_flag_tensor"):
+            return False
+        rf = model._range_flag_tensor(_model_device(model))
+        unsynced = (not planar) and getattr(model, "_range_switched", False) and not getattr(model, "_range_switch_synced", False)
+        hit = parallel.any_rank_flag(torch.ones_like(rf) if unsynced else rf)
+        rf.zero_()
         if hit:
-            rf.zero_()
+            model._range_switch_synced = True
+        if not planar:
+            return hit
     else:
+        if not planar:
+            return False
         hit = model.range_exceeded()
     if hit:
         logging.warning("ws_unet_amd.evaluate: activations beyond +-448 in mode '%s' (the planar format's e4m3 residual saturates there); "
                         "switching this model to mode 'bf16x3s' and recomputing", model.mode)
         model.mode = "bf16x3s"
+        model._range_switched = True
     return hit
 
 
@@ -132,8 +142,9 @@ def predict_unet(
         # pinned buffer) instead of PIL -- the same plane `imread4_f32(fname)[..., 3]` holds (tests/test_host_logic.py), 2.5x less host
         # time per image; files it does not support fall back to PIL inside read_luma_batch
         from .imread import png_shape
-        ahead = _AHEAD["pending"].pop(str(fname), None)      # decoded one row ahead by the iterator's lookahead (predict_unet_cover / _stego)
-        planes = ahead.result() if ahead is not None else (load_planes_u8([fname]) if png_shape(str(fname)) == (512, 512) else None)
+        planes = _take_ahead(str(fname))                     # decoded ahead by the iterator's lookahead (predict_unet_cover / _stego), if still valid
+        if planes is None:
+            planes = load_planes_u8([fname]) if png_shape(str(fname)) == (512, 512) else None
         if planes is not None:
             x_u8 = planes.to(_model_device(model), non_blocking=True)
             mark_uploaded(planes)
@@ -162,7 +173,16 @@ def predict_unet(
 # the files of rows i + 1 .. i + 3 into the pinned ring -- one decode (~2.2 ms) is longer than everything else of a row (reference: serial,
 # evaluate.py:142-149)
 _AHEAD_DEPTH = 3
-_AHEAD = {"pool": None, "pending": {}}
+_AHEAD = {"pool": None, "pending": {}, "gen": 0}
+
+
+def _file_stamp(path: str):
+    import os
+    try:
+        st = os.stat(path)
+        return (st.st_mtime_ns, st.st_size)
+    except OSError:
+        return None
 
 
 def _decode_ahead(path: str):
@@ -176,8 +196,29 @@ def _lookahead(fname) -> None:
         _AHEAD["pool"] = ThreadPoolExecutor(max_workers=_AHEAD_DEPTH)
     pend = _AHEAD["pending"]
     while len(pend) > _AHEAD_DEPTH:                          # rows that were announced and never asked for
-        pend.pop(next(iter(pend))).cancel()
-    pend[str(fname)] = _AHEAD["pool"].submit(_decode_ahead, str(fname))
+        pend.pop(next(iter(pend)))[0].cancel()
+    # an entry = (future, ring generation at submission, file stamp): a decode lives in one slot of load_planes_u8's pinned ring, which is
+    # re-issued after _NBUF further decodes -- an entry older than that, or of a file rewritten since, is dropped instead of uploaded
+    pend[str(fname)] = (_AHEAD["pool"].submit(_decode_ahead, str(fname)), _AHEAD["gen"], _file_stamp(str(fname)))
+    _AHEAD["gen"] += 1
+
+
+def _lookahead_reset() -> None:
+    """Forget every announced-but-unconsumed decode (start and end of a fabrika pass; a pass that raised midway leaves entries behind)."""
+    pend = _AHEAD["pending"]
+    while pend:
+        pend.pop(next(iter(pend)))[0].cancel()
+
+
+def _take_ahead(path: str):
+    ent = _AHEAD["pending"].pop(path, None)
+    if ent is None:
+        return None
+    fut, gen, stamp = ent
+    if _AHEAD["gen"] - gen > _NBUF - 1 or stamp != _file_stamp(path):    # its ring slot may have been re-issued / the file changed: decode again
+        fut.cancel()
+        return None
+    return fut.result()
 
 
 def _predict_unet_cover(*args, **kw):
@@ -189,6 +230,7 @@ def _predict_unet_stego(*args, **kw):
 
 
 _predict_unet_cover.lookahead = _predict_unet_stego.lookahead = _lookahead
+_predict_unet_cover.lookahead_reset = _predict_unet_stego.lookahead_reset = _lookahead_reset
 _predict_unet_cover.lookahead_depth = _predict_unet_stego.lookahead_depth = _AHEAD_DEPTH
 predict_unet_cover = fabrika.precovers(iterator="python", convert_to="pandas", ignore_missing=False, n_jobs=-1)(_predict_unet_cover)
 predict_unet_stego = fabrika.stego_spatial(iterator="python", convert_to="pandas", ignore_missing=False, n_jobs=-1)(_predict_unet_stego)
@@ -265,7 +307,9 @@ def mark_uploaded(planes: torch.Tensor) -> None:
     """Record, for a pinned buffer handed out by load_planes_u8, the point in the current stream after which it may be overwritten."""
     if not planes.is_pinned():
         return
-    for slot in _PINNED.values():
+    with _PINNED_LOCK:                                        # (helper threads insert into / clear _PINNED in load_planes_u8)
+        slots = list(_PINNED.values())
+    for slot in slots:
         for i, b in enumerate(slot["bufs"]):
             if b.data_ptr() == planes.data_ptr():
                 ev = torch.cuda.Event()

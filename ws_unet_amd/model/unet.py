@@ -17,9 +17,10 @@ Precision modes (``mode=`` or env ``WSU_MODE``):
   'f16f8p'  the 'f16f8' arithmetic on PLANAR storage -- [n][C/16][4 planes][H][W][16 B], the LDS image of the matrix kernels: staging is a
                                                    pure LDS-DMA and one persistent workgroup per CU pipelines it across chunks and tiles
                                                    (csrc/conv3x3_pl.hip, planar.hip); same values as 'f16f8' up to the accumulation order
-  'f16f4p'  (DEFAULT since round 3) 'f16f8p' storage; the 3x3 convs multiply both cross terms as ONE block-scaled fp4 (e2m1) operand pair per tap
-            pair (14 instead of 19 matrix units per chunk; include/wsu.h x_residual = 2): MAE 2.1e-5 (the gate is 1e-4) instead of 4e-6, 14 % more
-            images/s; training forwards and the transposed convs keep the e4m3 arithmetic (profiles/r03/f16f4p.md)
+  'f16f4p'  (DEFAULT since round 3) the 3x3 convs multiply both cross terms as ONE block-scaled fp4 (e2m1) operand pair per tap pair (14 instead of
+            19 matrix units per chunk): MAE 2.1e-5 (the gate is 1e-4) instead of 4e-6.  Since round 4 on planar Q storage (ops.PlanarQ, include/wsu.h
+            K1q): every producer's epilogue writes the fp4 granule + scale byte its consumer multiplies, the consumers' loader waves are pure DMA
+            (csrc/conv3x3_q.hip); training forwards and the transposed convs keep the e4m3 arithmetic and format (profiles/r03/f16f4p.md, profiles/r04)
   'f16f8q'  'f16f8p' with ONE cross term (the weights' residual) on the first conv of every decoder block: MAE ~4e-5 instead of 4e-6
   'f16f8'   f16 products + fp8 cross terms      -- f16(w)*f16(x) exactly, the two residual cross terms on the block-scaled fp8
                                                    matrix pipe (0.70 of bf16x3's matrix cycles, ~2^-15 relative error per product, MAE
@@ -98,6 +99,12 @@ class UNet(nn.Module):
         if nsteps > 4:
             raise NotImplementedError("the reference defines at most 4 pooling steps (unet.py:85-132)")
         self.nsteps = nsteps
+        # DEFAULT MODE POLICY (round 4, VERDICT r03 next #2b).  The library default is the fastest arithmetic that keeps >= 3x margin to the north
+        # star's gate (MAE <= 1e-4 of the [0,1] output against the fp32 CPU path) on BOTH weight sets the repository can pin: the full-range 'he'
+        # formula weights (tests/test_gpu_forward.py::test_mae_gate_512_batch, bench.py `mae_vs_cpu_oracle`: 2.1e-5) and weights trained by this
+        # package's own loop (tests/test_gpu_round4.py::test_mae_gate_on_trained_weights, bench.py `mae_vs_cpu_oracle_trained`: <= 3e-5).  Parity on
+        # the PUBLISHED checkpoints is unpinned -- the reference ships none (.MISSING_LARGE_BLOBS:7-12); mode='f16f8p' (MAE 4e-6, ~12 % slower) is
+        # the conservative setting one argument away, 'f32' the exact one.  A mode that misses the margin on either set must not become the default.
         self.mode = mode or os.environ.get("WSU_MODE", "f16f4p")
         self.fuse_head = os.environ.get("WSU_FUSE_HEAD", "1") != "0"  # fold outconv + sigmoid into the last 3x3 conv
         self.fuse_first = os.environ.get("WSU_FUSE_FIRST", "1") != "0"  # fold e11 into e12's input staging
@@ -208,6 +215,7 @@ class UNet(nn.Module):
                         logging.warning("ws_unet_amd.UNet: activations beyond +-448 in mode 'f16f8p' (the e4m3 residual saturates there); "
                                         "switching this model to mode 'bf16x3s'")
                         self.mode = "bf16x3s"
+                        self._range_switched = True                # (a sharded pass tells the other ranks: evaluate.range_fallback)
                         return self.forward_features(x, keep, want_logit)
                 return res
         if m in (ops.MODE_BF16X3S, ops.MODE_F16F8) and (save or self.nsteps < 1 or not (self.fuse_first and self.fuse_head)
@@ -314,57 +322,69 @@ class UNet(nn.Module):
         # 'f16f8q': the first conv of every decoder block (the two most expensive layers of unet_2) multiplies without the activations'
         # residual term: 15 instead of 19 matrix units there, MAE 4e-6 -> ~4e-5 on the gate's weights (still 2.5x inside 1e-4)
         quick = self.mode == "f16f8q"
-        q4 = self.mode == "f16f4p"                                   # block-scaled fp4 cross terms: own packed weights, x_residual = 2
+        # 'f16f4p' (default): block-scaled fp4 cross terms on planar Q tensors (ops.PlanarQ; csrc/conv3x3_q.hip): every producer's epilogue writes
+        # the fp4 granule and scale byte its consumer multiplies; only the two tensors the transposed convs read stay in the e4m3-residual format
+        q4 = self.mode == "f16f4p"
+        # (A/B switch, to be removed with the code it selects: WSU_Q4_R3=1 = round 3's organisation of this mode -- e4m3-residual storage
+        # everywhere, the consumers' loader waves derive the fp4 operands: conv3x3_pl_kernel<..., Q4>)
+        q4r3 = q4 and os.environ.get("WSU_Q4_R3") == "1"
         CK = "conv_f4" if q4 else "conv"
-        XR = 2 if q4 else True
+        Q, A = (ops.PLANAR_A if q4r3 else ops.PLANAR_Q), ops.PLANAR_A
         tag = ops.set_layer
         e11 = self.e11
         rf = self._range_flag_tensor(x.device)
-        # e11 is folded into e12 (its 64 channels are computed by the loader waves of the persistent kernel) for single-plane inputs
-        fuse_first = self.fuse_first_planar and e11.in_channels == 1 and e11.out_channels == 64 and self.nsteps >= 1
+
+        def conv(xa, xb, name, layer, fmt=Q, xres=True, **kw):       # one 3x3 conv of the planar path in this mode's arithmetic
+            if q4r3:
+                return ops.conv3x3_pl(xa, xb, self._packed(name, W, CK), layer.bias.detach(), layer.out_channels, x_residual=2, **kw)
+            if q4:
+                return ops.conv3x3_q(xa, xb, self._packed(name, W, CK), layer.bias.detach(), layer.out_channels, y_format=fmt, **kw)
+            return ops.conv3x3_pl(xa, xb, self._packed(name, W, CK), layer.bias.detach(), layer.out_channels, x_residual=xres, **kw)
+
+        # e11 is folded into e12 (its 64 channels are computed by the loader waves of the persistent kernel) for single-plane inputs -- an
+        # experiment switch of the e4m3 modes (the fused kernel multiplies e4m3 cross terms and writes the e4m3-residual format)
+        fuse_first = self.fuse_first_planar and not q4 and e11.in_channels == 1 and e11.out_channels == 64 and self.nsteps >= 1
         cur = None
         if not fuse_first:
             tag("e11")
-            cur = ops.conv3x3_first_pl(x, e11.weight, e11.bias.detach(), range_flag=rf)
-        skips: List[torch.Tensor] = []
+            cur = ops.conv3x3_first_pl(x, e11.weight, e11.bias.detach(), range_flag=rf, y_format=Q if q4 else A)
+        skips: List = []
         for lvl in range(self.nsteps + 1):
             a, b = ENC[lvl]
             if lvl == 0 and fuse_first:
                 lb = self.e12
                 tag("e11+e12")
-                full, cur = ops.conv3x3_pl_fused_first(x, e11.weight, e11.bias.detach(), self._packed("e12", W, CK), lb.bias.detach(),
+                full, cur = ops.conv3x3_pl_fused_first(x, e11.weight, e11.bias.detach(), self._packed("e12", W, "conv"), lb.bias.detach(),
                                                        lb.out_channels, pool=True, range_flag=rf)
                 skips.append(full)
                 continue
             if lvl >= 1:
                 la = getattr(self, a)
                 tag(a)
-                cur = ops.conv3x3_pl(cur, None, self._packed(a, W, CK), la.bias.detach(), la.out_channels, range_flag=rf, x_residual=XR)
+                cur = conv(cur, None, a, la, range_flag=rf)
             lb = getattr(self, b)
             tag(b)
             last = lvl == self.nsteps
             if last and self.nsteps == 0:
                 tag(b + "+outconv")
-                return ops.conv3x3_pl(cur, None, self._packed(b, W, CK), lb.bias.detach(), lb.out_channels, want_y=False,
-                                      head_w=self.outconv.weight.detach(), head_b=self.outconv.bias.detach(), want_logit=want_logit, x_residual=XR)
+                return conv(cur, None, b, lb, want_y=False, head_w=self.outconv.weight.detach(), head_b=self.outconv.bias.detach(), want_logit=want_logit)
             if not last:
-                full, cur = ops.conv3x3_pl(cur, None, self._packed(b, W, CK), lb.bias.detach(), lb.out_channels, pool=True, range_flag=rf, x_residual=XR)
+                full, cur = conv(cur, None, b, lb, pool=True, range_flag=rf)
                 skips.append(full)
             else:
-                cur = ops.conv3x3_pl(cur, None, self._packed(b, W, CK), lb.bias.detach(), lb.out_channels, range_flag=rf, x_residual=XR)
+                cur = conv(cur, None, b, lb, fmt=A, range_flag=rf)        # feeds the transposed conv
         for depth in range(self.nsteps, 0, -1):
             up, c1, c2 = dec_names(depth)
             lu, l1, l2 = getattr(self, up), getattr(self, c1), getattr(self, c2)
             tag(up)
-            xu = ops.convt2x2_pl(cur, self._packed(up, W, "convt"), lu.bias.detach(), lu.out_channels, range_flag=rf)
+            xu = ops.convt2x2_pl(cur, self._packed(up, W, "convt"), lu.bias.detach(), lu.out_channels, range_flag=rf, y_format=Q if q4 else A)
             tag(c1)
-            cur = ops.conv3x3_pl(xu, skips[depth - 1], self._packed(c1, W, CK), l1.bias.detach(), l1.out_channels, range_flag=rf, x_residual=(2 if q4 else not quick))
+            cur = conv(xu, skips[depth - 1], c1, l1, xres=not quick, range_flag=rf)
             if depth == 1:
                 tag(c2 + "+outconv")
-                return ops.conv3x3_pl(cur, None, self._packed(c2, W, CK), l2.bias.detach(), l2.out_channels, want_y=False,
-                                      head_w=self.outconv.weight.detach(), head_b=self.outconv.bias.detach(), want_logit=want_logit, x_residual=XR)
+                return conv(cur, None, c2, l2, want_y=False, head_w=self.outconv.weight.detach(), head_b=self.outconv.bias.detach(), want_logit=want_logit)
             tag(c2)
-            cur = ops.conv3x3_pl(cur, None, self._packed(c2, W, CK), l2.bias.detach(), l2.out_channels, range_flag=rf, x_residual=XR)
+            cur = conv(cur, None, c2, l2, fmt=A, range_flag=rf)           # feeds the next transposed conv
         raise AssertionError("unreachable")
 
     def forward(self, x_in: torch.Tensor) -> torch.Tensor:

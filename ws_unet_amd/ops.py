@@ -86,7 +86,7 @@ def _launch(kernel: str, meta: dict, fn) -> int:
     return fn() if _timer is None else _timer.launch(kernel, meta, fn)
 
 
-def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+def _ptr(t) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
@@ -272,6 +272,78 @@ def planar_shape(n: int, c: int, h: int, w: int):
     return (n, c // 16, PLANAR_PLANES, h, w, 4)
 
 
+PLANAR_A, PLANAR_Q = 0, 1     # include/wsu.h WSU_PLANAR_*: the e4m3-residual planar format / the planar Q format of mode 'f16f4p'
+
+
+class PlanarQ:
+    """A planar Q activation tensor ('F16F4P' storage, include/wsu.h, round 4): per image and 16-channel chunk the planes f16 ch 0-7 | f16 ch
+    8-15 | Q (32 fp4 nibbles per pixel: the f16 parts and the residuals * 2^11, both over the block's power-of-two scale) as [H][W][16 B], then
+    one E8M0 scale byte per pixel in 16 x 32-pixel tile blocks.  `data`: uint8 (N, C/16, chunk_bytes).  Written by the producing kernel's
+    epilogue (conv3x3_q / convt2x2_pl / conv3x3_first_pl with y_format=PLANAR_Q), read by conv3x3_q; opaque to everything else."""
+    __slots__ = ("data", "n", "c", "h", "w")
+
+    def __init__(self, data: torch.Tensor, n: int, c: int, h: int, w: int):
+        self.data, self.n, self.c, self.h, self.w = data, n, c, h, w
+
+    @staticmethod
+    def chunk_bytes(h: int, w: int) -> int:
+        return 48 * h * w + 512 * ((h + 15) // 16) * ((w + 31) // 32)
+
+    @classmethod
+    def empty(cls, n: int, c: int, h: int, w: int, device) -> "PlanarQ":
+        assert c % 16 == 0
+        return cls(torch.empty((n, c // 16, cls.chunk_bytes(h, w)), dtype=torch.uint8, device=device), n, c, h, w)
+
+    @property
+    def device(self):
+        return self.data.device
+
+    def data_ptr(self) -> int:
+        return self.data.data_ptr()
+
+
+def _planar_out(fmt: int, n: int, c: int, h: int, w: int, device):
+    return PlanarQ.empty(n, c, h, w, device) if fmt == PLANAR_Q else torch.empty(planar_shape(n, c, h, w), dtype=torch.float32, device=device)
+
+
+def conv3x3_q(x1: PlanarQ, x2: Optional[PlanarQ], w_packed_f4: torch.Tensor, bias: Optional[torch.Tensor], cout: int,
+              relu: bool = True, pool: bool = False, want_y: bool = True,
+              head_w: Optional[torch.Tensor] = None, head_b: Optional[torch.Tensor] = None, want_logit: bool = False,
+              range_flag: Optional[torch.Tensor] = None, y_format: int = PLANAR_Q):
+    """3x3 reflect conv (+ReLU, +2x2 max-pool, +1x1 head and sigmoid) in the fp4-cross-term arithmetic on planar Q activations
+    (wsu_conv3x3_q_fwd, csrc/conv3x3_q.hip; the default inference mode 'f16f4p').  x1 / x2: PlanarQ; w_packed_f4 from pack_conv3x3_f4;
+    y / y_pool: PlanarQ (y_format=PLANAR_Q) or e4m3-residual planar tensors (PLANAR_A: what convt2x2_pl reads; always for a y beside the head).
+    Returns y [, y_pool] or, with head_w, out [, logit][, y]."""
+    lib = _lib.load()
+    hw2 = None if head_w is None else head_w.detach().reshape(head_w.shape[0], -1).contiguous()
+    assert isinstance(x1, PlanarQ) and (x2 is None or isinstance(x2, PlanarQ)), "conv3x3_q reads planar Q tensors (ops.PlanarQ)"
+    _dev_check(x1.data, None if x2 is None else x2.data, w_packed_f4, bias, hw2, head_b)
+    n, h, w, c1 = x1.n, x1.h, x1.w, x1.c
+    c2 = 0
+    if x2 is not None:
+        assert (x2.n, x2.h, x2.w) == (n, h, w)
+        c2 = x2.c
+    assert w_packed_f4.numel() * w_packed_f4.element_size() == int(lib.wsu_conv3x3_packed_f4_bytes(c1 + c2, cout)), "w_packed_f4 is not pack_conv3x3_f4 of (cin, cout)"
+    hc = 0 if hw2 is None else hw2.shape[0]
+    yf = PLANAR_A if hc else y_format
+    y = _planar_out(yf, n, cout, h, w, x1.device) if want_y else None
+    yp = _planar_out(yf, n, cout, h // 2, w // 2, x1.device) if pool else None
+    out = torch.empty((n, hc, h, w), dtype=torch.float32, device=x1.device) if hc else None
+    logit = torch.empty_like(out) if (hc and want_logit) else None
+    act = n * h * w * ((c1 + c2) + (cout if want_y else 0)) + (n * (h // 2) * (w // 2) * cout if pool else 0)     # planar elements read + written
+    meta = {"flops": 2.0 * 9 * (c1 + c2) * cout * n * h * w,
+            "bytes": float(act * 49 / 16 + n * h * w * hc * 4 + 9 * (c1 + c2) * cout * 28 / 9),
+            "bytes_2B": float(act * 2 + n * h * w * hc * 4 + 9 * (c1 + c2) * cout * 2),
+            "tiles": n * ((h + 15) // 16) * ((w + 31) // 32) * (cout // 64), "steps_per_tile": (c1 + c2) // 16}
+    check(_launch("conv3x3_q", meta, lambda: lib.wsu_conv3x3_q_fwd(
+        x1.data_ptr(), _ptr(x2), w_packed_f4.data_ptr(), _ptr(bias), _ptr(y), _ptr(yp), _ptr(hw2), _ptr(head_b), _ptr(out), _ptr(logit), hc,
+        n, h, w, c1, c2, cout, int(relu), yf, _ptr(range_flag), _stream())), "wsu_conv3x3_q_fwd")
+    if hc:
+        res = [out] + ([logit] if want_logit else []) + ([y] if want_y else [])
+        return res[0] if len(res) == 1 else tuple(res)
+    return (y, yp) if pool else y
+
+
 def conv3x3_pl(x1: torch.Tensor, x2: Optional[torch.Tensor], w_packed: torch.Tensor, bias: Optional[torch.Tensor], cout: int,
                relu: bool = True, pool: bool = False, want_y: bool = True,
                head_w: Optional[torch.Tensor] = None, head_b: Optional[torch.Tensor] = None, want_logit: bool = False,
@@ -321,6 +393,9 @@ def conv3x3_pl_fused_first(x_nchw: torch.Tensor, w1: torch.Tensor, b1: Optional[
     _dev_check(x_nchw, w1, b1, w_packed, bias)
     n, cin, h, w = x_nchw.shape
     assert cin == 1 and tuple(w1.shape) == (64, 1, 3, 3) and x_nchw.dtype == torch.float32 and x_nchw.is_contiguous()
+    # the fused kernel multiplies e4m3 cross terms: it reads the 36 KB (block, chunk) slices of pack_conv3x3(mode f16f8), not the fp4 packing
+    assert w_packed.numel() * w_packed.element_size() == int(lib.wsu_conv3x3_packed_bytes(64, cout, _lib.MODE_F16F8)), \
+        "conv3x3_pl_fused_first needs weights from pack_conv3x3(w, mode_id('f16f8'))"
     y = torch.empty(planar_shape(n, cout, h, w), dtype=torch.float32, device=x_nchw.device)
     yp = torch.empty(planar_shape(n, cout, h // 2, w // 2), dtype=torch.float32, device=x_nchw.device) if pool else None
     act = n * h * w * cout + (n * (h // 2) * (w // 2) * cout if pool else 0)
@@ -334,19 +409,20 @@ def conv3x3_pl_fused_first(x_nchw: torch.Tensor, w1: torch.Tensor, b1: Optional[
 
 
 def convt2x2_pl(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor], cout: int,
-                range_flag: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """nn.ConvTranspose2d(k=2, s=2) + bias on planar F16F8P activations (wsu_convt2x2_pl_fwd); w_packed from pack_convt2x2(mode f16f8)."""
+                range_flag: Optional[torch.Tensor] = None, y_format: int = PLANAR_A):
+    """nn.ConvTranspose2d(k=2, s=2) + bias on planar F16F8P activations (wsu_convt2x2_pl_fwd); w_packed from pack_convt2x2(mode f16f8).
+    y_format=PLANAR_Q: the result is a PlanarQ (the input of conv3x3_q)."""
     lib = _lib.load()
     _dev_check(x, w_packed, bias)
     assert x.dtype == torch.float32 and x.dim() == 6 and x.shape[2] == PLANAR_PLANES and x.shape[5] == 4 and x.is_contiguous()
     n, nch, _, h, w, _ = x.shape
     cin = nch * 16
-    y = torch.empty(planar_shape(n, cout, 2 * h, 2 * w), dtype=torch.float32, device=x.device)
+    y = _planar_out(y_format, n, cout, 2 * h, 2 * w, x.device)
     meta = {"flops": 2.0 * 4 * cin * cout * n * h * w, "bytes": float(n * h * w * (cin + 4 * cout) * 3 + 4 * cin * cout * 4),
             "bytes_2B": float(n * h * w * (cin + 4 * cout) * 2 + 4 * cin * cout * 2),
             "tiles": n * ((h + 3) // 4) * ((w + 31) // 32) * (cout // 64), "steps_per_tile": cin // 32}
     check(_launch("convt2x2_pl", meta, lambda: lib.wsu_convt2x2_pl_fwd(
-        x.data_ptr(), w_packed.data_ptr(), _ptr(bias), y.data_ptr(), n, h, w, cin, cout, _ptr(range_flag), _stream())), "wsu_convt2x2_pl_fwd")
+        x.data_ptr(), w_packed.data_ptr(), _ptr(bias), y.data_ptr(), n, h, w, cin, cout, y_format, _ptr(range_flag), _stream())), "wsu_convt2x2_pl_fwd")
     return y
 
 
@@ -357,19 +433,20 @@ def relu_mask_alloc(n: int, c: int, h: int, w: int, device) -> torch.Tensor:
 
 
 def conv3x3_first_pl(x_nchw: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], relu: bool = True,
-                     range_flag: Optional[torch.Tensor] = None, want_mask: bool = False):
-    """First layer (N, cin <= 8, H, W) fp32 -> planar F16F8P tensor with w.shape[0] channels (wsu_conv3x3_first_pl_fwd) [, its relu_mask plane]."""
+                     range_flag: Optional[torch.Tensor] = None, want_mask: bool = False, y_format: int = PLANAR_A):
+    """First layer (N, cin <= 8, H, W) fp32 -> planar F16F8P tensor with w.shape[0] channels (wsu_conv3x3_first_pl_fwd) [, its relu_mask plane];
+    y_format=PLANAR_Q: a PlanarQ."""
     lib = _lib.load()
     w = w.detach().contiguous()
     _dev_check(x_nchw, w, bias)
     n, cin, h, wd = x_nchw.shape
     cout = w.shape[0]
     assert x_nchw.dtype == torch.float32 and x_nchw.is_contiguous() and w.shape[1] == cin
-    y = torch.empty(planar_shape(n, cout, h, wd), dtype=torch.float32, device=x_nchw.device)
+    y = _planar_out(y_format, n, cout, h, wd, x_nchw.device)
     mask = relu_mask_alloc(n, cout, h, wd, x_nchw.device) if want_mask else None
     meta = {"flops": 2.0 * 9 * cin * cout * n * h * wd, "bytes": float(n * h * wd * (cin * 4 + cout * 3)), "bytes_2B": float(n * h * wd * (cin * 4 + cout * 2))}
     check(_launch("conv3x3_first_pl", meta, lambda: lib.wsu_conv3x3_first_pl_fwd(
-        x_nchw.data_ptr(), w.data_ptr(), _ptr(bias), y.data_ptr(), n, h, wd, cin, cout, int(relu), _ptr(range_flag), _ptr(mask), _stream())), "wsu_conv3x3_first_pl_fwd")
+        x_nchw.data_ptr(), w.data_ptr(), _ptr(bias), y.data_ptr(), n, h, wd, cin, cout, int(relu), y_format, _ptr(range_flag), _ptr(mask), _stream())), "wsu_conv3x3_first_pl_fwd")
     return (y, mask) if want_mask else y
 
 

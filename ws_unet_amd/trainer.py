@@ -85,10 +85,7 @@ class FlatAdamW:
         self.step_count += 1
         self._table.step(self.step_count, self.lr, self.betas, self.eps, self.weight_decay, grad_scale, skip_flag)
         if hasattr(self.model, "invalidate_packed"):
-            try:
-                self.model.invalidate_packed(recheck_range=False)        # flat update bypasses tensor version counters
-            except TypeError:
-                self.model.invalidate_packed()
+            self.model.invalidate_packed(recheck_range=False)            # flat update bypasses tensor version counters
 
     def forget_skipped(self, n: int) -> None:
         """`n` of the counted steps were suppressed on the device (skip_flag): the bias corrections follow the APPLIED updates, as
@@ -258,3 +255,23 @@ def resume(model: torch.nn.Module, run_dir: Path, device) -> int:
     ckpt = torch.load(Path(run_dir) / "model" / "best_model.pt.tar", map_location=device, weights_only=True)
     model.load_state_dict(ckpt["state_dict"])
     return int(ckpt["epoch"])
+
+
+def synthetic_pretrain(model: torch.nn.Module, steps: int = 300, batch: int = 8, size: int = 128, seed: int = 5, lr: float = 1e-3,
+                       loss: str = "l1ws") -> float:
+    """`steps` AdamW steps of this package's own training loop on synthetic cover / LSBR-stego pairs (formula.synthetic_images, every second
+    image embedded at alpha = 0.4; the pattern of detector/train.py:55-95 on one fixed batch).  Gives a model "trained-like" weights: the second
+    weight set the accuracy gate of the default inference mode is measured on besides the 'he' formula weights (the reference ships no UNet
+    checkpoint: .MISSING_LARGE_BLOBS:7-12) -- tests/test_gpu_round4.py, bench.py `mae_vs_cpu_oracle_trained`.  Returns the last loss."""
+    from . import formula
+    dev = next(model.parameters()).device
+    cov = formula.synthetic_images(batch, size, size, seed=seed)
+    st = np.stack([formula.lsbr_embed(c, 0.4, seed=i) if i % 2 else c for i, c in enumerate(cov)])
+    covers = ops.u8_to_unit(torch.from_numpy(cov).to(dev))[:, None].contiguous()
+    inputs = ops.u8_to_unit(torch.from_numpy(st).to(dev))[:, None].contiguous()
+    alphas = torch.tensor([0.4 if i % 2 else 0.0 for i in range(batch)], device=dev)
+    tr = Trainer(model, loss=loss, lr=lr)
+    last = None
+    for _ in range(steps):
+        last, _ = tr.train_step(inputs, covers, alphas)
+    return float(last.item())
