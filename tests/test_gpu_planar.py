@@ -280,171 +280,3 @@ def test_small_grid_split_equals_the_unsplit_kernel():
         assert rr.returncode == 0, rr.stderr[-2000:]
         outs.append(torch.load(out, weights_only=True)); os.remove(out)
     assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32))       # 8 tiles x 4 blocks = 32 items -> 64 half-items when split
-
-
-# ---- block-scaled fp4 cross terms (x_residual = 2, round 3) ---------------------------------------------------------------------------------
-def _fp4(v):
-    """round to the e2m1 grid {0, .5, 1, 1.5, 2, 3, 4, 6} (nearest even, saturating), as v_cvt_scalef32_pk_fp4_* does (tools/fp4_probe.hip)"""
-    a = v.abs()
-    e = torch.floor(torch.log2(a.clamp_min(1e-30))).clamp(0, 2)
-    step = torch.exp2(e - 1)
-    return torch.sign(v) * (torch.round(a / step) * step).clamp_max(6.0)
-
-
-def _q4_blocks(hpart, res2048, dim):
-    """hpart: the f16 parts, res2048: the residuals * 2^11, blocks of 16 along `dim` -> (fp4 copy, fp4 residual) at true scale / with the 2^-11 undone"""
-    shp = list(hpart.shape)
-    blk = shp[:dim] + [shp[dim] // 16, 16] + shp[dim + 1:]
-    hv, rv = hpart.reshape(blk), res2048.reshape(blk)
-    amax = hv.abs().amax(dim=dim + 1, keepdim=True)
-    # E = exponent field of the largest |f16| - 15 - 1 (zero / subnormal blocks: field 0), one less when that element's mantissa is <= 1.5
-    # (wsu_q4_block_exp: largest / 2^E in [2, 3) or [4, 6])
-    ef = torch.where(amax >= 2.0 ** -14, torch.floor(torch.log2(amax.clamp_min(1e-30))) + 15, torch.zeros_like(amax))
-    finer = (ef > 0) & (amax <= 1.5 * torch.exp2(ef - 15))
-    sc = torch.exp2(ef - 16 - finer.to(ef.dtype))
-    return (_fp4(hv / sc) * sc).reshape(shp), (_fp4(rv / sc) * sc / 2048.0).reshape(shp)
-
-
-def _conv3x3_q4_ref(x, w, b):
-    """the arithmetic of conv3x3_pl(..., x_residual=2) on the CPU, fp64 accumulation: x = what the planar tensor holds (f16 part + e4m3 residual)"""
-    xp = F.pad(x, (1, 1, 1, 1), mode="reflect")
-    xh = xp.half().float()
-    xr = ((xp - xh) * 4096).to(torch.float8_e4m3fn).float() / 4096                      # the stored residual
-    wh = w.half().float()
-    xc4, xr4 = _q4_blocks(xh, xr * 2048.0, 1)
-    wc4, wr4 = _q4_blocks(wh, (w - wh) * 2048.0, 1)
-    y = F.conv2d(xh.double(), wh.double(), b.double()) + F.conv2d(xc4.double(), wr4.double()) + F.conv2d(xr4.double(), wc4.double())
-    return y.float()
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("n,h,w,c1,c2,cout,pool", [
-    (1, 16, 32, 64, 0, 64, False),            # one tile, 4 chunk steps
-    (2, 40, 72, 64, 0, 128, False),           # partial tiles, 2 output blocks
-    (2, 32, 64, 64, 64, 64, True),            # fused concat + pool
-    (1, 96, 160, 128, 0, 64, False),          # several tiles per workgroup would need > 256 tiles: 30 tiles x 8 steps
-    (5, 128, 128, 32, 0, 64, False),          # 320 tiles of 2 steps: workgroups walk two tiles, the three-slot input ring wraps across tiles
-    (1, 2, 2, 16, 0, 64, False),              # one chunk per tile (J = 1)
-])
-def test_conv3x3_pl_q4_matches_emulation(n, h, w, c1, c2, cout, pool):
-    """x_residual = 2: f16 products on the f16 pipe + both cross terms as block-scaled fp4 -- equal to the CPU emulation of exactly that arithmetic
-    (block exponents from the largest f16 part, fp4 rounding to nearest even) up to accumulation order and the store encoding; and within
-    2e-3 of the exact convolution relative to the output's scale (the cross terms now carry ~3 bits instead of e4m3's 4)."""
-    from ws_unet_amd import ops
-    cin = c1 + c2
-    g = torch.Generator().manual_seed(7)
-    x = planar_decode(planar_encode(torch.relu(torch.randn((n, cin, h, w), generator=g)) * torch.exp2(torch.randint(-3, 4, (n, cin, 1, 1), generator=g).float())))
-    wgt = torch.randn((cout, cin, 3, 3), generator=g) * (2.0 / (9 * cin)) ** 0.5
-    b = torch.randn(cout, generator=g) * 0.1
-    ref = torch.relu(_conv3x3_q4_ref(x, wgt, b))
-    exact = torch.relu(F.conv2d(F.pad(x, (1, 1, 1, 1), mode="reflect").double(), wgt.double(), b.double())).float()
-    wp = ops.pack_conv3x3_f4(wgt.to(DEV))
-    x1 = planar_encode(x[:, :c1]).to(DEV)
-    x2 = planar_encode(x[:, c1:]).to(DEV) if c2 else None
-    out = ops.conv3x3_pl(x1, x2, wp, b.to(DEV), cout, pool=pool, x_residual=2)
-    torch.cuda.synchronize()
-    y = planar_decode(out[0] if pool else out)
-    scale = float(exact.abs().max())
-    assert float((y - ref).abs().max()) < 3e-5 * scale, float((y - ref).abs().max()) / scale
-    assert float((y - exact).abs().max()) < 2e-3 * scale, float((y - exact).abs().max()) / scale
-    if pool:
-        assert float((planar_decode(out[1]) - F.max_pool2d(y, 2)).abs().max()) == 0.0
-
-
-@pytest.mark.gpu
-def test_conv3x3_pl_q4_variants_and_repeatability():
-    """The other instantiations of the fp4 variant against the same emulation -- fused head (1 and 3 planes), small grids (half-block work items),
-    no ReLU -- and launch-to-launch repeatability of the three-slot / two-slot rings (a missing wait on a DMA piece or a register load shows as a
-    difference between launches)."""
-    from ws_unet_amd import ops
-    g = torch.Generator().manual_seed(11)
-    # fused head
-    for hc in (1, 3):
-        n, h, w, cin = 2, 24, 40, 64
-        x = planar_decode(planar_encode(torch.relu(torch.randn((n, cin, h, w), generator=g))))
-        wgt = torch.randn((64, cin, 3, 3), generator=g) * (2.0 / (9 * cin)) ** 0.5
-        b = torch.randn(64, generator=g) * 0.1
-        hw_, hb = torch.randn((hc, 64, 1, 1), generator=g) * 0.2, torch.randn(hc, generator=g) * 0.1
-        ref = torch.sigmoid(F.conv2d(torch.relu(_conv3x3_q4_ref(x, wgt, b)), hw_, hb))
-        out = ops.conv3x3_pl(planar_encode(x).to(DEV), None, ops.pack_conv3x3_f4(wgt.to(DEV)), b.to(DEV), 64, head_w=hw_.to(DEV), head_b=hb.to(DEV), want_y=False, x_residual=2)
-        torch.cuda.synchronize()
-        assert float((out.cpu() - ref).abs().max()) < 2e-5, (hc, float((out.cpu() - ref).abs().max()))
-        # the head together with the stored activations: the same bits as each alone
-        wp4 = ops.pack_conv3x3_f4(wgt.to(DEV))
-        out_y = ops.conv3x3_pl(planar_encode(x).to(DEV), None, wp4, b.to(DEV), 64, head_w=hw_.to(DEV), head_b=hb.to(DEV), want_y=True, x_residual=2)
-        y_alone = ops.conv3x3_pl(planar_encode(x).to(DEV), None, wp4, b.to(DEV), 64, x_residual=2)
-        assert torch.equal(out_y[0], out) and torch.equal(out_y[1].view(torch.int32), y_alone.view(torch.int32))
-    # pooled output alone (no full-resolution store: the split last step passes an empty buffer for it) = the pooled output of the full call, ragged tile edges
-    n, h, w, cin = 3, 40, 72, 64
-    xe = planar_encode(torch.relu(torch.randn((n, cin, h, w), generator=g))).to(DEV)
-    wp4 = ops.pack_conv3x3_f4((torch.randn((64, cin, 3, 3), generator=g) * (2.0 / (9 * cin)) ** 0.5).to(DEV))
-    bz = (torch.randn(64, generator=g) * 0.1).to(DEV)
-    y_full, yp_full = ops.conv3x3_pl(xe, None, wp4, bz, 64, pool=True, x_residual=2)
-    y_none, yp_only = ops.conv3x3_pl(xe, None, wp4, bz, 64, pool=True, want_y=False, x_residual=2)
-    assert y_none is None and torch.equal(yp_only.view(torch.int32), yp_full.view(torch.int32))
-    # small grid: 2 x (32 x 32) x 128 channels = 16 tiles -> half-block work items (kernel variant MSPLIT); and no ReLU
-    n, h, w, cin, cout = 2, 32, 32, 128, 128
-    x = planar_decode(planar_encode(torch.randn((n, cin, h, w), generator=g)))
-    wgt = torch.randn((cout, cin, 3, 3), generator=g) * (2.0 / (9 * cin)) ** 0.5
-    b = torch.randn(cout, generator=g) * 0.1
-    ref = _conv3x3_q4_ref(x, wgt, b)
-    y = planar_decode(ops.conv3x3_pl(planar_encode(x).to(DEV), None, ops.pack_conv3x3_f4(wgt.to(DEV)), b.to(DEV), cout, relu=False, x_residual=2))
-    assert float((y - ref).abs().max()) < 3e-5 * float(ref.abs().max())
-    # repeatability at a size where every workgroup walks several tiles of 4 and of 16 steps
-    for (n, s, cin, cout, pool) in ((8, 256, 64, 64, True), (4, 128, 256, 128, False)):
-        xe = planar_encode(torch.relu(torch.randn((n, cin, s, s), generator=g))).to(DEV)
-        wp = ops.pack_conv3x3_f4((torch.randn((cout, cin, 3, 3), generator=g) * 0.05).to(DEV))
-        bz = torch.zeros(cout, device=DEV)
-        first = ops.conv3x3_pl(xe, None, wp, bz, cout, pool=pool, x_residual=2)
-        first = [t.clone() for t in (first if pool else (first,))]
-        for _ in range(10):
-            again = ops.conv3x3_pl(xe, None, wp, bz, cout, pool=pool, x_residual=2)
-            again = again if pool else (again,)
-            for a_, f_ in zip(again, first):
-                assert torch.equal(a_.view(torch.int32), f_.view(torch.int32))
-
-
-@pytest.mark.gpu
-def test_conv3x3_pl_q4_argument_errors():
-    """The fp4 variant's entry points refuse what they do not implement, with a message (no silent fallback)."""
-    from ws_unet_amd import ops, _lib
-    with pytest.raises(_lib.WsuError, match="fp4 packing"):
-        ops.pack_conv3x3_f4(torch.zeros((64, 8, 3, 3), device=DEV))                 # cin not a multiple of 16
-    with pytest.raises(_lib.WsuError, match="fp4 packing"):
-        ops.pack_conv3x3_f4(torch.zeros((32, 16, 3, 3), device=DEV))                # cout not a multiple of 64
-    x = planar_encode(torch.zeros((1, 16, 8, 8))).to(DEV)
-    wp = ops.pack_conv3x3_f4(torch.zeros((64, 16, 3, 3), device=DEV))
-    with pytest.raises(_lib.WsuError, match="relu_mask_out"):
-        ops.conv3x3_pl(x, None, wp, None, 64, x_residual=2, want_mask=True)         # the training forward's mask planes come from the e4m3 variant
-    with pytest.raises(_lib.WsuError, match="x_residual"):
-        ops.conv3x3_pl(x, None, wp, None, 64, x_residual=3)
-
-
-@pytest.mark.gpu
-def test_conv3x3_pl_q4_random_shapes():
-    """A dozen randomly drawn problem shapes (fixed seed): image sizes that are not multiples of the 16 x 32 tile, 1-6 chunks per source, fused
-    concat, pool on even sizes, 1-3 output blocks, negative inputs -- the fp4 variant against the CPU emulation of its arithmetic."""
-    from ws_unet_amd import ops
-    rng = np.random.default_rng(20261004)
-    g = torch.Generator().manual_seed(5)
-    import os
-    for _ in range(int(os.environ.get("WSU_TEST_SWEEP", "12"))):       # (WSU_TEST_SWEEP=300: the one-off sweep recorded in profiles/r03/f16f4p.md)
-        n = int(rng.integers(1, 4)); h = int(rng.integers(2, 70)); w = int(rng.integers(2, 90))
-        c1 = 16 * int(rng.integers(1, 7)); c2 = 16 * int(rng.integers(0, 4)); cout = 64 * int(rng.integers(1, 4))
-        pool = bool(rng.integers(0, 2)) and h % 2 == 0 and w % 2 == 0
-        relu = bool(rng.integers(0, 2))
-        cin = c1 + c2
-        x = planar_decode(planar_encode(torch.randn((n, cin, h, w), generator=g) * torch.exp2(torch.randint(-6, 5, (n, 1, h, w), generator=g).float())))
-        wgt = torch.randn((cout, cin, 3, 3), generator=g) * (2.0 / (9 * cin)) ** 0.5
-        b = torch.randn(cout, generator=g) * 0.1
-        ref = _conv3x3_q4_ref(x, wgt, b)
-        ref = torch.relu(ref) if relu else ref
-        out = ops.conv3x3_pl(planar_encode(x[:, :c1]).to(DEV), planar_encode(x[:, c1:]).to(DEV) if c2 else None, ops.pack_conv3x3_f4(wgt.to(DEV)), b.to(DEV), cout,
-                             relu=relu, pool=pool, x_residual=2)
-        torch.cuda.synchronize()
-        y = planar_decode(out[0] if pool else out)
-        scale = float(ref.abs().max())
-        err = float((y - ref).abs().max())
-        assert err < 3e-5 * scale, (n, h, w, c1, c2, cout, pool, relu, err / scale)
-        if pool:
-            assert float((planar_decode(out[1]) - F.max_pool2d(y, 2)).abs().max()) == 0.0

@@ -210,8 +210,14 @@ def test_conv3x3_q_variants_and_repeatability():
 def test_conv3x3_q_argument_errors():
     """The entry points refuse what they do not implement, with a message (no silent fallback)."""
     from ws_unet_amd import ops, _lib
+    with pytest.raises(_lib.WsuError, match="fp4 packing"):
+        ops.pack_conv3x3_f4(torch.zeros((64, 8, 3, 3), device=DEV))                 # cin not a multiple of 16
+    with pytest.raises(_lib.WsuError, match="fp4 packing"):
+        ops.pack_conv3x3_f4(torch.zeros((32, 16, 3, 3), device=DEV))                # cout not a multiple of 64
     x = planar_q_encode(torch.zeros((1, 16, 8, 8)))
     wp = ops.pack_conv3x3_f4(torch.zeros((64, 16, 3, 3), device=DEV))
+    with pytest.raises(_lib.WsuError, match="wsu_conv3x3_q_fwd"):                    # round 3's x_residual = 2 of the e4m3 kernel is gone, loudly
+        ops.conv3x3_pl(planar_encode(torch.zeros((1, 16, 8, 8))), None, wp, None, 64, x_residual=2)
     with pytest.raises(_lib.WsuError, match="y_format"):
         ops.conv3x3_q(x, None, wp, None, 64, y_format=7)
     with pytest.raises(AssertionError, match="PlanarQ"):

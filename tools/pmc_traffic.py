@@ -28,9 +28,9 @@ def per_launch(path, counter, kernel):
 
 def main():
     fetch_csv, write_csv, out = sys.argv[1:4]
-    kernel = sys.argv[4] if len(sys.argv) > 4 else "conv3x3_pl_kernel"
-    mode = sys.argv[5] if len(sys.argv) > 5 else "f16f8p"
-    source = "conv3x3_pl.hip" if "conv3x3_pl" in kernel else "conv3x3.hip"
+    kernel = sys.argv[4] if len(sys.argv) > 4 else "conv3x3_q_kernel"
+    mode = sys.argv[5] if len(sys.argv) > 5 else "f16f4p"
+    source = "conv3x3_q.hip" if "conv3x3_q" in kernel else "conv3x3_pl.hip" if "conv3x3_pl" in kernel else "conv3x3.hip"
     f = per_launch(fetch_csv, "FETCH_SIZE", kernel)
     w = per_launch(write_csv, "WRITE_SIZE", kernel)
     assert f and w and len(f) == len(w), (len(f), len(w))

@@ -13,7 +13,7 @@ libs = [a for a in sys.argv[1:] if a.endswith(".so")]
 if libs:
     _lib.LIB_PATH = Path(_lib.LIB_PATH).parent / libs[0]
 XRES = "--xres0" not in sys.argv
-Q4 = "--q4" in sys.argv                      # the product's block-scaled fp4 variant (x_residual = 2, weights from pack_conv3x3_f4)
+Q4 = False                                # (the fp4 variant moved to csrc/conv3x3_q.hip in round 4; its probe build: make qprobe16)
 ZEROS = "--zeros" in sys.argv                # all-zero activations and weights: the same instruction stream with (almost) no switching in the data paths --
                                              # what the kernel would do if it were not power-managed (profiles/r03/conv3x3_pl_last_step.md)
 from ws_unet_amd import ops
@@ -35,7 +35,7 @@ def run(cin, cout, hw, n=32, c2=0, pool=False):
         if x2 is not None: x2.zero_()
     b = torch.zeros(cout, device="cuda")
     wp = ops.pack_conv3x3_f4(w) if Q4 else ops.pack_conv3x3(w, M)
-    fn = lambda: ops.conv3x3_pl(x1, x2, wp, b, cout, pool=pool, x_residual=2 if Q4 else XRES)
+    fn = lambda: ops.conv3x3_pl(x1, x2, wp, b, cout, pool=pool, x_residual=XRES)
     for _ in range(3):
         fn()
     torch.cuda.synchronize()

@@ -1,12 +1,12 @@
 # SQ counter passes on the PRODUCT binaries (VERDICT r02 missing #4): rocprofv3 --pmc only (no trace flags), the program directly after `--`.
-# Run on the GPU box from the repo root: tools/profile_sq.sh [tag]; summaries land in gpurun_out/sq_<tag>/ -> copy into profiles/r03/.
+# Run on the GPU box from the repo root: tools/profile_sq.sh [tag]; summaries land in gpurun_out/sq_<tag>/ -> copy into profiles/rNN/.
 set -e
 R=$GRAFT_REPO_ROOT; [ -n "$R" ] || R=$(pwd)
 TAG=${1:-base}
 O=$R/gpurun_out/sq_$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-B="--no-other-modes --no-cpu-baseline --no-train-step --no-latency --steps 3 --warmup 1"
+B="--no-other-modes --no-cpu-baseline --no-train-step --no-latency --no-trained-mae --steps 3 --warmup 1"
 # 8 SQ slots per pass; GRBM_GUI_ACTIVE (effective clock) rides on the GRBM block
 timeout -k 10 300 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_VALU_MFMA_MOPS_F8 GRBM_GUI_ACTIVE -d $O/fwd1 -o bench --output-format csv -- python3 $R/bench.py $B > $O/fwd1.log 2>&1 || { tail -5 $O/fwd1.log; echo "fwd pass 1 failed (counter names?)"; }
 echo "fwd pass 1 done"

@@ -10,7 +10,7 @@ _lib.LIB_PATH = Path(_lib.LIB_PATH).parent / "libwsu_plstamp.so"          # `mak
 from ws_unet_amd import ops
 sys.path.insert(0, str(Path(__file__).resolve().parent))
 from time_pl import enc_planar          # noqa: E402  (runs nothing: time_pl guards its main)
-Q4 = "--q4" in sys.argv; POOL = "--pool" in sys.argv
+Q4 = False; POOL = "--pool" in sys.argv          # (the fp4 variant moved to csrc/conv3x3_q.hip in round 4: it carries no stamps)
 pos = [a for a in sys.argv[1:] if not a.startswith("--")]
 cin, cout, hw = int(pos[0]), int(pos[1]), int(pos[2])
 c2 = int(pos[3]) if len(pos) > 3 else 0
@@ -24,7 +24,7 @@ p1 = act(cin - c2); p2 = act(c2) if c2 else None
 w = torch.randn(cout, cin, 3, 3, device="cuda", generator=g) * (2.0 / (9 * cin)) ** 0.5
 wp = ops.pack_conv3x3_f4(w) if Q4 else ops.pack_conv3x3(w, M); b = torch.zeros(cout, device="cuda")
 for _ in range(20):
-    ops.conv3x3_pl(p1, p2, wp, b, cout, pool=POOL, x_residual=2 if Q4 else 1)
+    ops.conv3x3_pl(p1, p2, wp, b, cout, pool=POOL, x_residual=1)
 torch.cuda.synchronize()
 lib = _lib.load()
 buf = (ctypes.c_ulonglong * (256 * 8))()

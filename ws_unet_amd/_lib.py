@@ -23,7 +23,7 @@ LIB_PATH = _HERE / "libwsu.so"
 MODE_F32, MODE_BF16X3, MODE_BF16, MODE_BF16X3S, MODE_F16F8, MODE_F16F8X = 0, 1, 2, 3, 4, 5
 MODE_F16F8P = 6          # host-side names only: the planar inference path has its own entry points (wsu_*_pl_fwd), no `mode` argument
 MODE_F16F8Q = 7          # f16f8p with x_residual = 0 on the first conv of every decoder block
-MODE_F16F4P = 8          # f16f8p storage; the 3x3 convs multiply their cross terms as block-scaled fp4 (wsu_conv3x3_pl_fwd x_residual = 2)
+MODE_F16F4P = 8          # planar Q storage; the 3x3 convs multiply their cross terms as block-scaled fp4 (wsu_conv3x3_q_fwd)
 MODES = {"f32": MODE_F32, "bf16x3": MODE_BF16X3, "bf16": MODE_BF16, "bf16x3s": MODE_BF16X3S, "f16f8": MODE_F16F8, "f16f8x": MODE_F16F8X, "f16f8p": MODE_F16F8P, "f16f8q": MODE_F16F8Q,
          "f16f4p": MODE_F16F4P}
 

@@ -21,19 +21,6 @@
 #include "wsu_device.h"
 #include <cstdlib>
 
-#ifndef WSU_PL_EPO
-#define WSU_PL_EPO 1            // 1 = the Q4 variants overlap the first half of a tile's epilogue with the second half of its last step (see `EPO` in the kernel)
-#endif
-#ifndef WSU_PL_EPO_FENCE
-#define WSU_PL_EPO_FENCE 0      // experiment: 1 = one scheduling region per tap pair in the fused part of the last step (measured 0-1 % slower than leaving it to the scheduler)
-#endif
-#ifndef WSU_PL_EPO_HEAD
-#define WSU_PL_EPO_HEAD 0       // experiment: 1 = the head variants, too (their epilogue stores nothing: d42 + head measured 4-6 % slower with the split last step)
-#endif
-#ifndef WSU_PL_OPAQUE_HH
-#define WSU_PL_OPAQUE_HH 0      // experiment: 1 = the e4m3 variants, too, recompute their tap-pair offsets per step (see hh_q in the kernel)
-#endif
-
 namespace {
 
 constexpr int TW = 32, TH = 16, IW = TW + 2, IH = TH + 2;
@@ -51,19 +38,6 @@ constexpr int LDS_IN_H = 2 * PLANE;                       // 19584
 constexpr int STAGE_H = LDS_IN_H + 9 * 2 * WSU_COB * 16;  // 38016
 constexpr int NSTAGE_H = 4;
 static_assert(NSTAGE_H * STAGE_H <= 2 * STAGE, "the HONLY stages live in the two full stages' LDS");
-// Q4 (round 3, kernel variant of the forward): the two cross terms as ONE block-scaled fp4 (e2m1) MFMA operand pair -- a 16-byte granule per
-// (pixel, chunk) = fp4(f16 part) x 16 | fp4(residual * 2^11) x 16 with one E8M0 scale byte, derived by the loader waves from the three stored
-// granules; weights from wsu_conv3x3_pack_f4 ([tap][f16 ci 0-7 | f16 ci 8-15 | fp4(residual * 2^11) x 16 | fp4(f16 part) x 16][64 co] + a scale
-// byte per (tap, co)).  5 fp4 instructions of 32 cycles instead of 64: 14 instead of 19 matrix units per chunk; 27 instead of 36 KB of weights per
-// step.  The derivation needs all three planes of a pixel in ONE lane and time to run: the input pieces are assigned by segment (a lane fetches
-// planes 0 / 1 of its pixels by LDS-DMA and their residual granules into registers) and travel TWO steps ahead into a ring of three input slots,
-// the weights one step ahead into two slots -- the loader converts step j+1's pixels while the matrix waves multiply step j.
-constexpr int Q4_IN_SLOT = 3 * PLANE + 640;                // f16 ch 0-7 | f16 ch 8-15 | Q | S (612 scale bytes) = 30016
-constexpr int Q4_W_GRAN = 9 * 3 * WSU_COB * 16;            // 27648
-constexpr int Q4_W_SLOT = Q4_W_GRAN + 1024;                // + [9][64] scale bytes, padded to a DMA piece: 28672 = the packed slice of a (block, chunk)
-constexpr int Q4_NIN = 3, Q4_NW = 2;
-constexpr int Q4_W_BASE = Q4_NIN * Q4_IN_SLOT;             // 90048
-static_assert(Q4_W_BASE + Q4_NW * Q4_W_SLOT <= 2 * STAGE && Q4_W_SLOT % 1024 == 0 && (Q4_W_SLOT / 1024) % 4 == 0, "Q4 rings live in the two stages' LDS; 28 weight pieces = 7 per loader wave");
 constexpr int NWAVE = 8, NLOAD = 4, NT = (NWAVE + NLOAD) * 64;      // 8 matrix waves + 4 loader waves (one per SIMD)
 constexpr int IN_SEG = (NPIX + 63) / 64;                  // 10 wave-instructions per plane (the last one 36 lanes wide)
 constexpr int HBM_PLANES = 3;                             // stored planes per chunk: f16 ch 0-7 | f16 ch 8-15 | e4m3 residuals; LDS plane 3 is derived
@@ -104,7 +78,6 @@ struct PlArgs {
     unsigned char* relu_mask_out; const unsigned char* mbits; const unsigned char* mbits2;
     int msplit;                                           // 1: work items are half-blocks of 32 output channels (kernel variant MSPLIT); ncb = 2 * cout / 64
     int honly;                                            // GRAD, 1: f16 products only (kernel variant HONLY; wsu.h "products" of the backward entry points)
-    int q4;                                               // forward, 1: block-scaled fp4 cross terms (kernel variant Q4; weights from wsu_conv3x3_pack_f4)
 };
 
 struct Tile { int n, y0, x0, cb, mh; };                   // mh: the 32-channel half of block cb this item computes (kernel variant MSPLIT), else 0
@@ -471,139 +444,6 @@ __device__ __forceinline__ void pl_loader(const PlArgs& a, char* smem, int lane,
 }
 
 
-// ================= loader wave LW of the Q4 variant (see the Q4 notes at the top) ==========================================================
-#define WSU_VMCNT_CASE(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); break;
-__device__ __forceinline__ void wsu_wait_vmcnt(int n) {      // all but the n youngest vector-memory operations of this wave have completed
-    switch (n) {
-        WSU_VMCNT_CASE(0) WSU_VMCNT_CASE(1) WSU_VMCNT_CASE(2) WSU_VMCNT_CASE(3) WSU_VMCNT_CASE(4) WSU_VMCNT_CASE(5) WSU_VMCNT_CASE(6) WSU_VMCNT_CASE(7)
-        WSU_VMCNT_CASE(8) WSU_VMCNT_CASE(9) WSU_VMCNT_CASE(10) WSU_VMCNT_CASE(11) WSU_VMCNT_CASE(12) WSU_VMCNT_CASE(13) WSU_VMCNT_CASE(14) WSU_VMCNT_CASE(15)
-        WSU_VMCNT_CASE(16) WSU_VMCNT_CASE(17) WSU_VMCNT_CASE(18) WSU_VMCNT_CASE(19) WSU_VMCNT_CASE(20) WSU_VMCNT_CASE(21) WSU_VMCNT_CASE(22) WSU_VMCNT_CASE(23)
-        WSU_VMCNT_CASE(24) WSU_VMCNT_CASE(25) WSU_VMCNT_CASE(26) WSU_VMCNT_CASE(27) WSU_VMCNT_CASE(28) WSU_VMCNT_CASE(29) WSU_VMCNT_CASE(30) WSU_VMCNT_CASE(31)
-        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    }
-}
-typedef __attribute__((ext_vector_type(4))) int i32x4_t;
-
-template <int LW>
-__device__ __forceinline__ void pl_loader_q4(const PlArgs& a, char* smem, int lane, int lw, int G, int J) {
-    constexpr int NSEG = LW < 2 ? 3 : 2;                              // this wave's 64-pixel segments of the 612-pixel input tile: LW, LW + 4, LW + 8
-    constexpr int NW = Q4_W_SLOT / 1024 / NLOAD;                      // 7 weight pieces per step
-    constexpr int NIN = 3 * NSEG;                                     // vector-memory operations of an input issue: 2 DMA pieces + 1 register load per segment
-    lds_char* smem3 = (lds_char*)smem;
-    const unsigned hw16 = (unsigned)(a.h * a.w) * 16u;
-    unsigned voff[NSEG];                                              // per segment: this lane's pixel inside a plane (the issue cursor's tile)
-    auto plan = [&](const Tile& t) __attribute__((always_inline)) {
-        WSU_STATIC_FOR(NSEG, k, {
-            const int idx = min((LW + NLOAD * k) * 64 + lane, NPIX - 1);
-            const int r = idx / IW, c = idx - r * IW;
-            const int yy = wsu_reflect(t.y0 - 1 + r, a.h), xx = wsu_reflect(t.x0 - 1 + c, a.w);
-            voff[k] = (unsigned)(yy * a.w + xx) * 16u;
-        });
-    };
-    // residual granules of the step being fetched / the step being converted: two register sets addressed at COMPILE time (the step loop below is
-    // unrolled by two) -- a run-time index put them, and the operation counters of the vmcnt arithmetic, into scratch memory
-    u32x4 rres[2][NSEG];
-    Tile ti = tile_of(a, lw); int ci = 0, kti = 0;                    // cursor of the input issue
-    int cbw = ti.cb, cw = 0, ktw = 0;                                 // cursor of the weight issue (block, chunk)
-    auto issue_in = [&](auto par, int s) __attribute__((always_inline)) {
-        constexpr int P = decltype(par)::value;
-        const unsigned plane3 = hw16 * HBM_PLANES;
-        const char* in_src = ci < a.nch1 ? a.x1 + ((size_t)ti.n * a.nch1 + ci) * plane3 : a.x2 + ((size_t)ti.n * (a.nch - a.nch1) + (ci - a.nch1)) * plane3;
-        const auto rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(in_src), 0, (int)plane3, 0x00020000);
-        lds_char* slot = smem3 + (s % Q4_NIN) * Q4_IN_SLOT;
-        WSU_STATIC_FOR(NSEG, k, {
-            constexpr int seg = LW + NLOAD * k;
-            const bool live = seg < IN_SEG - 1 || lane < NPIX - (IN_SEG - 1) * 64;
-            if (live) {
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void*)(slot + seg * 1024), 16, voff[k], 0, 0, 0);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void*)(slot + PLANE + seg * 1024), 16, voff[k], (int)hw16, 0, 0);
-            }
-            rres[P][k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)voff[k], (int)(2u * hw16), 0));
-        });
-        if (++ci == a.nch && s + 1 < J) { ci = 0; ++kti; ti = tile_of(a, lw + kti * G); plan(ti); }
-    };
-    auto issue_w = [&](int s) __attribute__((always_inline)) {
-        const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(a.wp), 0, 0x7FFFFFF0, 0x00020000);
-        const int w_base = (cbw * a.nch + cw) * Q4_W_SLOT;
-        lds_char* slot = smem3 + Q4_W_BASE + (s % Q4_NW) * Q4_W_SLOT;
-        WSU_STATIC_FOR(NW, k, {
-            constexpr int piece = LW + NLOAD * k;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void*)(slot + piece * 1024), 16, (unsigned)lane * 16u, w_base + piece * 1024, 0, 0);
-        });
-        if (++cw == a.nch && s + 1 < J) { cw = 0; ++ktw; cbw = tile_of(a, lw + ktw * G).cb; }
-    };
-    auto derive = [&](auto par, int s) __attribute__((always_inline)) {  // Q granule + scale byte of this lane's pixels of step s (planes 0 / 1 landed in LDS, residuals in registers)
-        constexpr int P = decltype(par)::value;
-        if (a.ablate & 8) return;                                     // timing only
-        char* slot = smem + (s % Q4_NIN) * Q4_IN_SLOT;
-        WSU_STATIC_FOR(NSEG, k, {
-            constexpr int seg = LW + NLOAD * k;
-            const int idx = seg * 64 + lane;
-            if (seg < IN_SEG - 1 || idx < NPIX) {
-                const u32x4 h0 = *reinterpret_cast<const u32x4*>(slot + idx * 16), h1 = *reinterpret_cast<const u32x4*>(slot + PLANE + idx * 16);
-                uint32_t sb;
-                const u32x4 q = wsu_q4_encode_x(h0, h1, rres[P][k], &sb);
-                *reinterpret_cast<u32x4*>(slot + 2 * PLANE + idx * 16) = q;
-                *reinterpret_cast<unsigned char*>(slot + 3 * PLANE + idx) = (unsigned char)sb;
-            }
-        });
-    };
-    // vmcnt arithmetic: a wave issues, per step, NW weight operations and then NIN input operations (NSEG x (2 DMA pieces + 1 register load));
-    // `s_waitcnt vmcnt(n)` = all but the n youngest have completed
-    auto wait_all_but = [&](bool in_behind, int base) __attribute__((always_inline)) {
-        if (in_behind) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NIN + NW) : "memory");   // (only used with base = NW)
-        else if (base) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NW) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    };
-    if (J <= 0) return;
-    const std::integral_constant<int, 0> even{}; const std::integral_constant<int, 1> odd{};
-    plan(ti);
-    issue_w(0);
-    issue_in(even, 0);
-    if (J > 1) issue_in(odd, 1);
-    if (J > 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NIN) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // step 0's inputs (its weights are older)
-    derive(even, 0);
-    // one step: barrier j, then issue W(j+1), IN(j+2), convert step j+1 (its inputs were issued a whole step ago), wait for W(j+1)
-    [[maybe_unused]] unsigned long long q0 = 0, q1 = 0, q2 = 0, q3 = 0, q4 = 0, q5 = 0, t_bar = 0, t_issue = 0, t_win = 0, t_derive = 0, t_ww = 0, t0 = 0, rt0 = 0;   // stamps build only
-    STAMP(t0);
-#ifdef WSU_PL_STAMPS
-    rt0 = __builtin_amdgcn_s_memrealtime();
-#endif
-    auto step = [&](auto par, int j) __attribute__((always_inline)) -> bool {       // par = parity of j; returns false after the last barrier
-        constexpr int P = decltype(par)::value;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // this wave's Q / S of step j are written
-        STAMP(q0);
-        __builtin_amdgcn_s_barrier();                                 // barrier j: step j is complete in LDS; every matrix wave has left step j - 1
-        asm volatile("" ::: "memory");
-        STAMP(q1);
-        if (j + 1 >= J) return false;
-        issue_w(j + 1);                                               // its slot held step j - 1
-        const bool more = j + 2 < J;
-        if (more) issue_in(par, j + 2);                               // (same parity as j) its slot held step j - 1
-        STAMP(q2);
-        wait_all_but(more, NW);                                       // step j + 1's inputs: younger are W(j+1) and, if issued, IN(j+2)
-        STAMP(q3);
-        derive(std::integral_constant<int, 1 - P>{}, j + 1);
-        STAMP(q4);
-        if (more) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NIN) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // step j + 1's weights
-        STAMP(q5);
-        t_bar += q1 - q0; t_issue += q2 - q1; t_win += q3 - q2; t_derive += q4 - q3; t_ww += q5 - q4;
-        return true;
-    };
-    for (int j = 0; ; j += 2) {
-        if (!step(even, j)) break;
-        if (!step(odd, j + 1)) break;
-    }
-#ifdef WSU_PL_STAMPS
-    if (lane == 0 && LW == 0 && blockIdx.x < 32) {
-        unsigned long long* d = g_pl_stamps + (blockIdx.x * 2 + 1) * 8;
-        d[0] = __builtin_amdgcn_s_memtime() - t0; d[1] = __builtin_amdgcn_s_memrealtime() - rt0;
-        d[2] = t_win; d[3] = t_bar; d[4] = t_issue; d[5] = t_derive; d[6] = t_ww; d[7] = (unsigned long long)J;
-    }
-    if (lane == 0 && blockIdx.x >= 64 && blockIdx.x < 128) g_pl_stamps[(blockIdx.x * 2 + 1) * 8 + LW] = t_bar;      // per-wave barrier waits (blocks 64-127)
-#endif
-}
-
 // HEAD / POOL are compile-time: the kernel sits at the 168-register step (three waves per SIMD), and the head's partial sums or the pool's
 // exchange registers would otherwise be carried -- and spilled -- by the variants that do not use them.
 // XRES = false: the activations' residual plane is neither loaded nor multiplied (one cross term per product, the weights' residual:
@@ -617,10 +457,10 @@ __device__ __forceinline__ void pl_loader_q4(const PlArgs& a, char* smem, int la
 // CUs with half the matrix work per step each; the input tile and the whole 64-channel weight slice are fetched as before.
 // HONLY (round 3, a training arithmetic of the data gradient: wsu.h "products"): f16 products only -- the 9 f16 instructions of a chunk, no
 // cross terms; the residual plane of the gradient, the e4m3 weight planes and the derived plane are neither fetched nor built (needs XRES = false).
-template <int HC, bool POOL, bool XRES = true, bool F1 = false, bool GRAD = false, bool MSPLIT = false, bool HONLY = false, bool Q4 = false>   // HC = head planes compiled in: 0 (no head), 1 (the reference's single output plane) or 4 (1..4)
-// (EPO variants: the loop nest needs ~125 registers and the compiler then schedules for FOUR waves per SIMD, which the 157 KB of LDS rule out anyway;
-// told that three is all there will be, it uses ~160 and prefetches fragments further ahead: -0.9 % per layer)
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3, (WSU_PL_EPO && Q4 && !MSPLIT && (WSU_PL_EPO_HEAD || HC == 0)) ? 3 : 8)))
+// (Round 3's Q4 variant -- block-scaled fp4 cross terms with the fp4 operands derived by the loader waves -- moved to csrc/conv3x3_q.hip in round 4, where
+// the producers store those operands: the default inference mode no longer runs this kernel; training forwards, the data gradient and 'f16f8p' do.)
+template <int HC, bool POOL, bool XRES = true, bool F1 = false, bool GRAD = false, bool MSPLIT = false, bool HONLY = false>   // HC = head planes compiled in: 0 (no head), 1 (the reference's single output plane) or 4 (1..4)
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3, 8)))
 void conv3x3_pl_kernel(const PlArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -664,15 +504,7 @@ void conv3x3_pl_kernel(const PlArgs a) {
 
     if (wv >= NWAVE) {
         // ================= loader waves (pl_loader<LW, ...>: the slot geometry of a wave is compile-time) ===========================
-        if constexpr (Q4) {
-            static_assert(!Q4 || (XRES && !F1 && !GRAD && !HONLY), "Q4 is a variant of the forward");
-            switch (wv - NWAVE) {
-                case 0: pl_loader_q4<0>(a, smem, lane, lw, G, J); break;
-                case 1: pl_loader_q4<1>(a, smem, lane, lw, G, J); break;
-                case 2: pl_loader_q4<2>(a, smem, lane, lw, G, J); break;
-                default: pl_loader_q4<3>(a, smem, lane, lw, G, J); break;
-            }
-        } else if constexpr (F1) {
+        if constexpr (F1) {
             pl_loader<0, XRES, F1, GRAD, HONLY>(a, smem, lane, lw, G, J, wv - NWAVE);
         } else {
             switch (wv - NWAVE) {
@@ -691,13 +523,6 @@ void conv3x3_pl_kernel(const PlArgs a) {
 #endif
     Tile cur = tile_of(a, lw);
     constexpr int MH = MSPLIT ? 1 : 2;                                        // accumulator tiles along the output channels
-    // EPO (round 3): while a tile's epilogue runs -- ~6.6 vector instructions per stored value -- the matrix pipe of the SIMD idles (both of its
-    // matrix waves are in the epilogue at the same time).  The last step of a tile is therefore split by accumulator tile: m = 0 first, then the
-    // units of m = 1 in ONE basic block with the epilogue of m = 0 (stores predicated by out-of-range buffer offsets instead of branches), so that
-    // each wave has matrix instructions in flight while it encodes.  Same-box A/B of the whole net: +1.2-1.5 % (profiles/r03/conv3x3_pl_last_step.md,
-    // which also shows why no more: on real data this kernel runs against the chip's power management -- the same binary on all-zero operands
-    // is 27-31 % faster).
-    constexpr bool EPO = WSU_PL_EPO && Q4 && !MSPLIT && (WSU_PL_EPO_HEAD || HC == 0);
     f32x16 acc[2][2];                                                         // [MH][2] used (declared with the template-dependent bound, hipcc (ROCm 7.2)
                                                                               // silently emits no host stub for ANY instantiation of the kernel)
     const int sc_a = hh ? WSU_F8_SCALE_WLO : WSU_F8_SCALE_W;
@@ -705,15 +530,9 @@ void conv3x3_pl_kernel(const PlArgs a) {
     int c = 0, kt = 0, j = 0;                                                 // chunk inside the tile, tile counter, chunk step
     // per-step state (set by begin_step; the matrix section's lambdas below capture it by reference)
     char* st = smem;
-    [[maybe_unused]] unsigned q_in_off = 0, q_w_off = 0;                      // Q4: this step's input / weight slot
-    [[maybe_unused]] const char* q_in = smem;
-    [[maybe_unused]] const char* q_w = smem;
-    const char* ldsA = smem;                                                  // + ((tap*4 + g)*64 + m*32)*16   (HONLY: tap*2 + g; Q4: tap*3 + g)
+    const char* ldsA = smem;                                                  // + ((tap*4 + g)*64 + m*32)*16   (HONLY: tap*2 + g)
     const char* ldsB = smem;                                                  // + g*PLANE + ((q+dy)*IW + dx)*16
-    // (an opaque copy of the lane half per step: the tap-pair offsets of the cross terms -- in the Q4 variant weight granule, both scale bytes
-    // and pixel -- are loop invariant per lane, and hoisted out of the tile loop the 15-20 of them stayed live across it: the variant spilled the
-    // epilogue's constants, whose re-loads drained the epilogue's stores.  Recomputed per step: no spill.)
-    [[maybe_unused]] int hh_q = hh;
+    const int hh_q = hh;
 #if WSU_PROBE == 5
     u32x4 sa0[2], sa1[2], sb0[2], sb1[2], sah[2], sbh[2];
 #endif
@@ -725,14 +544,9 @@ void conv3x3_pl_kernel(const PlArgs a) {
         asm volatile("" ::: "memory");
         STAMP(s2);
         st = HONLY ? smem + (j % NSTAGE_H) * STAGE_H : smem + (j & 1) * STAGE;
-        q_in_off = (unsigned)(j % Q4_NIN) * Q4_IN_SLOT; q_w_off = Q4_W_BASE + (unsigned)(j % Q4_NW) * Q4_W_SLOT;
-        q_in = smem + q_in_off;
-        q_w = smem + q_w_off;
         STAMP(s3);
-        ldsA = Q4 ? q_w + (cur.mh * 32 + l31) * 16 : st + (HONLY ? LDS_IN_H : LDS_IN) + (cur.mh * 32 + l31) * 16;
-        ldsB = (Q4 ? q_in : st) + ((2 * wv) * IW + l31) * 16;
-        hh_q = hh;
-        if constexpr (Q4 || WSU_PL_OPAQUE_HH) asm volatile("" : "+v"(hh_q));
+        ldsA = st + (HONLY ? LDS_IN_H : LDS_IN) + (cur.mh * 32 + l31) * 16;
+        ldsB = st + ((2 * wv) * IW + l31) * 16;
     };
     auto zero_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
@@ -793,7 +607,7 @@ _Pragma("unroll")
             {
 #endif
 _Pragma("unroll")
-            for (int m = ML; m < MU; ++m) ah[m] = *reinterpret_cast<const u32x4*>(ldsA + ((tap * (HONLY ? 2 : Q4 ? 3 : 4) + hh) * 64 + m * 32) * 16);
+            for (int m = ML; m < MU; ++m) ah[m] = *reinterpret_cast<const u32x4*>(ldsA + ((tap * (HONLY ? 2 : 4) + hh) * 64 + m * 32) * 16);
 _Pragma("unroll")
             for (int q = 0; q < 2; ++q) bh[q] = *reinterpret_cast<const u32x4*>(ldsB + hh * PLANE + ((q + dy) * IW + dx) * 16);
 #if WSU_PROBE == 5
@@ -811,70 +625,9 @@ _Pragma("unroll")
         // Measured neutral on this section (gpurun_out/ab_prio.log, time_pl*.log): raising the priority of waves 4-7 for its second half so
         // that SIMD partners reach the barrier together; fetching fragments one unit ahead of their matrix instructions behind scheduling
         // fences (two ahead needs 190 registers).
-        // Q4: both cross terms of a tap pair in one fp4 instruction -- lane half hh carries tap 2 tp + hh: weight granule plane 2 and the pixel's Q
-        // granule, each with its E8M0 scale byte (per (tap, co) / per pixel)
-        auto cross_q4 = [&](auto tp_c, auto ms_c) __attribute__((always_inline)) {
-            constexpr int tp = decltype(tp_c)::value;
-            constexpr int ms = decltype(ms_c)::value, ML = ms < 0 ? 0 : ms, MU = ms < 0 ? MH : ms + 1;     // accumulator tiles [ML, MU) along the output channels
-            constexpr int t0 = 2 * tp, t1 = (2 * tp + 1 < 9) ? 2 * tp + 1 : 2 * tp;
-            constexpr bool single = 2 * tp + 1 >= 9;
-            const int tap = hh_q ? t1 : t0;
-            const int pixoff = (tap / 3) * IW + tap % 3;                        // (dy, dx) of this lane's tap
-            u32x4 a4[2], b4[2]; int sa[2], sb[2];
-            // 32-bit LDS addresses (address space 3): as generic 64-bit pointers the per-lane scale addresses were spilled and re-loaded from scratch inside this loop
-            typedef __attribute__((address_space(3))) const unsigned char lds_cuchar;
-            typedef __attribute__((address_space(3))) const u32x4 lds_cu32x4;
-            lds_char* L = (lds_char*)smem;
-            const unsigned wbase = q_w_off + (unsigned)(cur.mh * 32 + l31) * 16u + (unsigned)((tap * 3 + 2) * 64) * 16u;
-            const unsigned sabase = q_w_off + Q4_W_GRAN + (unsigned)(tap * 64 + cur.mh * 32 + l31);
-            const unsigned pix = (unsigned)((2 * wv) * IW + l31 + pixoff);
-_Pragma("unroll")
-            for (int m = ML; m < MU; ++m) {
-                a4[m] = *(lds_cu32x4*)(L + wbase + m * 32 * 16);
-                sa[m] = *(lds_cuchar*)(L + sabase + m * 32);
-            }
-_Pragma("unroll")
-            for (int q = 0; q < 2; ++q) {
-                b4[q] = *(lds_cu32x4*)(L + q_in_off + 2 * PLANE + (pix + q * IW) * 16u);
-                sb[q] = *(lds_cuchar*)(L + q_in_off + 3 * PLANE + pix + q * IW);
-            }
-            if (single && hh_q) {
-                const u32x4 z = mk_u4(0, 0, 0, 0);
-_Pragma("unroll")
-                for (int m = ML; m < MU; ++m) a4[m] = z;
-                b4[0] = z; b4[1] = z;
-            }
-_Pragma("unroll")
-            for (int m = ML; m < MU; ++m)
-_Pragma("unroll")
-                for (int q = 0; q < 2; ++q) wsu_mfma_q4(a4[m], b4[q], sa[m], sb[q], acc[m][q]);
-        };
         static_assert(!HONLY || !XRES, "HONLY reads neither residual plane");
-        [[maybe_unused]] auto units_q4_range = [&](auto ms_c, auto lo_c, auto hi_c) __attribute__((always_inline)) {     // tap pairs [lo, hi)
-            constexpr int lo = decltype(lo_c)::value, hi = decltype(hi_c)::value;
-            if constexpr (EPO) asm volatile("" : "+v"(hh_q));                 // (per call: the three paths of a step must not share -- and hoist -- their lane offsets)
-            WSU_STATIC_FOR(hi - lo, i, {
-                constexpr int tp = lo + i;
-                cross_q4(std::integral_constant<int, tp>{}, ms_c);
-                main_term(std::integral_constant<int, 2 * tp>{}, ms_c);
-                if constexpr (2 * tp + 1 < 9) main_term(std::integral_constant<int, 2 * tp + 1>{}, ms_c);
-            });
-        };
-        [[maybe_unused]] auto units_q4 = [&](auto ms_c) __attribute__((always_inline)) {
-            units_q4_range(ms_c, std::integral_constant<int, 0>{}, std::integral_constant<int, 5>{});
-        };
         auto units_all = [&]() __attribute__((always_inline)) {
-        if constexpr (Q4) {
-            // (the Q4 variants end 6-13 registers above the 168 of three waves per SIMD: lane-derived epilogue constants are spilled at the kernel entry
-            // and re-loaded per tile; scheduling fences between the groups, or recomputing those constants in the epilogue, moved the spills into
-            // this loop and measured slower)
-            // (stamps build, per-wave view: the arbiter serves the OLDER matrix wave of a SIMD first -- waves 0-3 leave their section after ~3500 cycles,
-            // waves 4-7 after ~4450, alone on the pipe at half its rate for the last ~950, and everyone waits for them at the barrier.  Swapping
-            // s_setprio between the two inside the section, after tap pair 2 or 3, measured 1-2 % SLOWER; fetching the fragments of unit u + 1 before
-            // the matrix instructions of unit u behind scheduling fences, and walking the f16 products column-wise with the shared pixel fragment
-            // carried in registers (12 instead of 18 reads per step), both measured +-0.1 %: profiles/r03/conv3x3_pl_last_step.md.)
-            units_q4(all_m);
-        } else if constexpr (HONLY) {
+        if constexpr (HONLY) {
             WSU_STATIC_FOR(9, tap, { main_term(std::integral_constant<int, tap>{}, all_m); });
         } else if constexpr (XRES) {
             WSU_STATIC_FOR(5, tp, {
@@ -925,11 +678,10 @@ _Pragma("unroll")
             for (int q = 0; q < 2; ++q)
 #pragma unroll
                 for (int o = 0; o < (HC > 0 ? HC : 1); ++o) hz[q][o] = 0.f;
-            auto epi_m = [&](auto m_c, auto&& before_piece) __attribute__((always_inline)) {   // one accumulator tile along the output channels: 32 channels x this wave's 2 x 32 pixels
+            auto epi_m = [&](auto m_c) __attribute__((always_inline)) {   // one accumulator tile along the output channels: 32 channels x this wave's 2 x 32 pixels
                 constexpr int m = decltype(m_c)::value;
                 auto piece = [&](auto cp_c) __attribute__((always_inline)) {   // 16 output channels = accumulator groups g4 = 2cp, 2cp+1
                     constexpr int cp = decltype(cp_c)::value;
-                    before_piece(std::integral_constant<int, 3 * cp>{});       // hook 3 cp: before the bias / ReLU of these 16 channels, 3 cp + 1 + q: before the encoding and stores of row q
                     const int oc = cur.cb * 4 + (m + cur.mh) * 2 + cp;
                     const int co0 = oc * 16 + 4 * hh;                          // this lane: channels co0..co0+3 (X) and co0+8..co0+11 (Y)
                     f32x4 vx[2], vy[2];
@@ -983,15 +735,6 @@ _Pragma("unroll")
                         swap32(xh0, yh0); swap32(xh1, yh1);                     // lanes 0-31: f16 ch 0-7, lanes 32-63: f16 ch 8-15
                         uint32_t xlp = xlo, ylp = ylo;
                         swap32(xlo, xlp); swap32(ylo, ylp);                     // lanes 0-31: xlp / ylp = the partner lane's residuals (ch 4-7 / 12-15)
-                        if constexpr (EPO) {
-                            // no branch (a branch ends the basic block the matrix instructions are scheduled in): a lane that must not store passes
-                            // an offset beyond the buffer's extent, which the hardware drops
-                            const auto rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, have ? (int)(3u * plane_bytes) : 0, 0x00020000);      // (have: wave-uniform)
-                            const uint32_t o1 = ok ? off + (hh ? plane_bytes : 0u) : OOB;
-                            const uint32_t o2 = (ok && !hh) ? off + 2u * plane_bytes : OOB;
-                            __builtin_amdgcn_raw_buffer_store_b128(mk_u4(xh0, xh1, yh0, yh1), rs, (int)o1, 0, 0);
-                            __builtin_amdgcn_raw_buffer_store_b128(mk_u4(xlo, xlp, ylo, ylp), rs, (int)o2, 0, 0);
-                        } else
                         if (ok) {
                             // (one 32-bit lane offset per store: written `base + off + hh * plane_bytes` the loop-invariant 64-bit `hh * plane_bytes` stayed live
                             // across the tile loop, was spilled, and every re-load drained the epilogue's stores with an s_waitcnt vmcnt(0))
@@ -1016,9 +759,8 @@ _Pragma("unroll")
                             store_px(vx[q], vy[q], base, (uint32_t)(row * a.w + col) * 16u, (uint32_t)hw * 16u, row < a.h && col < a.w);
                         }
                     } else
-                    if ((EPO && !HEAD) || a.y) {                               // (EPO without a head: no branch -- a null y makes the buffer empty)
+                    if (a.y) {
                         WSU_STATIC_FOR(2, q, {
-                            before_piece(std::integral_constant<int, 3 * cp + 1 + q>{});
                             const int row = cur.y0 + 2 * wv + q;
                             char* base = a.y + (((size_t)cur.n * nco + oc) * HBM_PLANES) * hw * 16;
                             unsigned char* mdst = nullptr;
@@ -1028,9 +770,6 @@ _Pragma("unroll")
                             }
                             store_px(vx[q], vy[q], base, (uint32_t)(row * a.w + col) * 16u, (uint32_t)hw * 16u, row < a.h && col < a.w, mdst, a.y != nullptr);
                         });
-                    } else if constexpr (EPO) {                                // (a head that stores no activations: the hooks still run -- they carry matrix units)
-                        before_piece(std::integral_constant<int, 3 * cp + 1>{});
-                        before_piece(std::integral_constant<int, 3 * cp + 2>{});
                     }
                     if constexpr (POOL) {                                      // every lane takes part in the exchanges
                         f32x4 px, py;
@@ -1052,23 +791,7 @@ _Pragma("unroll")
                 piece(std::integral_constant<int, 0>{});
                 piece(std::integral_constant<int, 1>{});
             };
-            auto nothing = [](auto) __attribute__((always_inline)) {};
-            if constexpr (EPO) {
-                // the last step's units of m = 1, one tap pair per scheduling region, each with a part of the encoding of m = 0
-                epi_m(std::integral_constant<int, 0>{}, [&](auto h_c) __attribute__((always_inline)) {
-                    constexpr int h = decltype(h_c)::value;                    // six hooks, five tap pairs: one scheduling region each (no fragment prefetch across them:
-#if WSU_PL_EPO_FENCE
-                    __builtin_amdgcn_sched_barrier(0);                         // with two tap pairs per region the variants spilled an accumulator tile in EVERY step)
-#endif
-                    if constexpr (h < 5) units_q4_range(std::integral_constant<int, 1>{}, std::integral_constant<int, h>{}, std::integral_constant<int, h + 1>{});
-                });
-#if WSU_PL_EPO_FENCE
-                __builtin_amdgcn_sched_barrier(0);
-#endif
-                epi_m(std::integral_constant<int, 1>{}, nothing);
-            } else {
-                WSU_STATIC_FOR(MH, m, { (void)m; epi_m(m_c, nothing); });
-            }
+            WSU_STATIC_FOR(MH, m, { (void)m; epi_m(m_c); });
             if constexpr (HEAD) {
                 // the other 32 channels of this pixel sit in the partner lane (lane ^ 32)
 #pragma unroll
@@ -1099,18 +822,7 @@ _Pragma("unroll")
             t_epi += __builtin_amdgcn_s_memtime() - s4;
 #endif
         };
-        if constexpr (EPO) {
-            // one loop nest per tile, the last step spelled out after the inner loop (as ONE step loop with a branch for the last step, the three-way
-            // code of a step made the register allocator copy and spill whole accumulator tiles in every step)
-            for (int t = 0; t < K; ++t) {
-                zero_acc();
-                for (int cc = 1; cc < a.nch; ++cc) { begin_step(); units_all(); ++j; }
-                begin_step();
-                units_q4(std::integral_constant<int, 0>{});                    // the last step: m = 0 first; m = 1 follows inside the epilogue
-                finish_tile();
-                ++j;
-            }
-        } else {
+        {
             for (; j < J; ++j) {
                 begin_step();
                 if (c == 0) zero_acc();
@@ -1143,61 +855,6 @@ _Pragma("unroll")
 #endif
 }
 
-// (explicit instantiations: referenced only from pl_launch, hipcc (ROCm 7.2) emitted the host stub of the first Q4 variant and left the other four
-// as undefined symbols -- without a diagnostic)
-template __global__ void conv3x3_pl_kernel<0, false, true, false, false, false, false, true>(const PlArgs);
-template __global__ void conv3x3_pl_kernel<0, true, true, false, false, false, false, true>(const PlArgs);
-template __global__ void conv3x3_pl_kernel<1, false, true, false, false, false, false, true>(const PlArgs);
-template __global__ void conv3x3_pl_kernel<4, false, true, false, false, false, false, true>(const PlArgs);
-template __global__ void conv3x3_pl_kernel<0, false, true, false, false, true, false, true>(const PlArgs);
-
-// one thread per (block, chunk, tap, co): 16 weights -> two f16 granules, the fp4 granule and the scale byte (layout: wsu_conv3x3_pack_f4 below)
-__global__ void pack_conv3x3_f4_kernel(const float* __restrict__ w, char* __restrict__ dst, int cin, int cout) {
-    const int nch = cin / 16;
-    const long long total = (long long)(cout / WSU_COB) * nch * 9 * WSU_COB;
-    for (long long d = (long long)blockIdx.x * blockDim.x + threadIdx.x; d < total; d += (long long)gridDim.x * blockDim.x) {
-        long long t = d;
-        const int co = (int)(t % WSU_COB); t /= WSU_COB;
-        const int tap = (int)(t % 9); t /= 9;
-        const int c = (int)(t % nch); const int cb = (int)(t / nch);
-        float v[16], r[16];
-        uint32_t h[8];
-#pragma unroll
-        for (int e = 0; e < 16; ++e) v[e] = w[(((size_t)(cb * WSU_COB + co) * cin + c * 16 + e) * 3 + tap / 3) * 3 + tap % 3];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const _Float16 a = (_Float16)v[2 * e], b = (_Float16)v[2 * e + 1];              // round to nearest even, as every f16 part of the library
-            h[e] = (uint32_t)__builtin_bit_cast(unsigned short, a) | ((uint32_t)__builtin_bit_cast(unsigned short, b) << 16);
-            r[2 * e] = (v[2 * e] - (float)a) * 2048.f; r[2 * e + 1] = (v[2 * e + 1] - (float)b) * 2048.f;
-        }
-        const u32x4 h0 = mk_u4(h[0], h[1], h[2], h[3]), h1 = mk_u4(h[4], h[5], h[6], h[7]);
-        const int E = wsu_q4_block_exp(wsu_f16x16_max_abs_bits(h0, h1));
-        const float sc = wsu_pow2f(E);
-        uint32_t q[4] = {0, 0, 0, 0};
-        WSU_STATIC_FOR(8, e, { q[e >> 2] = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(q[e >> 2], r[2 * e], r[2 * e + 1], sc, e & 3); });   // nibbles 0-15: residuals, meet fp4(x)
-        q[2] = wsu_f16x8_to_fp4(h0, sc); q[3] = wsu_f16x8_to_fp4(h1, sc);                                                            // nibbles 16-31: copies, meet the residuals of x
-        char* slice = dst + ((size_t)cb * nch + c) * Q4_W_SLOT;
-        char* base = slice + (size_t)(tap * 3) * (WSU_COB * 16) + co * 16;
-        *reinterpret_cast<u32x4*>(base) = h0;
-        *reinterpret_cast<u32x4*>(base + WSU_COB * 16) = h1;
-        *reinterpret_cast<u32x4*>(base + 2 * WSU_COB * 16) = mk_u4(q[0], q[1], q[2], q[3]);
-        slice[Q4_W_GRAN + tap * 64 + co] = (char)(E + 127 - 11);
-        if (tap == 0 && co < 7) *reinterpret_cast<u32x4*>(slice + Q4_W_GRAN + 576 + co * 64) = mk_u4(0, 0, 0, 0), *reinterpret_cast<u32x4*>(slice + Q4_W_GRAN + 576 + co * 64 + 16) = mk_u4(0, 0, 0, 0),
-            *reinterpret_cast<u32x4*>(slice + Q4_W_GRAN + 576 + co * 64 + 32) = mk_u4(0, 0, 0, 0), *reinterpret_cast<u32x4*>(slice + Q4_W_GRAN + 576 + co * 64 + 48) = mk_u4(0, 0, 0, 0);   // the 448 pad bytes
-    }
-}
-
-// diagnostic (wsu_debug_q4_encode): the loaders' Q granule + scale byte of every pixel of one planar chunk, written to global memory
-__global__ void debug_q4_encode_kernel(const char* __restrict__ x, char* __restrict__ q, unsigned char* __restrict__ sbytes, int hw) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= hw) return;
-    const u32x4 h0 = *reinterpret_cast<const u32x4*>(x + (size_t)i * 16), h1 = *reinterpret_cast<const u32x4*>(x + ((size_t)hw + i) * 16),
-                r = *reinterpret_cast<const u32x4*>(x + (2 * (size_t)hw + i) * 16);
-    uint32_t sb;
-    *reinterpret_cast<u32x4*>(q + (size_t)i * 16) = wsu_q4_encode_x(h0, h1, r, &sb);
-    sbytes[i] = (unsigned char)sb;
-}
-
 // one place that knows the instantiations: attributes once, then the variant the arguments select
 int pl_launch(PlArgs a, bool first, hipStream_t s, bool grad = false) {
     static int ablate = -1;
@@ -1213,13 +870,6 @@ int pl_launch(PlArgs a, bool first, hipStream_t s, bool grad = false) {
                               reinterpret_cast<const void*>(&conv3x3_pl_kernel<1, false>), reinterpret_cast<const void*>(&conv3x3_pl_kernel<4, false>),
                               reinterpret_cast<const void*>(&conv3x3_pl_kernel<0, false, false>),
                               reinterpret_cast<const void*>(&conv3x3_pl_kernel<0, false, true, true>), reinterpret_cast<const void*>(&conv3x3_pl_kernel<0, true, true, true>)};
-        const void* q4fns[5] = {reinterpret_cast<const void*>(&conv3x3_pl_kernel<0, false, true, false, false, false, false, true>), reinterpret_cast<const void*>(&conv3x3_pl_kernel<0, true, true, false, false, false, false, true>),
-                                reinterpret_cast<const void*>(&conv3x3_pl_kernel<1, false, true, false, false, false, false, true>), reinterpret_cast<const void*>(&conv3x3_pl_kernel<4, false, true, false, false, false, false, true>),
-                                reinterpret_cast<const void*>(&conv3x3_pl_kernel<0, false, true, false, false, true, false, true>)};
-        for (const void* fn : q4fns) {
-            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
-            if (e != hipSuccess) { wsu_set_error("hipFuncSetAttribute(conv3x3_pl q4): %s", hipGetErrorString(e)); return WSU_ERR_HIP; }
-        }
         hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_pl_kernel<0, false, true, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
         if (e0 != hipSuccess) { wsu_set_error("hipFuncSetAttribute(conv3x3_pl): %s", hipGetErrorString(e0)); return WSU_ERR_HIP; }
         for (const void* fn : fns) {
@@ -1234,19 +884,11 @@ int pl_launch(PlArgs a, bool first, hipStream_t s, bool grad = false) {
     a.msplit = 0;
     if (msplit_on && !grad && !first && !a.head_w && !a.ypool && a.xres && 2 * (long long)a.ntiles <= ncu) {
         a.msplit = 1; a.ncb *= 2; a.ntiles *= 2;
-        if (a.q4) hipLaunchKernelGGL((conv3x3_pl_kernel<0, false, true, false, false, true, false, true>), dim3(a.ntiles), dim3(NT), LDS_TOTAL, s, a);
-        else hipLaunchKernelGGL((conv3x3_pl_kernel<0, false, true, false, false, true>), dim3(a.ntiles), dim3(NT), LDS_TOTAL, s, a);
+        hipLaunchKernelGGL((conv3x3_pl_kernel<0, false, true, false, false, true>), dim3(a.ntiles), dim3(NT), LDS_TOTAL, s, a);
         return wsu_check_launch("conv3x3_pl_kernel");
     }
     const int grid = a.ntiles < ncu ? a.ntiles : ncu;
     const dim3 g(grid), b(NT);
-    if (a.q4 && !grad && !first) {
-        if (a.head_w && a.head_cout == 1) hipLaunchKernelGGL((conv3x3_pl_kernel<1, false, true, false, false, false, false, true>), g, b, LDS_TOTAL, s, a);
-        else if (a.head_w) hipLaunchKernelGGL((conv3x3_pl_kernel<4, false, true, false, false, false, false, true>), g, b, LDS_TOTAL, s, a);
-        else if (a.ypool) hipLaunchKernelGGL((conv3x3_pl_kernel<0, true, true, false, false, false, false, true>), g, b, LDS_TOTAL, s, a);
-        else hipLaunchKernelGGL((conv3x3_pl_kernel<0, false, true, false, false, false, false, true>), g, b, LDS_TOTAL, s, a);
-        return wsu_check_launch("conv3x3_pl_kernel<q4>");
-    }
     if (grad && a.honly) hipLaunchKernelGGL((conv3x3_pl_kernel<0, false, false, false, true, false, true>), g, b, LDS_TOTAL, s, a);
     else if (grad) hipLaunchKernelGGL((conv3x3_pl_kernel<0, false, true, false, true>), g, b, LDS_TOTAL, s, a);
     else if (first) {
@@ -1268,26 +910,6 @@ extern "C" {
 int wsu_debug_read_pl_stamps(unsigned long long* host_dst, int nblocks) {
     if (nblocks > 256) nblocks = 256;
     return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_pl_stamps), (size_t)nblocks * 8 * sizeof(unsigned long long)) == hipSuccess ? 0 : -2;
-}
-
-// Weights of the Q4 variant (x_residual = 2): per (64-channel output block, 16-channel input chunk) one 28 KB slice =
-// [tap 9][plane 3][64 co][16 B] with planes f16 ci 0-7 | f16 ci 8-15 | fp4(residual * 2^11 / 2^E) ci 0-15, fp4(f16 part / 2^E) ci 0-15 (nibble i =
-// channel i), then [tap 9][64 co] scale bytes E + 127 - 11 (the 2^-11 of the residual's pre-scaling rides in the weight's scale), zero padded to 1 KB.
-size_t wsu_conv3x3_packed_f4_bytes(int cin, int cout) {
-    if (cin <= 0 || cout <= 0 || cin % 16 || cout % WSU_COB) return 0;
-    return (size_t)(cout / WSU_COB) * (cin / 16) * Q4_W_SLOT;
-}
-int wsu_conv3x3_pack_f4(const float* w_oihw, void* w_packed, int cin, int cout, void* stream) {
-    WSU_REQUIRE(w_oihw && w_packed, "conv3x3_pack_f4: null pointer");
-    WSU_REQUIRE(cin > 0 && cin % 16 == 0 && cout > 0 && cout % WSU_COB == 0, "conv3x3_pack_f4: cin=%d must be a multiple of 16, cout=%d of %d", cin, cout, WSU_COB);
-    hipLaunchKernelGGL(pack_conv3x3_f4_kernel, dim3(512), dim3(256), 0, static_cast<hipStream_t>(stream), w_oihw, (char*)w_packed, cin, cout);
-    return wsu_check_launch("pack_conv3x3_f4_kernel");
-}
-
-// diagnostic only (not part of include/wsu.h; tests/test_gpu_planar.py): Q granules (hw x 16 B) and scale bytes (hw) of ONE planar chunk (3 planes x hw x 16 B)
-int wsu_debug_q4_encode(const void* x_chunk, void* q, unsigned char* scale_bytes, int hw, void* stream) {
-    hipLaunchKernelGGL(debug_q4_encode_kernel, dim3((hw + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), (const char*)x_chunk, (char*)q, scale_bytes, hw);
-    return wsu_check_launch("debug_q4_encode_kernel");
 }
 
 size_t wsu_relu_mask_bytes(int n, int c, int h, int w) {
@@ -1320,8 +942,8 @@ int wsu_conv3x3_pl_fwd(const void* x1, const void* x2, const void* w_packed, con
     a.y = (char*)y; a.ypool = (char*)y_pool;
     a.head_w = head_w; a.head_b = head_b; a.head_out = head_out; a.head_logit = head_logit; a.head_cout = head_cout;
     a.range_flag = range_flag; a.xres = x_residual ? 1 : 0;
-    WSU_REQUIRE(x_residual >= 0 && x_residual <= 2, "conv3x3_pl: x_residual must be 0 (one e4m3 cross term), 1 (both) or 2 (block-scaled fp4 cross terms)");
-    WSU_REQUIRE(x_residual != 2 || !relu_mask_out, "conv3x3_pl: relu_mask_out is built into the e4m3 variants (x_residual = 1)");
+    WSU_REQUIRE(x_residual == 0 || x_residual == 1, "conv3x3_pl: x_residual must be 0 (one e4m3 cross term) or 1 (both); the block-scaled fp4 cross terms "
+                "(x_residual = 2 of round 3) moved to wsu_conv3x3_q_fwd on planar Q tensors");
     a.n = n; a.h = h; a.w = w; a.c1 = c1; a.c2 = c2; a.cout = cout;
     a.tiles_x = (w + TW - 1) / TW; a.tiles_y = (h + TH - 1) / TH; a.ncb = cout / WSU_COB;
     a.nch1 = c1 / 16; a.nch = (c1 + c2) / 16; a.relu = relu;
@@ -1330,7 +952,7 @@ int wsu_conv3x3_pl_fwd(const void* x1, const void* x2, const void* w_packed, con
     a.ntiles = (int)nt;
     a.img = nullptr; a.w1 = nullptr; a.b1 = nullptr;
     a.y2 = nullptr; a.nco1 = cout / 16; a.mask = nullptr; a.mask2 = nullptr; a.imgs_per_wset = 0; a.wset_bytes = 0;
-    a.relu_mask_out = relu_mask_out; a.mbits = nullptr; a.mbits2 = nullptr; a.honly = 0; a.q4 = x_residual == 2 ? 1 : 0;
+    a.relu_mask_out = relu_mask_out; a.mbits = nullptr; a.mbits2 = nullptr; a.honly = 0;
     return pl_launch(a, false, static_cast<hipStream_t>(stream));
 }
 
@@ -1357,7 +979,7 @@ int wsu_conv3x3_pl_fused_first_fwd(const float* img, const float* w1, const floa
     WSU_REQUIRE(nt > 0 && nt < 0x3FFFFFFFLL, "conv3x3_pl_fused_first: %lld tiles out of range", nt);
     a.ntiles = (int)nt;
     a.y2 = nullptr; a.nco1 = cout / 16; a.mask = nullptr; a.mask2 = nullptr; a.imgs_per_wset = 0; a.wset_bytes = 0;
-    a.relu_mask_out = nullptr; a.mbits = nullptr; a.mbits2 = nullptr; a.honly = 0; a.q4 = 0;
+    a.relu_mask_out = nullptr; a.mbits = nullptr; a.mbits2 = nullptr; a.honly = 0;
     return pl_launch(a, true, static_cast<hipStream_t>(stream));
 }
 
@@ -1398,7 +1020,7 @@ int wsu_conv3x3_pl_bwd_data(const void* g, const void* w_packed_dgrad, const voi
     a.head_w = nullptr; a.head_b = nullptr; a.head_out = nullptr; a.head_logit = nullptr; a.head_cout = 0;
     a.range_flag = nullptr; a.xres = 1; a.img = nullptr; a.w1 = nullptr; a.b1 = nullptr;
     a.imgs_per_wset = 0; a.wset_bytes = 0;
-    a.relu_mask_out = nullptr; a.mbits = mask1_bits; a.mbits2 = mask2_bits; a.honly = products == WSU_PRODUCTS_F16 ? 1 : 0; a.q4 = 0;
+    a.relu_mask_out = nullptr; a.mbits = mask1_bits; a.mbits2 = mask2_bits; a.honly = products == WSU_PRODUCTS_F16 ? 1 : 0;
     a.n = n; a.h = h; a.w = w; a.c1 = cout; a.c2 = 0; a.cout = cin;
     a.tiles_x = (w + TW - 1) / TW; a.tiles_y = (h + TH - 1) / TH; a.ncb = cin / WSU_COB;
     a.nch1 = cout / 16; a.nch = cout / 16; a.relu = 0;

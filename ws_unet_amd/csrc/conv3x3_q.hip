@@ -17,7 +17,7 @@
 // of three slots, weights one step ahead into two; ONE s_barrier per chunk step; epilogue straight from the accumulators (bias, ReLU, fused 2x2
 // max-pool, fused 1x1 head + sigmoid), the last step of a tile split by accumulator tile so that its second half overlaps the first half's stores.
 // Replaces nn.Conv2d(k=3, reflect) + F.relu (+ torch.cat, nn.MaxPool2d, outconv + sigmoid) of src/unet/model/unet.py:141-189.
-// Weights: wsu_conv3x3_pack_f4 (conv3x3_pl.hip).
+// Weights: wsu_conv3x3_pack_f4 (below).
 #include "wsu_device.h"
 #include <cstdlib>
 
@@ -564,6 +564,42 @@ _Pragma("unroll")
     }
 }
 
+// one thread per (block, chunk, tap, co): 16 weights -> two f16 granules, the fp4 granule and the scale byte (layout: wsu_conv3x3_pack_f4 below)
+__global__ void pack_conv3x3_f4_kernel(const float* __restrict__ w, char* __restrict__ dst, int cin, int cout) {
+    const int nch = cin / 16;
+    const long long total = (long long)(cout / WSU_COB) * nch * 9 * WSU_COB;
+    for (long long d = (long long)blockIdx.x * blockDim.x + threadIdx.x; d < total; d += (long long)gridDim.x * blockDim.x) {
+        long long t = d;
+        const int co = (int)(t % WSU_COB); t /= WSU_COB;
+        const int tap = (int)(t % 9); t /= 9;
+        const int c = (int)(t % nch); const int cb = (int)(t / nch);
+        float v[16], r[16];
+        uint32_t h[8];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] = w[(((size_t)(cb * WSU_COB + co) * cin + c * 16 + e) * 3 + tap / 3) * 3 + tap % 3];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const _Float16 a = (_Float16)v[2 * e], b = (_Float16)v[2 * e + 1];              // round to nearest even, as every f16 part of the library
+            h[e] = (uint32_t)__builtin_bit_cast(unsigned short, a) | ((uint32_t)__builtin_bit_cast(unsigned short, b) << 16);
+            r[2 * e] = (v[2 * e] - (float)a) * 2048.f; r[2 * e + 1] = (v[2 * e + 1] - (float)b) * 2048.f;
+        }
+        const u32x4 h0 = mk_u4(h[0], h[1], h[2], h[3]), h1 = mk_u4(h[4], h[5], h[6], h[7]);
+        const int E = wsu_q4_block_exp(wsu_f16x16_max_abs_bits(h0, h1));
+        const float sc = wsu_pow2f(E);
+        uint32_t q[4] = {0, 0, 0, 0};
+        WSU_STATIC_FOR(8, e, { q[e >> 2] = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(q[e >> 2], r[2 * e], r[2 * e + 1], sc, e & 3); });   // nibbles 0-15: residuals, meet fp4(x)
+        q[2] = wsu_f16x8_to_fp4(h0, sc); q[3] = wsu_f16x8_to_fp4(h1, sc);                                                            // nibbles 16-31: copies, meet the residuals of x
+        char* slice = dst + ((size_t)cb * nch + c) * W_SLOT;
+        char* base = slice + (size_t)(tap * 3) * (WSU_COB * 16) + co * 16;
+        *reinterpret_cast<u32x4*>(base) = h0;
+        *reinterpret_cast<u32x4*>(base + WSU_COB * 16) = h1;
+        *reinterpret_cast<u32x4*>(base + 2 * WSU_COB * 16) = mk_u4(q[0], q[1], q[2], q[3]);
+        slice[W_GRAN + tap * 64 + co] = (char)(E + 127 - 11);
+        if (tap == 0 && co < 7) *reinterpret_cast<u32x4*>(slice + W_GRAN + 576 + co * 64) = mk_u4(0, 0, 0, 0), *reinterpret_cast<u32x4*>(slice + W_GRAN + 576 + co * 64 + 16) = mk_u4(0, 0, 0, 0),
+            *reinterpret_cast<u32x4*>(slice + W_GRAN + 576 + co * 64 + 32) = mk_u4(0, 0, 0, 0), *reinterpret_cast<u32x4*>(slice + W_GRAN + 576 + co * 64 + 48) = mk_u4(0, 0, 0, 0);   // the 448 pad bytes
+    }
+}
+
 #define WSU_Q_INST(RQ) \
     template __global__ void conv3x3_q_kernel<RQ, 0, false, false, false>(const QArgs); \
     template __global__ void conv3x3_q_kernel<RQ, 0, false, true, false>(const QArgs);  \
@@ -611,6 +647,20 @@ int q_launch_rq(QArgs a, int yq, hipStream_t s, int ncu, bool msplit_on) {
 }  // namespace
 
 extern "C" {
+
+// Weights of the fp4-cross-term conv: per (64-channel output block, 16-channel input chunk) one 28 KB slice =
+// [tap 9][plane 3][64 co][16 B] with planes f16 ci 0-7 | f16 ci 8-15 | fp4(residual * 2^11 / 2^E) ci 0-15, fp4(f16 part / 2^E) ci 0-15 (nibble i =
+// channel i), then [tap 9][64 co] scale bytes E + 127 - 11 (the 2^-11 of the residual's pre-scaling rides in the weight's scale), zero padded to 1 KB.
+size_t wsu_conv3x3_packed_f4_bytes(int cin, int cout) {
+    if (cin <= 0 || cout <= 0 || cin % 16 || cout % WSU_COB) return 0;
+    return (size_t)(cout / WSU_COB) * (cin / 16) * W_SLOT;
+}
+int wsu_conv3x3_pack_f4(const float* w_oihw, void* w_packed, int cin, int cout, void* stream) {
+    WSU_REQUIRE(w_oihw && w_packed, "conv3x3_pack_f4: null pointer");
+    WSU_REQUIRE(cin > 0 && cin % 16 == 0 && cout > 0 && cout % WSU_COB == 0, "conv3x3_pack_f4: cin=%d must be a multiple of 16, cout=%d of %d", cin, cout, WSU_COB);
+    hipLaunchKernelGGL(pack_conv3x3_f4_kernel, dim3(512), dim3(256), 0, static_cast<hipStream_t>(stream), w_oihw, (char*)w_packed, cin, cout);
+    return wsu_check_launch("pack_conv3x3_f4_kernel");
+}
 
 // Bytes of a planar Q tensor (n images, c channels -- a multiple of 16 -- at h x w): n * c/16 chunks of 48 h w + 512 ceil(h/16) ceil(w/32) bytes.
 size_t wsu_planar_q_bytes(int n, int c, int h, int w) {

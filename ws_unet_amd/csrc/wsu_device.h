@@ -190,7 +190,7 @@ __device__ __forceinline__ u32x2 wsu_f16x8_to_fp8(const u32x4& h) {
     hi = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(hi, __builtin_shufflevector(c, c, 6, 7), WSU_F8_X_DIV, true);
     return mk_u2(__builtin_bit_cast(uint32_t, lo), __builtin_bit_cast(uint32_t, hi));
 }
-// ---- block-scaled fp4 (e2m1) cross terms ("Q4", round 3; semantics probed on the device: tools/fp4_probe.hip) -------------------------------------
+// ---- block-scaled fp4 (e2m1) cross terms (round 3; since round 4 on planar Q storage, below; semantics probed on the device: tools/fp4_probe.hip) ----
 // A block = the 16 channels of one (pixel, chunk) resp. one (output channel, tap, chunk); its E8M0 scale is 2^E, the smallest power of two
 // with (largest |f16 part|) / 2^E <= 6 = fp4's largest value (wsu_q4_block_exp: the largest element lands in [2, 3) or [4, 6]); both halves of a block
 // share it -- the copy c = f16 part and the residual pre-scaled by 2^11 (|residual| <= 2^-11 |value|).  v_cvt_scalef32_pk_fp4_f16 / _f32
@@ -226,24 +226,6 @@ __device__ __forceinline__ uint32_t wsu_f16x8_to_fp4(const u32x4& h, float scale
     asm volatile("v_cvt_scalef32_pk_fp4_f16 %0, %1, %2 op_sel:[0,0,0,1]" : "+v"(d) : "v"(h.z), "v"(scale));
     asm volatile("v_cvt_scalef32_pk_fp4_f16 %0, %1, %2 op_sel:[0,0,1,1]" : "+v"(d) : "v"(h.w), "v"(scale));
     return d;
-}
-// 8 stored e4m3 residual bytes (two dwords; value = byte * res_mul) -> 8 fp4 nibbles of (residual value / scale)
-__device__ __forceinline__ uint32_t wsu_fp8x8_to_fp4(uint32_t r0, uint32_t r1, float res_mul, float scale) {
-    uint32_t d = 0;
-    d = __builtin_amdgcn_cvt_scalef32_pk_fp4_f16(d, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(r0, res_mul, false), scale, 0);
-    d = __builtin_amdgcn_cvt_scalef32_pk_fp4_f16(d, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(r0, res_mul, true), scale, 1);
-    d = __builtin_amdgcn_cvt_scalef32_pk_fp4_f16(d, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(r1, res_mul, false), scale, 2);
-    d = __builtin_amdgcn_cvt_scalef32_pk_fp4_f16(d, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(r1, res_mul, true), scale, 3);
-    return d;
-}
-// The Q granule and scale byte of one (pixel, chunk) from its three stored granules (f16 ch 0-7 | f16 ch 8-15 | e4m3 residuals * 2^12):
-// nibbles 0-15 = fp4(f16 part / 2^E), nibbles 16-31 = fp4(residual * 2^11 / 2^E); *scale_byte = E + 127.
-__device__ __forceinline__ u32x4 wsu_q4_encode_x(const u32x4& h0, const u32x4& h1, const u32x4& res, uint32_t* scale_byte) {
-    const int e = wsu_q4_block_exp(wsu_f16x16_max_abs_bits(h0, h1));
-    const float sc = wsu_pow2f(e);
-    *scale_byte = (uint32_t)(e + 127);
-    // stored residual byte = e4m3((x - f16 x) * 2^12): (x - f16 x) * 2^11 = byte value / 2
-    return mk_u4(wsu_f16x8_to_fp4(h0, sc), wsu_f16x8_to_fp4(h1, sc), wsu_fp8x8_to_fp4(res.x, res.y, 0.5f, sc), wsu_fp8x8_to_fp4(res.z, res.w, 0.5f, sc));
 }
 // ---- planar Q storage ("F16F4P" tensors, round 4; layout: include/wsu.h): the PRODUCER emits what the fp4 conv multiplies -----------------------
 // Per (image, 16-channel chunk): planes f16 ch 0-7 | f16 ch 8-15 | Q (the 16-byte granule above) as [H][W][16 B], then the E8M0 scale bytes as

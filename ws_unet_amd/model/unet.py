@@ -325,18 +325,13 @@ class UNet(nn.Module):
         # 'f16f4p' (default): block-scaled fp4 cross terms on planar Q tensors (ops.PlanarQ; csrc/conv3x3_q.hip): every producer's epilogue writes
         # the fp4 granule and scale byte its consumer multiplies; only the two tensors the transposed convs read stay in the e4m3-residual format
         q4 = self.mode == "f16f4p"
-        # (A/B switch, to be removed with the code it selects: WSU_Q4_R3=1 = round 3's organisation of this mode -- e4m3-residual storage
-        # everywhere, the consumers' loader waves derive the fp4 operands: conv3x3_pl_kernel<..., Q4>)
-        q4r3 = q4 and os.environ.get("WSU_Q4_R3") == "1"
         CK = "conv_f4" if q4 else "conv"
-        Q, A = (ops.PLANAR_A if q4r3 else ops.PLANAR_Q), ops.PLANAR_A
+        Q, A = ops.PLANAR_Q, ops.PLANAR_A
         tag = ops.set_layer
         e11 = self.e11
         rf = self._range_flag_tensor(x.device)
 
         def conv(xa, xb, name, layer, fmt=Q, xres=True, **kw):       # one 3x3 conv of the planar path in this mode's arithmetic
-            if q4r3:
-                return ops.conv3x3_pl(xa, xb, self._packed(name, W, CK), layer.bias.detach(), layer.out_channels, x_residual=2, **kw)
             if q4:
                 return ops.conv3x3_q(xa, xb, self._packed(name, W, CK), layer.bias.detach(), layer.out_channels, y_format=fmt, **kw)
             return ops.conv3x3_pl(xa, xb, self._packed(name, W, CK), layer.bias.detach(), layer.out_channels, x_residual=xres, **kw)

@@ -156,7 +156,7 @@ def pack_conv3x3(w: torch.Tensor, mode: int, dgrad: bool = False) -> torch.Tenso
 
 
 def pack_conv3x3_f4(w: torch.Tensor) -> torch.Tensor:
-    """w: (Cout, Cin, 3, 3) fp32 OIHW on the device -> the packed weights of conv3x3_pl(..., x_residual=2): f16 planes + block-scaled fp4 cross-term
+    """w: (Cout, Cin, 3, 3) fp32 OIHW on the device -> the packed weights of conv3x3_q: f16 planes + block-scaled fp4 cross-term
     granules + scale bytes (wsu_conv3x3_pack_f4)."""
     lib = _lib.load()
     w = w.detach()
@@ -349,8 +349,8 @@ def conv3x3_pl(x1: torch.Tensor, x2: Optional[torch.Tensor], w_packed: torch.Ten
                head_w: Optional[torch.Tensor] = None, head_b: Optional[torch.Tensor] = None, want_logit: bool = False,
                range_flag: Optional[torch.Tensor] = None, x_residual=True, want_mask: bool = False):
     """3x3 reflect conv (+ReLU, +2x2 max-pool, +1x1 head and sigmoid) on planar F16F8P activations (wsu_conv3x3_pl_fwd).
-    x1 / x2: planar tensors (N, C/16, 4, H, W, 4); w_packed from pack_conv3x3(mode f16f8) -- or, with x_residual=2 (block-scaled fp4 cross
-    terms), from pack_conv3x3_f4.  Returns y [, y_pool] or, with head_w, out [, logit][, y]."""
+    x1 / x2: planar tensors (N, C/16, 4, H, W, 4); w_packed from pack_conv3x3(mode f16f8) (the block-scaled fp4 cross terms of the default
+    inference mode: conv3x3_q on PlanarQ tensors).  Returns y [, y_pool] or, with head_w, out [, logit][, y]."""
     lib = _lib.load()
     hw2 = None if head_w is None else head_w.detach().reshape(head_w.shape[0], -1).contiguous()
     _dev_check(x1, x2, w_packed, bias, hw2, head_b)
