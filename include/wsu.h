@@ -243,6 +243,9 @@ size_t wsu_chansum_pl_workspace_bytes(int c);
 int wsu_colsum_pl(const void* g, float* db, float* workspace, size_t workspace_bytes, int n, int h, int w, int c, int products, void* stream);
 int wsu_conv3x3_first_pl_bwd_weight(const void* g, const float* img, float* dw, float* db, float* workspace, size_t workspace_bytes,
                                     int n, int h, int w, int c, int products, void* stream);
+/*      wsu_conv3x3_first_pl_bwd_data (round 4): the INPUT gradient of the planar training path (saliency, src/saliency.py:159-174): g (planar gradient,
+ *        c channels), w_oihw (c, cin <= 8, 3, 3) -> dx (N, cin, H, W) fp32 in g's power-of-two scale (the reflect adjoint included). */
+int wsu_conv3x3_first_pl_bwd_data(const void* g, const float* w_oihw, float* dx_nchw, int n, int h, int w, int cin, int c, int products, void* stream);
 
 /* ---- K3p / K0p: the other two kernels of the planar (F16F8P) inference path (csrc/planar.hip).
  *      wsu_convt2x2_pl_fwd: nn.ConvTranspose2d(k2, s2) + bias (unet.py:125,130,177,183), x: cin channels at (h, w) planar -> y: cout channels at

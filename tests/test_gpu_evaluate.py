@@ -233,3 +233,22 @@ def test_u8_shards_give_the_identical_table(tmp_path):
         assert a["name"].tolist() == b["name"].tolist()
         np.testing.assert_array_equal(a["beta_hat"].to_numpy(), b["beta_hat"].to_numpy())
         np.testing.assert_array_equal(a["l1"].to_numpy(), b["l1"].to_numpy())
+
+
+def test_per_image_api_one_readback(tmp_path, caplog):
+    """Round 4: predict_unet brings beta_hat, l1 AND the range flag back in one copy.  Same numbers as the batched path;
+    a tripped range flag still switches the model (loudly) and the row is recomputed in the fallback arithmetic."""
+    _make_dataset(tmp_path)
+    model = gpu_model(2, "he", None, drop_rate=0.)
+    per = evaluate.predict_unet_cover(tmp_path, model=model, progress_on=False)
+    bat = evaluate.predict_unet_cover_batched(tmp_path, model=model)
+    np.testing.assert_allclose(per["beta_hat"].to_numpy(float), bat["beta_hat"].to_numpy(float), atol=2e-5)
+    x = evaluate.load_planes_u8([str(tmp_path / "images" / "1.png")]).to(DEV)
+    b0, l0, tripped = evaluate.predict_u8_one_readback(x, model)
+    assert not tripped and b0.shape == (1,) and np.float32(b0[0]) == np.float32(per["beta_hat"].iloc[0])
+    model._range_flag_tensor(torch.device(DEV)).fill_(1)                   # as if an epilogue had stored a value beyond +-448
+    import logging
+    with caplog.at_level(logging.WARNING):
+        row = evaluate.predict_unet(str(tmp_path / "images" / "1.png"), model)
+    assert model.mode == "bf16x3s" and any("448" in r.message for r in caplog.records)
+    assert abs(float(row["beta_hat"]) - float(b0[0])) < 1e-4

@@ -86,3 +86,19 @@ def test_train_step_of_the_dropout_config(mode):
         worst[k] = rel_l2(p.grad.detach().cpu(), gref[k])
         assert worst[k] < band, (k, worst[k])
     print("dropout-config gradients, mode", mode, "worst rel L2", max(worst.values()))
+
+
+@pytest.mark.parametrize("cin,cout", [(3, 1), (2, 3)])
+def test_multi_plane_inputs_in_the_default_mode(cin, cout):
+    """VERDICT r03 missing #6: a whole unet_2 with in_channels > 1 (src/_defs/loader.py:61-103 stacks colour planes; the published runs use one)
+    and several output planes in the DEFAULT mode against the CPU oracle: the first-layer kernel reads up to 8 planes, the fused head writes up to 4."""
+    sd_np = formula.formula_state_dict(2, "he", in_channels=cin, out_channels=cout)
+    m = get_model("unet_2", in_channels=cin, out_channels=cout, channel=[0], drop_rate=None, mode=None)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()})
+    m = m.to(DEV)
+    x = torch.rand((2, cin, 64, 96), generator=torch.Generator().manual_seed(31))
+    with torch.no_grad():
+        y = m(x.to(DEV)).cpu()
+        ref = unet_ref.unet_forward(x.clone(), unet_ref.to_torch_state(sd_np), 2)
+    assert m.mode == "f16f4p" and tuple(y.shape) == (2, cout, 64, 96)
+    assert float((y - ref).abs().max()) <= 6e-4 and float((y - ref).abs().mean()) <= 5e-5, (float((y - ref).abs().max()), float((y - ref).abs().mean()))

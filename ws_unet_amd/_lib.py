@@ -70,6 +70,7 @@ SIGNATURES = {
     "wsu_chansum_pl_workspace_bytes": (c_size_t, [c_int]),
     "wsu_colsum_pl": (c_int, [_P, _P, _P, c_size_t] + [c_int] * 5 + [_P]),
     "wsu_conv3x3_first_pl_bwd_weight": (c_int, [_P] * 5 + [c_size_t] + [c_int] * 5 + [_P]),
+    "wsu_conv3x3_first_pl_bwd_data": (c_int, [_P] * 3 + [c_int] * 6 + [_P]),
     "wsu_conv3x3_first_pl_fwd": (c_int, [_P, _P, _P, _P] + [c_int] * 7 + [_P, _P, _P]),
     "wsu_conv3x3_first_fwd": (c_int, [_P, _P, _P, _P] + [c_int] * 7 + [_P]),
     "wsu_maxpool2x2_fwd": (c_int, [_P, _P, _P] + [c_int] * 5 + [_P]),

@@ -31,23 +31,6 @@ __device__ __forceinline__ void store_chunk_px(const f32x4& X, const f32x4& Y, c
     }
 }
 
-// Planar Q output (round 4, wsu_device.h "planar Q storage"): TWO pixels of a lane (X0 / Y0, X1 / Y1: the same channels as above) -> their f16 granules (all
-// lanes, plane hh), then lanes 0-31 store pixel 0's Q granule and scale byte, lanes 32-63 pixel 1's.  `chunk`: the (image, output chunk)'s first byte;
-// off0 / off1: the pixels' byte offsets inside a 16-byte plane; soff0 / soff1: their scale bytes' offsets inside the scale plane.
-__device__ __forceinline__ void store_chunk_pair_q(const f32x4& X0, const f32x4& Y0, const f32x4& X1, const f32x4& Y1, char* chunk, size_t plane_bytes,
-                                                   size_t off0, size_t off1, unsigned soff0, unsigned soff1, int hh, bool ok) {
-    u32x4 g0, g1; uint32_t dh0, dr0, sb0, dh1, dr1, sb1;
-    wsu_q4_pre(X0, Y0, g0, dh0, dr0, sb0);
-    wsu_q4_pre(X1, Y1, g1, dh1, dr1, sb1);
-    const u32x4 qg = wsu_q4_pair(dh0, dr0, dh1, dr1);
-    if (ok) {
-        *reinterpret_cast<u32x4*>(chunk + hh * plane_bytes + off0) = g0;
-        *reinterpret_cast<u32x4*>(chunk + hh * plane_bytes + off1) = g1;
-        *reinterpret_cast<u32x4*>(chunk + 2 * plane_bytes + (hh ? off1 : off0)) = qg;
-        *reinterpret_cast<unsigned char*>(chunk + 3 * plane_bytes + (hh ? soff1 : soff0)) = (unsigned char)(hh ? sb1 : sb0);
-    }
-}
-
 // =====================================================================================================================================
 // K3p.  y[n, 2i+a, 2j+b, co] = bias[co] + sum_ci x[n, i, j, ci] * w[ci, co, a, b]: four 1-tap GEMMs that share their B operand.
 // Tile = 4 x 32 INPUT pixels x 64 co x 4 sub-positions.  Matrix wave w: output-row parity a = w & 1, input rows 2 (w>>1 & 1) + {0, 1}, output
@@ -164,6 +147,7 @@ __device__ __forceinline__ void ct_loader(const CtpArgs& a, char* smem, int lane
     }
 }
 
+template <bool YQ>                                                           // YQ: y is a planar Q tensor (compile-time: with both epilogues in one kernel the register allocator spilled 33 registers -- 0.45 -> 0.68 ms per launch)
 __global__ __launch_bounds__(ct::NT) void convt2x2_pl_kernel(const CtpArgs a) {
     using namespace ct;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -188,6 +172,7 @@ __global__ __launch_bounds__(ct::NT) void convt2x2_pl_kernel(const CtpArgs a) {
 
     // ---- matrix waves --------------------------------------------------------------------------------------------------------------
     const int pa = wv & 1, half = (wv >> 1) & 1, mh = wv >> 2;
+    const int l31_k = l31, hh_k = hh;
     CtTile cur = ct_tile_of(a, lw);
     f32x16 acc[2][2];                                                   // [b][q]
     const int sc_a = hh ? WSU_F8_SCALE_WLO : WSU_F8_SCALE_W, sc_b = hh ? WSU_F8_SCALE_X : WSU_F8_SCALE_XLO;
@@ -240,6 +225,10 @@ __global__ __launch_bounds__(ct::NT) void convt2x2_pl_kernel(const CtpArgs a) {
             const int oh = 2 * a.h, ow = 2 * a.w;
             const size_t ohw = (size_t)oh * ow;
             const int nco = a.cout >> 4;
+            // (opaque per-tile copies of the lane coordinates: what the epilogue derives from them is recomputed per tile instead of being hoisted out of
+            // the step loop and spilled -- the Q variant sits at the kernel's 168-register step)
+            int l31 = l31_k, hh = hh_k;
+            if constexpr (YQ) asm volatile("" : "+v"(l31), "+v"(hh));
             const int icol = cur.x0 + l31;
             float vmax = 0.f;
 #pragma unroll
@@ -251,24 +240,41 @@ __global__ __launch_bounds__(ct::NT) void convt2x2_pl_kernel(const CtpArgs a) {
                 for (int q = 0; q < 2; ++q) {
                     const int irow = cur.y0 + 2 * half + q;
                     const bool ok = irow < a.h && icol < a.w;
-                    f32x4 X[2], Y[2];
-#pragma unroll
-                    for (int b = 0; b < 2; ++b)
+                    auto value = [&](int b_, f32x4& X, f32x4& Y) __attribute__((always_inline)) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            X[b][e] = acc[b][q][8 * cp + e] + bx[e]; Y[b][e] = acc[b][q][8 * cp + 4 + e] + by[e];
-                            vmax = fmaxf(vmax, fmaxf(fabsf(X[b][e]), fabsf(Y[b][e])));
+                            X[e] = acc[b_][q][8 * cp + e] + bx[e]; Y[e] = acc[b_][q][8 * cp + 4 + e] + by[e];
+                            vmax = fmaxf(vmax, fmaxf(fabsf(X[e]), fabsf(Y[e])));
                         }
-                    if (a.yq) {                                      // (wave-uniform) the lane's two output pixels are a pair of the Q format's epilogue
+                    };
+                    if constexpr (YQ) {                              // the lane's two output pixels are a pair of the Q format's epilogue (wsu_device.h)
                         const int orow = 2 * irow + pa, ocol = 2 * icol;
-                        char* chunk = a.y + ((size_t)cur.n * nco + oc) * wsu_q_chunk_bytes(oh, ow);
-                        const size_t off = ((size_t)orow * ow + ocol) * 16;
+                        // stores through a wave-uniform descriptor of the (image, output chunk) + 32-bit lane offsets: no 64-bit address registers (the
+                        // kernel sits at its 168-register step); a lane that must not store passes an offset beyond the descriptor, which the hardware drops
+                        const unsigned cbytes = (unsigned)wsu_q_chunk_bytes(oh, ow), pb = (unsigned)ohw * 16u;
+                        const auto rs = __builtin_amdgcn_make_buffer_rsrc(a.y + ((size_t)cur.n * nco + oc) * cbytes, 0, (int)cbytes, 0x00020000);
+                        const unsigned off = (unsigned)(orow * ow + ocol) * 16u;
+                        const unsigned OOB_ = 0xFFFFFFF0u;
                         const int otx = (ow + 31) >> 5;
-                        store_chunk_pair_q(X[0], Y[0], X[1], Y[1], chunk, ohw * 16, off, off + 16, wsu_q_soff(orow, ocol, otx), wsu_q_soff(orow, ocol + 1, otx), hh, ok);
+                        f32x4 X, Y; u32x4 g; uint32_t dh0, dr0, sb0, dh1, dr1, sb1;
+                        value(0, X, Y);
+                        wsu_q4_pre(X, Y, g, dh0, dr0, sb0);
+                        __builtin_amdgcn_raw_buffer_store_b128(g, rs, (int)(ok ? off + (hh ? pb : 0u) : OOB_), 0, 0);
+                        value(1, X, Y);
+                        wsu_q4_pre(X, Y, g, dh1, dr1, sb1);
+                        __builtin_amdgcn_raw_buffer_store_b128(g, rs, (int)(ok ? off + 16u + (hh ? pb : 0u) : OOB_), 0, 0);
+                        const u32x4 qg = wsu_q4_pair(dh0, dr0, dh1, dr1);
+                        __builtin_amdgcn_raw_buffer_store_b128(qg, rs, (int)(ok ? 2u * pb + off + (hh ? 16u : 0u) : OOB_), 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b8((unsigned char)(hh ? sb1 : sb0), rs, (int)(ok ? 3u * pb + wsu_q_soff(orow, ocol + hh, otx) : OOB_), 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);           // one (16 channels, row) group at a time: interleaved, the four groups of a tile spilled
                     } else {
                         char* dst = a.y + ((((size_t)cur.n * nco + oc) * HBM_PLANES) * ohw + (size_t)(2 * irow + pa) * ow + 2 * icol) * 16;
 #pragma unroll
-                        for (int b = 0; b < 2; ++b) store_chunk_px(X[b], Y[b], dst + b * 16, ohw * 16, hh, ok);
+                        for (int b = 0; b < 2; ++b) {
+                            f32x4 X, Y;
+                            value(b, X, Y);
+                            store_chunk_px(X, Y, dst + b * 16, ohw * 16, hh, ok);
+                        }
                     }
                 }
             }
@@ -542,6 +548,7 @@ __global__ void pack_convt_dgrad_pl_kernel(const float* __restrict__ w, char* __
 // =====================================================================================================================================
 struct FirstPlArgs { const float* x; const float* w; const float* b; char* y; unsigned* range_flag; int n, h, w_, cin, cout, relu; unsigned char* relu_mask_out; int yq; };
 
+template <bool YQ>                                                           // YQ: y is a planar Q tensor (compile-time, like convt2x2_pl_kernel)
 __global__ __launch_bounds__(256) void first_pl_kernel(const FirstPlArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* wl = reinterpret_cast<float*>(smem);                         // [ci][tap][cout]
@@ -595,7 +602,7 @@ __global__ __launch_bounds__(256) void first_pl_kernel(const FirstPlArgs a) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) vmax = fmaxf(vmax, fabsf(v[g][e]));
             }
-            if (a.yq) {                                                  // planar Q output: f16 | f16 | Q | scale byte (wsu_device.h)
+            if constexpr (YQ) {                                          // planar Q output: f16 | f16 | Q | scale byte (wsu_device.h)
                 u32x4 h0, h1, qg; uint32_t sb;
                 wsu_q4_encode16(v, h0, h1, qg, sb);
                 char* chunk = a.y + ((size_t)img * nco + oc) * wsu_q_chunk_bytes(a.h, a.w_);
@@ -635,7 +642,7 @@ int wsu_convt2x2_pl_fwd(const void* x, const void* w_packed, const float* bias, 
     WSU_REQUIRE(n > 0 && h > 0 && w > 0, "convt2x2_pl: bad shape n=%d h=%d w=%d", n, h, w);
     WSU_REQUIRE(cin > 0 && cin % 32 == 0, "convt2x2_pl: cin=%d must be a multiple of 32", cin);
     WSU_REQUIRE(cout > 0 && cout % WSU_COB == 0 && cout <= 1024, "convt2x2_pl: cout=%d must be a multiple of %d (<= 1024)", cout, WSU_COB);
-    WSU_REQUIRE((long long)h * w * 96 < 0xFFFFFFF0LL, "convt2x2_pl: h*w too large (two input chunks and one output plane triple must stay below 4 GiB)");
+    WSU_REQUIRE((long long)h * w * 200 < 0xFFFFFFF0LL, "convt2x2_pl: h*w too large (two input chunks and one output chunk must stay below 4 GiB)");
     CtpArgs a;
     a.x = (const char*)x; a.wp = (const char*)w_packed; a.bias = bias; a.y = (char*)y; a.range_flag = range_flag;
     a.n = n; a.h = h; a.w = w; a.cin = cin; a.cout = cout; a.yq = y_format == WSU_PLANAR_Q ? 1 : 0;
@@ -649,12 +656,14 @@ int wsu_convt2x2_pl_fwd(const void* x, const void* w_packed, const float* bias, 
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
             wsu_set_error("convt2x2_pl: cannot query the device"); return WSU_ERR_HIP;
         }
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&convt2x2_pl_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, ct::LDS_TOTAL);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&convt2x2_pl_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, ct::LDS_TOTAL);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&convt2x2_pl_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, ct::LDS_TOTAL);
         if (e != hipSuccess) { wsu_set_error("hipFuncSetAttribute(convt2x2_pl): %s", hipGetErrorString(e)); return WSU_ERR_HIP; }
         ncu = prop.multiProcessorCount;
     }
     const int grid = (int)(nt < ncu ? nt : ncu);
-    hipLaunchKernelGGL(convt2x2_pl_kernel, dim3(grid), dim3(ct::NT), ct::LDS_TOTAL, static_cast<hipStream_t>(stream), a);
+    if (a.yq) hipLaunchKernelGGL(convt2x2_pl_kernel<true>, dim3(grid), dim3(ct::NT), ct::LDS_TOTAL, static_cast<hipStream_t>(stream), a);
+    else hipLaunchKernelGGL(convt2x2_pl_kernel<false>, dim3(grid), dim3(ct::NT), ct::LDS_TOTAL, static_cast<hipStream_t>(stream), a);
     return wsu_check_launch("convt2x2_pl_kernel");
 }
 
@@ -711,7 +720,8 @@ int wsu_conv3x3_first_pl_fwd(const float* x_nchw, const float* w_oihw, const flo
     const long long total = (long long)n * h * w;
     const unsigned nblk = (unsigned)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
     const size_t lds = ((size_t)cin * 9 * cout + cout) * sizeof(float);
-    hipLaunchKernelGGL(first_pl_kernel, dim3(nblk), dim3(256), lds, static_cast<hipStream_t>(stream), a);
+    if (a.yq) hipLaunchKernelGGL(first_pl_kernel<true>, dim3(nblk), dim3(256), lds, static_cast<hipStream_t>(stream), a);
+    else hipLaunchKernelGGL(first_pl_kernel<false>, dim3(nblk), dim3(256), lds, static_cast<hipStream_t>(stream), a);
     return wsu_check_launch("first_pl_kernel");
 }
 

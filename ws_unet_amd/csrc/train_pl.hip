@@ -366,6 +366,56 @@ __global__ __launch_bounds__(256) void block_sum_kernel(const float* __restrict_
     if (lane == 0) out[i] = sacc;
 }
 // first layer: [c][10] sums -> dw (c, 1, 3, 3), db (c)
+// K7p (round 4): data gradient of the first layer from a PLANAR gradient -- the input gradient of the planar training path (saliency,
+// src/saliency.py:159-174; VERDICT r03 missing #4: a default-mode model used to switch to the fp32-storage kernels for this call).
+// dx[n,ci,y,x] = sum over the padded positions that reflect onto (y,x) of sum_{u,v,co} W[co,ci,u,v] * g[n, yp-u+1, xp-v+1, co] (g zero outside the
+// image): one thread per input element, consecutive lanes = consecutive pixels of a row (16 contiguous bytes per lane and plane), weights as
+// [tap][co] in LDS, fp32 accumulation in a fixed order.  `gres` = 0: the gradient carries no residual plane (products F16).
+__global__ __launch_bounds__(256) void first_dgrad_pl_kernel(const char* __restrict__ g, const float* __restrict__ w, float* __restrict__ dx,
+                                                             int n, int h, int wd, int cin, int c, int gres) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* wl = reinterpret_cast<float*>(smem);                 // [ci][tap][co]
+    for (int i = threadIdx.x; i < cin * 9 * c; i += blockDim.x) {
+        const int co = i % c, tap = (i / c) % 9, ci = i / (9 * c);
+        wl[i] = w[((size_t)co * cin + ci) * 9 + tap];
+    }
+    __syncthreads();
+    const size_t hw = (size_t)h * wd;
+    const int nch = c >> 4;
+    const long long total = (long long)n * cin * hw;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % wd); long long t = i / wd;
+        const int y = (int)(t % h); t /= h;
+        const int ci = (int)(t % cin); const int img = (int)(t / cin);
+        int ys[3], xs[3]; int ny = 0, nx = 0;
+        ys[ny++] = y; if (y == 1) ys[ny++] = -1; if (y == h - 2) ys[ny++] = h;
+        xs[nx++] = x; if (x == 1) xs[nx++] = -1; if (x == wd - 2) xs[nx++] = wd;
+        float acc = 0.f;
+        for (int iy = 0; iy < ny; ++iy)
+            for (int ix = 0; ix < nx; ++ix)
+                for (int u = 0; u < 3; ++u) {
+                    const int sy = ys[iy] - u + 1;
+                    if (sy < 0 || sy >= h) continue;
+                    for (int v = 0; v < 3; ++v) {
+                        const int sx = xs[ix] - v + 1;
+                        if (sx < 0 || sx >= wd) continue;
+                        const size_t pix = (size_t)sy * wd + sx;
+                        const float* wp = wl + (ci * 9 + u * 3 + v) * c;
+                        float s_ = 0.f;
+                        for (int ch = 0; ch < nch; ++ch) {
+                            float gv[16];
+                            pl_decode16(*reinterpret_cast<const u32x4*>(g + pl_off(img, nch, ch, 0, hw, pix)), *reinterpret_cast<const u32x4*>(g + pl_off(img, nch, ch, 1, hw, pix)),
+                                        gres ? *reinterpret_cast<const u32x4*>(g + pl_off(img, nch, ch, 2, hw, pix)) : mk_u4(0, 0, 0, 0), WSU_F8_GLO_DIV, gv);
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) s_ = fmaf(gv[e], wp[ch * 16 + e], s_);
+                        }
+                        acc += s_;
+                    }
+                }
+        dx[i] = acc;
+    }
+}
+
 __global__ void first_split_kernel(const float* __restrict__ sums, float* __restrict__ dw, float* __restrict__ db, int c) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= c * 10) return;
@@ -465,6 +515,18 @@ int wsu_conv3x3_first_pl_bwd_weight(const void* g, const float* img, float* dw, 
     if (rc) return rc;
     hipLaunchKernelGGL(first_split_kernel, dim3((c * 10 + 63) / 64), dim3(64), 0, s, (const float*)sums, dw, db, c);
     return wsu_check_launch("first_split_kernel");
+}
+
+// K7p: data gradient of the first layer: g (planar gradient, c channels at h x w), w_oihw (c, cin, 3, 3) fp32 -> dx (N, cin, H, W) fp32 (in g's scale).
+int wsu_conv3x3_first_pl_bwd_data(const void* g, const float* w_oihw, float* dx_nchw, int n, int h, int w, int cin, int c, int products, void* stream) {
+    WSU_REQUIRE(g && w_oihw && dx_nchw, "conv3x3_first_pl_bwd_data: null pointer");
+    WSU_REQUIRE(products == WSU_PRODUCTS_F16F8 || products == WSU_PRODUCTS_F16, "conv3x3_first_pl_bwd_data: products must be WSU_PRODUCTS_F16F8 or WSU_PRODUCTS_F16");
+    WSU_REQUIRE(n > 0 && h >= 2 && w >= 2 && cin >= 1 && cin <= 8 && c >= 16 && c <= 256 && c % 16 == 0, "conv3x3_first_pl_bwd_data: bad shape cin=%d c=%d", cin, c);
+    const long long total = (long long)n * cin * h * w;
+    const unsigned nblk = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(first_dgrad_pl_kernel, dim3(nblk), dim3(256), (size_t)cin * 9 * c * sizeof(float), static_cast<hipStream_t>(stream),
+                       (const char*)g, w_oihw, dx_nchw, n, h, w, cin, c, products == WSU_PRODUCTS_F16 ? 0 : 1);
+    return wsu_check_launch("first_dgrad_pl_kernel");
 }
 
 }  // extern "C"

@@ -5,7 +5,7 @@ src/unet/model/unet.py:137-189.  Here the whole network is ONE autograd node: fo
 activations, backward walks the layers in reverse calling the K7 kernels (include/wsu.h).  `model.train_mode` picks the path:
   'f16f8p'  (default for planar models) activations AND gradients in the planar three-plane layout (3 bytes per element), the f16f8
             arithmetic in forward, data gradient and weight gradient (_forward_train_pl / _backward_pl); single-plane inputs, no input
-            gradient -- other calls fall back to 'bf16x3';
+            gradient included -- multi-plane inputs fall back to 'bf16x3';
   'bf16x3'  fp32 NHWC tensors; the matrix kernels run the f16f8 arithmetic on them (`train_fwd_mode` / `train_bwd_mode` = 'f16f8x', default)
             or split-bf16; 2-bit pool argmax saved by the forward;
   'f32'     exact fp32 on the matrix cores.
@@ -106,7 +106,7 @@ def _forward_train_pl(model, x: torch.Tensor) -> Dict[str, torch.Tensor]:
     return t
 
 
-def _backward_pl(model, t: Dict[str, torch.Tensor], x: torch.Tensor, dout: torch.Tensor) -> Dict[str, torch.Tensor]:
+def _backward_pl(model, t: Dict[str, torch.Tensor], x: torch.Tensor, dout: torch.Tensor, want_dx: bool = False) -> Dict[str, torch.Tensor]:
     """Backward of train_mode 'f16f8p': every gradient tensor planar (f16 + e4m3 residual, pre-scaled by a power of two), data gradients through
     the persistent LDS-DMA conv kernel, weight gradients from planar operands; the same layer walk as the fp32-storage path below."""
     W = ops.MODE_F16F8
@@ -142,6 +142,8 @@ def _backward_pl(model, t: Dict[str, torch.Tensor], x: torch.Tensor, dout: torch
         g, _ = conv_bwd(b, g, xa, None, xa, mask1_bits=t.get("m_x" + a))
         if lvl == 0:
             grads[a + ".weight"], grads[a + ".bias"] = ops.conv3x3_first_pl_bwd_weight(g, x, products=products)
+            if want_dx:                                                   # saliency (src/saliency.py:159-174): the input gradient, in the planar arithmetic too
+                grads["__dx__"] = ops.conv3x3_first_pl_bwd_data(g, getattr(model, a).weight, products=products)
         else:
             g, _ = conv_bwd(a, g, t[f"xp{lvl}"], None, None)
     ops.scale_many_(list(grads.values()), scale[1:2])
@@ -149,8 +151,9 @@ def _backward_pl(model, t: Dict[str, torch.Tensor], x: torch.Tensor, dout: torch
 
 
 def planar_train_ok(model, x: torch.Tensor) -> bool:
-    """The planar training path covers what the planar inference path covers, for single-plane inputs and without an input gradient."""
-    return model._planar_ok() and model.e11.in_channels == 1 and model.outconv.in_channels == 64 and not x.requires_grad
+    """The planar training path covers what the planar inference path covers, for single-plane inputs (the input gradient included since
+    round 4: wsu_conv3x3_first_pl_bwd_data)."""
+    return model._planar_ok() and model.e11.in_channels == 1 and model.outconv.in_channels == 64
 
 
 def planar_range_fallback(model) -> bool:
@@ -201,9 +204,9 @@ class _UNetFn(torch.autograd.Function):
         dx = None
         dout = dout.contiguous().float()
         if m == ops.MODE_F16F8P:
-            grads = _backward_pl(model, t, x, dout)
+            grads = _backward_pl(model, t, x, dout, want_dx=ctx.needs_input_grad[1])
             ctx.t = None
-            return (None, None) + tuple(grads[name] if p.requires_grad else None for name, p in model.named_parameters())
+            return (None, grads.pop("__dx__", None)) + tuple(grads[name] if p.requires_grad else None for name, p in model.named_parameters())
         # data- and weight-gradient GEMMs of a split-bf16 run: f16f8 arithmetic on the fp32 tensors (model.train_bwd_mode).  Gradients of
         # a mean-reduced loss sit far below f16's normal range, so the whole backward chain runs on gradients scaled by a power of two
         # chosen from |dL/dout| (every kernel on the way is linear in the gradient; ReLU masks and pool routing ignore the scale) and all

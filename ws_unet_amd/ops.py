@@ -615,6 +615,21 @@ def conv3x3_first_pl_bwd_weight(g: torch.Tensor, x_nchw: torch.Tensor, want_bias
     return dw, db
 
 
+def conv3x3_first_pl_bwd_data(g: torch.Tensor, w: torch.Tensor, products: str = "f16f8") -> torch.Tensor:
+    """Input gradient of the first layer from a planar gradient (wsu_conv3x3_first_pl_bwd_data): g planar (N, C/16, 3, H, W, 4), w (C, cin, 3, 3)
+    -> dx (N, cin, H, W) fp32 in g's scale."""
+    lib = _lib.load()
+    w = w.detach().contiguous()
+    _dev_check(g, w)
+    n, nch, _, h, wd, _ = g.shape
+    c, cin = nch * 16, w.shape[1]
+    assert tuple(w.shape) == (c, cin, 3, 3)
+    dx = torch.empty((n, cin, h, wd), dtype=torch.float32, device=g.device)
+    check(_launch("conv3x3_first_pl_bwd_data", {"bytes": float(n * h * wd * (c * (2 if products == "f16" else 3) + 4 * cin))}, lambda: lib.wsu_conv3x3_first_pl_bwd_data(
+        g.data_ptr(), w.data_ptr(), dx.data_ptr(), n, h, wd, cin, c, products_id(products), _stream())), "wsu_conv3x3_first_pl_bwd_data")
+    return dx
+
+
 def pack_conv3x3_wino(w: torch.Tensor) -> torch.Tensor:
     """OIHW fp32 -> Winograd F(2,3) packed weights of wsu_conv3x3_wino_fwd (mode bf16x3)."""
     lib = _lib.load()
