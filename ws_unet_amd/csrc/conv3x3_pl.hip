@@ -444,6 +444,8 @@ __device__ __forceinline__ void pl_loader(const PlArgs& a, char* smem, int lane,
 }
 
 
+template <bool ON> __device__ __forceinline__ int opaque_if(int v) { if constexpr (ON) asm volatile("" : "+v"(v)); return v; }
+
 // HEAD / POOL are compile-time: the kernel sits at the 168-register step (three waves per SIMD), and the head's partial sums or the pool's
 // exchange registers would otherwise be carried -- and spilled -- by the variants that do not use them.
 // XRES = false: the activations' residual plane is neither loaded nor multiplied (one cross term per product, the weights' residual:
@@ -465,6 +467,7 @@ void conv3x3_pl_kernel(const PlArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+    const int l31_k = l31, hh_k = hh;
     const int G = gridDim.x;
     const int lw = (int)wsu_xcd_remap(blockIdx.x, G);
     const int K = a.ntiles > lw ? (a.ntiles - lw + G - 1) / G : 0;           // tiles walked by this workgroup
@@ -668,6 +671,9 @@ _Pragma("unroll")
         };
         // ---- epilogue of the tile: accumulators -> planar global memory ---------------------------------------------------------
         auto finish_tile = [&]() __attribute__((always_inline)) {
+            // (HC = 4, the four-plane head: opaque per-tile copies of the lane coordinates -- hoisted out of the tile loop, what the epilogue derives
+            // from them pushed this variant two registers past its 168-register step; the other variants are untouched)
+            const int l31 = opaque_if<HC == 4>(l31_k), hh = opaque_if<HC == 4>(hh_k);
             const int col = cur.x0 + l31;
             const size_t hw = (size_t)a.h * a.w;
             const int nco = a.cout >> 4;                                       // output chunks
