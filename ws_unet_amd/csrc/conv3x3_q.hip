@@ -24,6 +24,12 @@
 #ifndef WSU_Q_EPO
 #define WSU_Q_EPO 1             // 1 = the last step of a tile is split by accumulator tile and its second half shares a basic block with the first half of the epilogue
 #endif
+#ifndef WSU_Q_PIPE2
+#define WSU_Q_PIPE2 0           // experiment: 1 = the eight-wave organisation (RQ = 2) also issues the fragment reads of unit u + 1 before the matrix instructions of unit u
+#endif
+#ifndef WSU_Q_PIPE_DEPTH
+#define WSU_Q_PIPE_DEPTH 1      // units of fragment reads in flight in front of the matrix instructions that use them (explicit pipeline)
+#endif
 #ifndef WSU_Q_EPO_FENCE
 #define WSU_Q_EPO_FENCE 1       // 1 = one scheduling region per hook of that block (RQ = 4: without the fences the scheduler hoists the fragment reads of all five tap
 #endif                          //     pairs above the epilogue and spills 60-70 registers)
@@ -191,8 +197,8 @@ void conv3x3_q_kernel(const QArgs a) {
     // ================= matrix waves ===================================================================================================
     Tile cur = tile_of(a, lw);
     constexpr int MH = MSPLIT ? 1 : 2;                                        // accumulator tiles along the output channels
-    constexpr bool PIPE = RQ == 4;                                            // explicit software pipeline of the fragment reads (below)
-    constexpr bool EPO = WSU_Q_EPO && !MSPLIT && HC == 0 && !PIPE;
+    constexpr bool PIPE = RQ == 4 || WSU_Q_PIPE2;                             // explicit software pipeline of the fragment reads (below)
+    constexpr bool EPO = WSU_Q_EPO && !MSPLIT && HC == 0 && RQ != 4;
     f32x16 acc[2][4];                                                         // [MH][RQ] used (fixed bounds: a template-dependent bound made hipcc (ROCm 7.2) drop the host stubs)
     int kt = 0, j = 0;
     unsigned q_in_off = 0, q_w_off = 0;                                       // this step's input / weight slot
@@ -341,18 +347,18 @@ _Pragma("unroll")
         }
     };
     auto units_pipelined = [&]() __attribute__((always_inline)) {
-        constexpr int NU = 14;
-        Frag fr[2];
-        load_unit(std::integral_constant<int, 0>{}, fr[0]);
+        constexpr int NU = 14, D = WSU_Q_PIPE_DEPTH, NS = D + 1;              // D units of reads in flight, NS fragment sets
+        Frag fr[NS];
+        WSU_STATIC_FOR(D, u, { load_unit(u_c, fr[u % NS]); });
         WSU_STATIC_FOR(NU, u, {
-            if constexpr (u + 1 < NU) load_unit(std::integral_constant<int, u + 1>{}, fr[(u + 1) & 1]);
+            if constexpr (u + D < NU) load_unit(std::integral_constant<int, u + D>{}, fr[(u + D) % NS]);
             __builtin_amdgcn_sched_barrier(0);                                // (the reads FIRST: left to itself the scheduler sinks them behind most of the unit's matrix instructions)
-            mma_unit(u_c, fr[u & 1]);
+            mma_unit(u_c, fr[u % NS]);
             __builtin_amdgcn_sched_barrier(0);
         });
     };
     auto units_all = [&](auto ms_c) __attribute__((always_inline)) {
-        if constexpr (PIPE) { units_pipelined(); return; }
+        if constexpr (PIPE && decltype(ms_c)::value < 0) { units_pipelined(); return; }      // (the split last step of EPO keeps the unpipelined units of its half)
         units_range(ms_c, std::integral_constant<int, 0>{}, std::integral_constant<int, 5>{});
     };
 
