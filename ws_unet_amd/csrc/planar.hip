@@ -548,8 +548,8 @@ __global__ void pack_convt_dgrad_pl_kernel(const float* __restrict__ w, char* __
 // =====================================================================================================================================
 struct FirstPlArgs { const float* x; const float* w; const float* b; char* y; unsigned* range_flag; int n, h, w_, cin, cout, relu; unsigned char* relu_mask_out; int yq; };
 
-template <bool YQ>                                                           // YQ: y is a planar Q tensor (compile-time, like convt2x2_pl_kernel)
-__global__ __launch_bounds__(256) void first_pl_kernel(const FirstPlArgs a) {
+template <bool YQ, int CINMAX>                                              // YQ: y is a planar Q tensor (compile-time, like convt2x2_pl_kernel); CINMAX: 1 (the
+__global__ __launch_bounds__(256) void first_pl_kernel(const FirstPlArgs a) {   // published runs' single plane: 9 window registers instead of 72) or 8
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* wl = reinterpret_cast<float*>(smem);                         // [ci][tap][cout]
     float* bl = wl + a.cin * 9 * a.cout;
@@ -566,9 +566,9 @@ __global__ __launch_bounds__(256) void first_pl_kernel(const FirstPlArgs a) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int x = (int)(i % a.w_); long long t = i / a.w_;
         const int y = (int)(t % a.h); const int img = (int)(t / a.h);
-        float p[8][9];
+        float p[CINMAX][9];
 #pragma unroll
-        for (int ci = 0; ci < 8; ++ci)
+        for (int ci = 0; ci < CINMAX; ++ci)
             if (ci < a.cin) {
                 const float* src = a.x + ((size_t)img * a.cin + ci) * hw;
 #pragma unroll
@@ -576,22 +576,39 @@ __global__ __launch_bounds__(256) void first_pl_kernel(const FirstPlArgs a) {
                     p[ci][tp] = src[(size_t)wsu_reflect(y + tp / 3 - 1, a.h) * a.w_ + wsu_reflect(x + tp % 3 - 1, a.w_)];
             }
         for (int oc = 0; oc < nco; ++oc) {
-            f32x4 v[4];
+            // 16 channels = eight accumulator PAIRS updated by v_pk_fma_f32 (two fused multiply-adds per instruction: bitwise the fmaf chain, half the
+            // issue slots; VERDICT r03 next #8: -fno-slp-vectorize took the compiler's packed forms away and cost this kernel 5-8 %).  Written by
+            // hand because of the packed-f32 read-after-write hazard (profiles/r03/pk_hazard.md): a pair is re-read eight instructions later by its
+            // own next tap, and an explicit `s_nop 0` separates the last update from the epilogue's first read (tests/test_isa_lint.py scans for
+            // adjacent producer / consumer pairs).
+            f32x2 acc2[8];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) v[g] = *reinterpret_cast<const f32x4*>(bl + oc * 16 + 4 * g);
+            for (int k = 0; k < 8; ++k) acc2[k] = *reinterpret_cast<const f32x2*>(bl + oc * 16 + 2 * k);
 #pragma unroll
-            for (int ci = 0; ci < 8; ++ci)
+            for (int ci = 0; ci < CINMAX; ++ci)
                 if (ci < a.cin)
 #pragma unroll
                     for (int tp = 0; tp < 9; ++tp) {
                         const float* wr = wl + (ci * 9 + tp) * a.cout + oc * 16;
+                        // (packed operands are 64-bit register pairs: the window value rides in one half of a pair and op_sel / op_sel_hi pick that half for both products)
+                        const f32x2 pw = {p[ci][tp & ~1], p[ci][(tp | 1) < 9 ? (tp | 1) : tp]};
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
                             const f32x4 w4 = *reinterpret_cast<const f32x4*>(wr + 4 * g);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[g][e] = fmaf(p[ci][tp], w4[e], v[g][e]);
+                            const f32x2 wlo = {w4[0], w4[1]}, whi = {w4[2], w4[3]};
+                            if (tp & 1) {
+                                asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc2[2 * g]) : "v"(pw), "v"(wlo));
+                                asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc2[2 * g + 1]) : "v"(pw), "v"(whi));
+                            } else {
+                                asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(acc2[2 * g]) : "v"(pw), "v"(wlo));
+                                asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(acc2[2 * g + 1]) : "v"(pw), "v"(whi));
+                            }
                         }
                     }
+            asm volatile("s_nop 0" ::: "memory");
+            f32x4 v[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) v[g] = mk_f4(acc2[2 * g][0], acc2[2 * g][1], acc2[2 * g + 1][0], acc2[2 * g + 1][1]);
             uint32_t h[8], lo[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -720,8 +737,14 @@ int wsu_conv3x3_first_pl_fwd(const float* x_nchw, const float* w_oihw, const flo
     const long long total = (long long)n * h * w;
     const unsigned nblk = (unsigned)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
     const size_t lds = ((size_t)cin * 9 * cout + cout) * sizeof(float);
-    if (a.yq) hipLaunchKernelGGL(first_pl_kernel<true>, dim3(nblk), dim3(256), lds, static_cast<hipStream_t>(stream), a);
-    else hipLaunchKernelGGL(first_pl_kernel<false>, dim3(nblk), dim3(256), lds, static_cast<hipStream_t>(stream), a);
+    hipStream_t s_ = static_cast<hipStream_t>(stream);
+    if (cin == 1) {
+        if (a.yq) hipLaunchKernelGGL((first_pl_kernel<true, 1>), dim3(nblk), dim3(256), lds, s_, a);
+        else hipLaunchKernelGGL((first_pl_kernel<false, 1>), dim3(nblk), dim3(256), lds, s_, a);
+    } else {
+        if (a.yq) hipLaunchKernelGGL((first_pl_kernel<true, 8>), dim3(nblk), dim3(256), lds, s_, a);
+        else hipLaunchKernelGGL((first_pl_kernel<false, 8>), dim3(nblk), dim3(256), lds, s_, a);
+    }
     return wsu_check_launch("first_pl_kernel");
 }
 
