@@ -294,6 +294,9 @@ class UNet(nn.Module):
         return res
 
     def _range_flag_tensor(self, device) -> torch.Tensor:
+        device = torch.device(device)
+        if device.type == "cuda" and device.index is None:           # 'cuda' and 'cuda:0' name the same card: do not replace a live flag word
+            device = torch.device("cuda", torch.cuda.current_device())
         rf = getattr(self, "_range_flag", None)
         if rf is None or rf.device != device:
             rf = self._range_flag = torch.zeros(1, dtype=torch.int32, device=device)
