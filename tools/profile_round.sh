@@ -1,5 +1,5 @@
 # Refreshes the numbers under profiles/: run on the GPU box from the repo root (tools/profile_round.sh), then copy gpurun_out/prof_round/*
-set -e
+set -e   # (a failing step stops the script: nothing below it would be trustworthy)
 R=$GRAFT_REPO_ROOT; [ -n "$R" ] || R=$(pwd)
 O=$R/gpurun_out/prof_round
 mkdir -p $O
