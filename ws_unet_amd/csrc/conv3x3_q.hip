@@ -30,6 +30,9 @@
 #ifndef WSU_Q_PIPE_DEPTH
 #define WSU_Q_PIPE_DEPTH 1      // units of fragment reads in flight in front of the matrix instructions that use them (explicit pipeline)
 #endif
+#ifndef WSU_Q_PROBE_NOX8
+#define WSU_Q_PROBE_NOX8 0      // timing-only probe (results wrong; make qnox8): 1 = the half-empty fp4 instruction of the unpaired ninth tap is skipped
+#endif                          // (profiles/r04/ab_forward_organisations.md, third A/B: the time follows the ENERGY of the useful products)
 #ifndef WSU_Q_EPO_FENCE
 #define WSU_Q_EPO_FENCE 1       // 1 = one scheduling region per hook of that block (RQ = 4: without the fences the scheduler hoists the fragment reads of all five tap
 #endif                          //     pairs above the epilogue and spills 60-70 registers)
@@ -279,7 +282,7 @@ _Pragma("unroll")
         if constexpr (EPO) asm volatile("" : "+v"(hh_q));                     // (per call: the paths of a step must not share -- and hoist -- their lane offsets)
         WSU_STATIC_FOR(hi - lo, i, {
             constexpr int tp = lo + i;
-            cross_q4(std::integral_constant<int, tp>{}, ms_c);
+            if constexpr (!(WSU_Q_PROBE_NOX8 && tp == 4)) cross_q4(std::integral_constant<int, tp>{}, ms_c);
             main_term(std::integral_constant<int, 2 * tp>{}, ms_c);
             if constexpr (2 * tp + 1 < 9) main_term(std::integral_constant<int, 2 * tp + 1>{}, ms_c);
         });
