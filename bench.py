@@ -343,7 +343,7 @@ def sq_counters(args, ckey="conv3x3_pl"):
         out.update({"mfma_busy": k.get("mfma_busy"), "mfma_busy_time_based": k.get("mfma_busy_t"), "clock_GHz_profiled": k.get("clock_GHz"),
                     "wave_wait_any_share": k.get("sq_wait_any_share"), "wave_wait_inst_share": k.get("sq_wait_inst_any_share"),
                     "wave_active_share": k.get("sq_active_inst_any_share"),
-                    "note": "SQ_VALU_MFMA_BUSY_CYCLES / (32 x SQ_BUSY_CYCLES) over the conv3x3_pl launches of this command under rocprofv3 --pmc "
+                    "note": f"SQ_VALU_MFMA_BUSY_CYCLES / (32 x SQ_BUSY_CYCLES) over the {ckey} launches of this command under rocprofv3 --pmc "
                             "(product libwsu.so; profiled passes run ~3 % below the un-profiled clock)"})
     return out
 
