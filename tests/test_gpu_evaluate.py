@@ -156,6 +156,15 @@ def test_sharded_dataset_evaluate_and_cli(tmp_path, mode):
     table = pd.read_csv(out)
     assert len(table) == 7 and table["name"].tolist()[:5] == ref_c["name"].tolist()
     np.testing.assert_allclose(table["beta_hat"].to_numpy(float)[:5], ref_c["beta_hat"].to_numpy(float), atol=2e-5)
+    # the same driver fed from pre-decoded uint8 shards (written on first use): the identical CSV
+    out2 = tmp_path / "res" / "ws_shards.csv"
+    try:
+        evaluate.main(["--data", str(data), "--model-dir", str(tmp_path / "models"), "--stego-method", "LSBR", "--eval-methods", "LSBR",
+                       "--out", str(out2), "--u8-shards", str(tmp_path / "shards")] + (["--mode", mode] if mode else []))
+    finally:
+        evaluate.use_u8_shards(None)
+    assert (tmp_path / "shards" / "index.json").exists()
+    pd.testing.assert_frame_equal(pd.read_csv(out2), table)
 
 
 def test_range_guard_looks_once_per_dataset_pass(tmp_path, caplog):
