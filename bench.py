@@ -263,7 +263,7 @@ def compact_line(result: dict) -> dict:
         roof["per_layer"]["layers"] = [[row["layer"], row["ms"], row.get(key, row.get("frac"))] for row in pl["layers"]]
     for k in ("note", "traffic_unit"):
         roof.pop(k, None)
-    for sub in ("mfma_issue", "mfma_busy", "convt2x2"):
+    for sub in ("mfma_issue", "mfma_busy", "convt2x2", "fused_up", "all_conv"):
         if isinstance(roof.get(sub), dict):
             roof[sub].pop("note", None)
     if isinstance(r.get("latency_b1"), dict):
@@ -545,7 +545,7 @@ def main():
             "avg_launch_ms": conv["avg_ms"], "launches": conv["launches"],
             "algorithmic_gflop_per_launch": conv["flops"] / conv["launches"] / 1e9,
             "hbm_GBps_algorithmic": conv["bytes"] / (conv["total_ms"] * 1e-3) / 1e9,
-            "note": "algorithmic FLOPs = 2*9*Cin*Cout*N*H*W summed over the 9 conv3x3 launches of a forward "
+            "note": "algorithmic FLOPs = 2*9*Cin*Cout*N*H*W summed over this kernel's conv3x3 launches of a forward (9; 7 when the decoder blocks' first convs run fused with their transposed convs: roofline.fused_up) "
                     "(the split modes issue extra MFMAs per product -- bf16x3: 3 bf16; f16f8: 1 f16 + one fp8 instruction per tap pair -- they are not counted)",
         }
         # matrix-pipe occupancy next to the algorithmic fraction: one unit = one 32x32x16 bf16/f16 MFMA (32 cycles, 32 768 FLOP); per
@@ -556,6 +556,19 @@ def main():
             roofline["mfma_issue"] = {"units_per_product": units, "tflops_equivalent": achieved * units / 1e12,
                                       "frac_of_peak": achieved * units / PEAK[args.mode],
                                       "note": "matrix-pipe time actually issued (split terms included) against the same dense bf16 peak"}
+        if "conv3x3_up_q" in ks:
+            # the decoder blocks' fused entries (transposed conv + concat + first 3x3 conv in one launch, csrc/conv3x3_qu.hip): priced at the
+            # ALGORITHMIC work of the two reference ops they replace (the kernel itself executes 512 instead of 576 + 64 multiply-adds per
+            # output and low-resolution channel pair), and the whole 3x3-conv family together
+            fu = ks["conv3x3_up_q"]
+            ach = fu["flops"] / (fu["total_ms"] * 1e-3)
+            roofline["fused_up"] = {"kernel": "conv3x3_qu_kernel", "bound": "mfma", "achieved": ach / 1e12, "peak": PEAK[args.mode] / 1e12, "unit": "TFLOP/s",
+                                    "frac": ach / PEAK[args.mode], "avg_launch_ms": fu["avg_ms"], "launches": fu["launches"],
+                                    "algorithmic_gflop_per_launch": fu["flops"] / fu["launches"] / 1e9,
+                                    "note": "algorithmic FLOPs = nn.ConvTranspose2d(k2,s2) + the 3x3 conv over cat[xu, skip] (unet.py:177-179,183-185), both ops of the reference"}
+            tot_f, tot_t = conv["flops"] + fu["flops"], conv["total_ms"] + fu["total_ms"]
+            roofline["all_conv"] = {"achieved": tot_f / (tot_t * 1e-3) / 1e12, "frac": tot_f / (tot_t * 1e-3) / PEAK[args.mode], "ms_per_step": tot_t / args.steps,
+                                    "note": "conv3x3_q_kernel + conv3x3_qu_kernel launches together"}
         roofline.update(pmc_traffic(args, conv["bytes"] / conv["launches"], ckey + "_kernel"))
         busy = sq_counters(args, ckey)
         if busy is not None and "mfma_issue" in roofline:

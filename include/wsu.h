@@ -179,6 +179,26 @@ int wsu_conv3x3_q_fwd(const void* x1, const void* x2, const void* w_packed_f4, c
                       const float* head_w, const float* head_b, float* head_out, float* head_logit, int head_cout,
                       int n, int h, int w, int c1, int c2, int cout, int relu, int y_format, unsigned* range_flag, void* stream);
 
+/* ---- K1u (round 4): a decoder block's transposed conv + concat + first 3x3 conv in ONE launch, default inference mode (csrc/conv3x3_qu.hip):
+ *          y = relu(conv3x3_reflect(cat[conv_transpose2x2_s2(x_low), x_skip]))        (unet.py:171-173, 177-179, 183-185)
+ *      There is no non-linearity between the two convs, so the upsampled half is a 2 x 2-tap conv on x_low with weights combined per PARITY CLASS of
+ *      the output pixel (row parity py, column parity px): Wc[py,px][dy,dx][co][c] = sum_ci sum_{(ky,kx) -> (dy,dx)} w3[co][ci][ky][kx] wT[c][ci][sy][sx],
+ *      reading x_low rows i - 1 + py + dy, columns j - 1 + px + dx of output pixel (2 i + py, 2 j + px), CLAMPED at the border (= the reflect
+ *      padding of the upsampled tensor); the transposed conv's bias folds into one combined bias per output channel.  512 instead of 576
+ *      multiply-adds per output and channel pair, no transposed-conv launch, and the upsampled tensor never exists.  Arithmetic and operand
+ *      formats as K1q (f16 products + block-scaled fp4 cross terms, planar Q tensors in and out).
+ *      wsu_conv3x3_up_pack: w3 (cout, cup + c2, 3, 3) OIHW fp32 (input channels [0, cup) = the upsampled tensor, as torch.cat([xu, skip]) orders
+ *      them), wt (cl, cup, 2, 2) fp32 (nn.ConvTranspose2d), bt (cup) / b3 (cout) biases or NULL -> w_low_packed (wsu_conv3x3_up_packed_bytes: per
+ *      (64-co block, 16-channel chunk of x_low, dy) a 25 KB slice [class 4][dx 2][plane 3][64 co][16 B] + [8][64] scale bytes), bias_out (cout
+ *      floats), and optionally wc_dense (cout * cl * 16 floats, [cout][cl][py][px][dy][dx]).  The skip half is wsu_conv3x3_pack_f4 of w3[:, cup:].
+ *      wsu_conv3x3_up_q_fwd: x_low planar Q (cl channels at h/2 x w/2), x_skip planar Q (c2 channels at h x w) -> y planar Q (cout at h x w).
+ *      h, w even; cl, c2 positive multiples of 16; cout a multiple of 64, <= 512.  Asynchronous; allocates nothing. */
+size_t wsu_conv3x3_up_packed_bytes(int cl, int cout);
+int wsu_conv3x3_up_pack(const float* w3_oihw, const float* wt, const float* bt, const float* b3, void* w_low_packed, float* bias_out, float* wc_dense,
+                        int cl, int cup, int c2, int cout, void* stream);
+int wsu_conv3x3_up_q_fwd(const void* x_low, const void* x_skip, const void* w_skip_packed, const void* w_low_packed, const float* bias, void* y,
+                         int n, int h, int w, int cl, int c2, int cout, int relu, unsigned* range_flag, void* stream);
+
 /* ---- K1p + K0p fused: e11 -> e12 (-> pool) of the planar path in one launch for single-plane inputs (unet.py:141-144).  The loader waves of
  *      the persistent kernel compute e11's 64 channels from the image straight into the LDS stages (instead of fetching them); bitwise the
  *      result of wsu_conv3x3_first_pl_fwd followed by wsu_conv3x3_pl_fwd, and xe11 never reaches HBM.  img (N,1,H,W) fp32, w1 (64,1,3,3),

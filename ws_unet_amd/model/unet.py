@@ -111,6 +111,9 @@ class UNet(nn.Module):
         # planar path: e11 computed by the loader waves of e12's kernel (wsu_conv3x3_pl_fused_first_fwd).  Off by default: xe11 never
         # reaches HBM (-2.1 GB at batch 32) but the loaders' VALU work makes them the critical path -- e11 + e12 1.82 -> 1.60 ms, +0.8 % images/s
         self.fuse_first_planar = os.environ.get("WSU_FUSE_FIRST_PL", "0") != "0"
+        # default mode: every decoder block's transposed conv + concat + first conv is ONE launch (ops.conv3x3_up_q, csrc/conv3x3_qu.hip); 0 = the
+        # two-kernel path (convt2x2_pl -> conv3x3_q), kept as the A/B reference
+        self.fuse_up_planar = os.environ.get("WSU_FUSE_UP", "1") != "0"
         # arithmetic of the autograd path: exact fp32 MFMA for an 'f32' model; 'f16f8p' for a planar model -- the f16f8 arithmetic on planar
         # activations AND gradients (3 bytes per element, model/autograd.py; single-plane inputs, falls back to 'bf16x3' otherwise and when the
         # input gradient is asked for); else split-bf16 on fp32 tensors (~2^-16 relative per product -- finer than the TF32 convs PyTorch
@@ -178,6 +181,19 @@ class UNet(nn.Module):
             packed = ops.pack_convt2x2_dgrad(p, mode)
         else:
             packed = ops.pack_convt2x2(p, mode)
+        self._pack_cache[key] = (tag, packed)
+        return packed
+
+    def _packed_up(self, up: str, c1: str):
+        """(w_skip_packed, w_low_packed, bias) of the fused decoder-block entry (ops.pack_conv3x3_up), cached on all four parameters' versions."""
+        lu, l1 = getattr(self, up), getattr(self, c1)
+        ps = (lu.weight, lu.bias, l1.weight, l1.bias)
+        key = (up, c1, "up_q")
+        tag = tuple((p._version, p.data_ptr(), p.device) for p in ps)
+        hit = self._pack_cache.get(key)
+        if hit is not None and hit[0] == tag:
+            return hit[1]
+        packed = ops.pack_conv3x3_up(l1.weight, lu.weight, lu.bias, l1.bias)
         self._pack_cache[key] = (tag, packed)
         return packed
 
@@ -339,6 +355,10 @@ class UNet(nn.Module):
                 return ops.conv3x3_q(xa, xb, self._packed(name, W, CK), layer.bias.detach(), layer.out_channels, y_format=fmt, **kw)
             return ops.conv3x3_pl(xa, xb, self._packed(name, W, CK), layer.bias.detach(), layer.out_channels, x_residual=xres, **kw)
 
+        def fuse_up(depth):                                          # decoder block `depth` runs upconv + concat + first conv as one launch
+            l1 = getattr(self, dec_names(depth)[1])
+            return q4 and self.fuse_up_planar and l1.out_channels <= 512 and l1.out_channels % 64 == 0
+
         # e11 is folded into e12 (its 64 channels are computed by the loader waves of the persistent kernel) for single-plane inputs -- an
         # experiment switch of the e4m3 modes (the fused kernel multiplies e4m3 cross terms and writes the e4m3-residual format)
         fuse_first = self.fuse_first_planar and not q4 and e11.in_channels == 1 and e11.out_channels == 64 and self.nsteps >= 1
@@ -370,19 +390,23 @@ class UNet(nn.Module):
                 full, cur = conv(cur, None, b, lb, pool=True, range_flag=rf)
                 skips.append(full)
             else:
-                cur = conv(cur, None, b, lb, fmt=A, range_flag=rf)        # feeds the transposed conv
+                cur = conv(cur, None, b, lb, fmt=Q if fuse_up(self.nsteps) else A, range_flag=rf)        # feeds the transposed conv
         for depth in range(self.nsteps, 0, -1):
             up, c1, c2 = dec_names(depth)
             lu, l1, l2 = getattr(self, up), getattr(self, c1), getattr(self, c2)
-            tag(up)
-            xu = ops.convt2x2_pl(cur, self._packed(up, W, "convt"), lu.bias.detach(), lu.out_channels, range_flag=rf, y_format=Q if q4 else A)
-            tag(c1)
-            cur = conv(xu, skips[depth - 1], c1, l1, xres=not quick, range_flag=rf)
+            if fuse_up(depth):
+                tag(up + "+" + c1)
+                cur = ops.conv3x3_up_q(cur, skips[depth - 1], *self._packed_up(up, c1), l1.out_channels, range_flag=rf)
+            else:
+                tag(up)
+                xu = ops.convt2x2_pl(cur, self._packed(up, W, "convt"), lu.bias.detach(), lu.out_channels, range_flag=rf, y_format=Q if q4 else A)
+                tag(c1)
+                cur = conv(xu, skips[depth - 1], c1, l1, xres=not quick, range_flag=rf)
             if depth == 1:
                 tag(c2 + "+outconv")
                 return conv(cur, None, c2, l2, want_y=False, head_w=self.outconv.weight.detach(), head_b=self.outconv.bias.detach(), want_logit=want_logit)
             tag(c2)
-            cur = conv(cur, None, c2, l2, fmt=A, range_flag=rf)           # feeds the next transposed conv
+            cur = conv(cur, None, c2, l2, fmt=Q if fuse_up(depth - 1) else A, range_flag=rf)           # feeds the next transposed conv
         raise AssertionError("unreachable")
 
     def forward(self, x_in: torch.Tensor) -> torch.Tensor:

@@ -344,6 +344,61 @@ def conv3x3_q(x1: PlanarQ, x2: Optional[PlanarQ], w_packed_f4: torch.Tensor, bia
     return (y, yp) if pool else y
 
 
+def pack_conv3x3_up(w3: torch.Tensor, wt: torch.Tensor, bt: Optional[torch.Tensor], b3: Optional[torch.Tensor], want_dense: bool = False):
+    """Weights of the fused decoder-block entry conv3x3_up_q (wsu_conv3x3_up_pack, csrc/conv3x3_qu.hip).  w3: (Cout, Cup + C2, 3, 3) fp32, the
+    block's first conv (input channels [0, Cup) = the transposed conv's output, torch.cat([xu, skip]) order, unet.py:172,178,184); wt: (Cl, Cup, 2, 2)
+    fp32, the nn.ConvTranspose2d weights; bt / b3: their biases.  Returns (w_skip_packed, w_low_packed, bias[, wc_dense]): the skip half packed
+    like any conv3x3_q weight, the upsampled half as parity-class 2x2-tap weights combined in fp32 on the device, the combined bias, and on
+    request the combined weights (Cout, Cl, 2, 2, 2, 2) [py][px][dy][dx]."""
+    lib = _lib.load()
+    w3, wt = w3.detach().contiguous(), wt.detach().contiguous()
+    bt = None if bt is None else bt.detach().contiguous()
+    b3 = None if b3 is None else b3.detach().contiguous()
+    _dev_check(w3, wt, bt, b3)
+    assert w3.dtype == torch.float32 and w3.dim() == 4 and w3.shape[2:] == (3, 3) and wt.dtype == torch.float32 and wt.dim() == 4 and wt.shape[2:] == (2, 2)
+    cout, ctot = w3.shape[:2]
+    cl, cup = wt.shape[:2]
+    c2 = ctot - cup
+    nbytes = lib.wsu_conv3x3_up_packed_bytes(cl, cout)
+    if nbytes == 0 or c2 <= 0 or c2 % 16:
+        raise _lib.WsuError(f"fused upsample packing needs cl % 16 == 0, c2 % 16 == 0 (> 0) and cout % 64 == 0 (got cl={cl}, cup={cup}, c2={c2}, cout={cout})")
+    w_skip = pack_conv3x3_f4(w3[:, cup:].contiguous())
+    w_low = torch.empty(nbytes, dtype=torch.uint8, device=w3.device)
+    bias = torch.empty(cout, dtype=torch.float32, device=w3.device)
+    dense = torch.empty((cout, cl, 2, 2, 2, 2), dtype=torch.float32, device=w3.device) if want_dense else None
+    check(lib.wsu_conv3x3_up_pack(w3.data_ptr(), wt.data_ptr(), _ptr(bt), _ptr(b3), w_low.data_ptr(), bias.data_ptr(), _ptr(dense),
+                                  cl, cup, c2, cout, _stream()), "wsu_conv3x3_up_pack")
+    return (w_skip, w_low, bias, dense) if want_dense else (w_skip, w_low, bias)
+
+
+def conv3x3_up_q(x_low: PlanarQ, x_skip: PlanarQ, w_skip_packed: torch.Tensor, w_low_packed: torch.Tensor, bias: torch.Tensor, cout: int,
+                 relu: bool = True, range_flag: Optional[torch.Tensor] = None) -> PlanarQ:
+    """relu(conv3x3_reflect(cat[conv_transpose2x2_s2(x_low), x_skip])) of a decoder block (unet.py:171-173, 177-179, 183-185) in one launch, in the
+    arithmetic of the default inference mode (wsu_conv3x3_up_q_fwd, csrc/conv3x3_qu.hip): the upsampled half runs as a 2x2-tap conv on x_low with
+    weights combined per output-pixel parity class -- the upsampled tensor never exists.  x_low: PlanarQ at (h/2, w/2); x_skip: PlanarQ at (h, w);
+    weights from pack_conv3x3_up.  Returns y: PlanarQ."""
+    lib = _lib.load()
+    assert isinstance(x_low, PlanarQ) and isinstance(x_skip, PlanarQ), "conv3x3_up_q reads planar Q tensors (ops.PlanarQ)"
+    _dev_check(x_low.data, x_skip.data, w_skip_packed, w_low_packed, bias)
+    n, h, w, c2, cl = x_skip.n, x_skip.h, x_skip.w, x_skip.c, x_low.c
+    assert (x_low.n, 2 * x_low.h, 2 * x_low.w) == (n, h, w), "x_low must have half the skip tensor's height and width"
+    assert w_skip_packed.numel() == int(lib.wsu_conv3x3_packed_f4_bytes(c2, cout)), "w_skip_packed is not pack_conv3x3_f4 of (c2, cout)"
+    assert w_low_packed.numel() == int(lib.wsu_conv3x3_up_packed_bytes(cl, cout)), "w_low_packed is not pack_conv3x3_up of (cl, cout)"
+    assert bias is not None and bias.numel() == cout
+    y = PlanarQ.empty(n, cout, h, w, x_skip.device)
+    cup = cl // 2
+    act = n * h * w * (c2 + cout) + n * (h // 2) * (w // 2) * cl
+    # algorithmic work = the two reference ops it replaces: ConvTranspose2d (2 * 4 * cl * cup MACs per low pixel) + the 3x3 conv over cup + c2 channels
+    meta = {"flops": 2.0 * 9 * (cup + c2) * cout * n * h * w + 2.0 * 4 * cl * cup * n * (h // 2) * (w // 2),
+            "flops_executed": 2.0 * (9 * c2 + 4 * cl) * cout * n * h * w,
+            "bytes": float(act * 49 / 16 + (9 * c2 + 16 * cl) * cout * 28 / 9), "bytes_2B": float(act * 2 + (9 * (cup + c2) * cout + 4 * cl * cup) * 2),
+            "tiles": n * ((h + 15) // 16) * ((w + 31) // 32) * (cout // 64), "steps_per_tile": c2 // 16 + 2 * (cl // 16)}
+    check(_launch("conv3x3_up_q", meta, lambda: lib.wsu_conv3x3_up_q_fwd(
+        x_low.data_ptr(), x_skip.data_ptr(), w_skip_packed.data_ptr(), w_low_packed.data_ptr(), bias.data_ptr(), y.data_ptr(),
+        n, h, w, cl, c2, cout, int(relu), _ptr(range_flag), _stream())), "wsu_conv3x3_up_q_fwd")
+    return y
+
+
 def conv3x3_pl(x1: torch.Tensor, x2: Optional[torch.Tensor], w_packed: torch.Tensor, bias: Optional[torch.Tensor], cout: int,
                relu: bool = True, pool: bool = False, want_y: bool = True,
                head_w: Optional[torch.Tensor] = None, head_b: Optional[torch.Tensor] = None, want_logit: bool = False,
