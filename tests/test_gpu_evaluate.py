@@ -261,3 +261,64 @@ def test_per_image_api_one_readback(tmp_path, caplog):
         row = evaluate.predict_unet(str(tmp_path / "images" / "1.png"), model)
     assert model.mode == "bf16x3s" and any("448" in r.message for r in caplog.records)
     assert abs(float(row["beta_hat"]) - float(b0[0])) < 1e-4
+
+
+def _many_pngs(root, n, seed=77):
+    (root / "images").mkdir()
+    u8 = formula.synthetic_images(n, 512, 512, seed=seed)
+    for i in range(n):
+        Image.fromarray(u8[i]).save(root / "images" / f"{i:03d}.png", compress_level=1)
+    (root / "images" / "files.csv").write_text("name,height,width\n" + "".join(f"images/{i:03d}.png,512,512\n" for i in range(n)))
+    return u8
+
+
+def test_per_image_api_rows_ahead_ride_along(tmp_path, monkeypatch):
+    """The per-image API (the reference's call pattern, evaluate.py:48,142-149): rows announced ahead whose files are already decoded join the
+    launch of the row that is asked for (at most _MICRO_BATCH images), their statistics wait for their own calls.  Rows, order and numbers are
+    those of the one-image-per-launch loop, bit for bit; every image is computed exactly once."""
+    n = 40
+    _many_pngs(tmp_path, n)
+    model = gpu_model(2, "he", None, drop_rate=0.)
+    sizes = []
+    real = evaluate.predict_u8_batch
+    monkeypatch.setattr(evaluate, "predict_u8_batch", lambda x, m: (sizes.append(int(x.shape[0])), real(x, m))[1])
+    df = evaluate.predict_unet_cover(tmp_path, model=model, progress_on=False)
+    assert sum(sizes) == n and max(sizes) > 1 and max(sizes) <= evaluate._MICRO_BATCH, sizes
+    assert not evaluate._AHEAD["results"] and not evaluate._AHEAD["pending"] and not evaluate._AHEAD["inflight"]          # nothing left behind
+    sizes.clear()
+    monkeypatch.setattr(evaluate, "_MICRO_BATCH", 1)
+    df1 = evaluate.predict_unet_cover(tmp_path, model=model, progress_on=False)
+    assert sizes == [1] * n
+    assert df["name"].tolist() == df1["name"].tolist() == [f"images/{i:03d}.png" for i in range(n)]
+    np.testing.assert_array_equal(df["beta_hat"].to_numpy(), df1["beta_hat"].to_numpy())
+    np.testing.assert_array_equal(df["l1"].to_numpy(), df1["l1"].to_numpy())
+    assert df["beta_hat"].dtype == df1["beta_hat"].dtype
+
+
+def test_rows_computed_ahead_follow_the_file_and_the_model(tmp_path):
+    """A result computed ahead is used only for the same file contents, the same model and the same arithmetic; a pass that ends (or raises)
+    leaves none behind."""
+    u8 = _many_pngs(tmp_path, 6, seed=5)
+    files = [str(tmp_path / "images" / f"{i:03d}.png") for i in range(6)]
+    model = gpu_model(2, "he", None, drop_rate=0.)
+    plain = [evaluate.predict_unet(f, model) for f in files]                        # nothing announced: one image per launch
+    evaluate._lookahead_reset()
+    for f in files[1:]:
+        evaluate._lookahead(f)
+    for fut, _, _ in list(evaluate._AHEAD["pending"].values()):
+        fut.result()                                                                # all five decoded
+    r0 = evaluate.predict_unet(files[0], model)                                      # ... and computed with row 0
+    assert set(evaluate._AHEAD["results"]) == set(files[1:]) and not evaluate._AHEAD["inflight"] and r0["beta_hat"] == plain[0]["beta_hat"]
+    # file 1 is rewritten before its row comes: its ahead result is dropped, the row is computed from the new file
+    Image.fromarray(u8[5]).save(files[1], compress_level=1)
+    r1 = evaluate.predict_unet(files[1], model)
+    assert r1["beta_hat"] == plain[5]["beta_hat"] and r1["l1"] == plain[5]["l1"]
+    # another model object: not its result
+    other = gpu_model(2, "default", None, drop_rate=0.)
+    r2 = evaluate.predict_unet(files[2], other)
+    assert r2["beta_hat"] != plain[2]["beta_hat"]
+    # the same model: taken from the cache, same numbers as the plain loop
+    r3 = evaluate.predict_unet(files[3], model)
+    assert r3["beta_hat"] == plain[3]["beta_hat"] and r3["l1"] == plain[3]["l1"] and files[3] not in evaluate._AHEAD["results"]
+    evaluate._lookahead_reset()
+    assert not evaluate._AHEAD["results"]

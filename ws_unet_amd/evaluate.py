@@ -142,16 +142,39 @@ def predict_unet(
         # pinned buffer) instead of PIL -- the same plane `imread4_f32(fname)[..., 3]` holds (tests/test_host_logic.py), 2.5x less host
         # time per image; files it does not support fall back to PIL inside read_luma_batch
         from .imread import png_shape
-        planes = _take_ahead(str(fname))                     # decoded ahead by the iterator's lookahead (predict_unet_cover / _stego), if still valid
-        if planes is None:
-            planes = load_planes_u8([fname]) if png_shape(str(fname)) == (512, 512) else None
-        if planes is not None:
-            x_u8 = planes.to(_model_device(model), non_blocking=True)
-            mark_uploaded(planes)
-            beta, l1, tripped = predict_u8_one_readback(x_u8, model)          # statistics AND the range flag in one 12-byte copy
-            if tripped and range_fallback(model):                              # (rare: warn, switch the model to 'bf16x3s', recompute)
-                beta, l1, _ = predict_u8_one_readback(x_u8, model)
-            return {**kw, "beta_hat": np.float32(beta[0]), "l1": np.float32(l1[0])}
+        now = _file_stamp(str(fname))                        # ONE stat per call: what is taken from the caches below must be of this file as it is now
+        hit = _take_result(str(fname), model, now)           # computed in an earlier row's launch (the rows announced ahead ride along, below)
+        if hit is not None:
+            return {**kw, "beta_hat": hit[0], "l1": hit[1]}
+        # rows announced ahead whose files are already decoded join this row's launch (up to _MICRO_BATCH images), and ONE further launch of
+        # such rows is queued behind it before this call blocks on its own result: the reference's loop is one image per forward and one
+        # blocking read-back per image (evaluate.py:48); rows, order and numbers stay those of that loop -- an image's statistics do not depend
+        # on what else is in its batch -- but the GPU sees launches it can fill and works on the next one while Python hands out this one's rows
+        h = _inflight_of(str(fname), model, now)
+        if h is None:
+            planes = _take_ahead(str(fname), now)            # decoded ahead by the iterator's lookahead (predict_unet_cover / _stego), if still valid
+            if planes is None:
+                planes = load_planes_u8([fname]) if png_shape(str(fname)) == (512, 512) else None
+            if planes is not None:
+                h = _submit_rows([(str(fname), planes, now)] + _take_ready_ahead(_MICRO_BATCH - 1), model)
+        if h is not None:
+            if len(_AHEAD["inflight"]) < 2 and _ready_ahead() >= max(1, _MICRO_BATCH // 2):      # (a launch of one or two rows costs the host what a full one does)
+                more = _take_ready_ahead(_MICRO_BATCH)
+                if more:
+                    _submit_rows(more, model)
+            while True:                                      # collect in submission order up to this row's launch; the other rows' results wait for their calls
+                g = _AHEAD["inflight"].pop(0)
+                if g["model"] != id(model):                  # queued for another model (a caller alternating models outside a fabrika pass): not ours
+                    continue
+                beta, l1 = _collect_rows(g, model)
+                for k, path in enumerate(g["paths"]):
+                    if g is h and path == str(fname):
+                        mine = (np.float32(beta[k]), np.float32(l1[k]))
+                    else:
+                        _AHEAD["results"][path] = (np.float32(beta[k]), np.float32(l1[k]), g["stamps"][k], id(model), getattr(model, "mode", None))
+                if g is h:
+                    break
+            return {**kw, "beta_hat": mine[0], "l1": mine[1]}
     x = imread(fname)[..., 3:]
     if isinstance(model, torch.nn.Module) and hasattr(model, "forward_features") and x.shape[:2] == (512, 512):
         xi = np.ascontiguousarray(x[..., 0])
@@ -169,11 +192,14 @@ def predict_unet(
     return {**kw, "beta_hat": beta_hat, "l1": l1_hat}
 
 
-# ---- files ahead for the per-image API: while predict_unet works on row i (upload, forward, two scalars back: ~0.7 ms), helper threads decode
-# the files of rows i + 1 .. i + 3 into the pinned ring -- one decode (~2.2 ms) is longer than everything else of a row (reference: serial,
-# evaluate.py:142-149)
-_AHEAD_DEPTH = 3
-_AHEAD = {"pool": None, "pending": {}, "gen": 0}
+# ---- files ahead for the per-image API: while predict_unet works on row i (upload, forward, two scalars back: ~0.6 ms), helper threads decode
+# the files of rows i + 1 .. i + 16 into the pinned ring -- one decode (~1.5 ms) is longer than everything else of a row (reference: serial,
+# evaluate.py:142-149) -- and the rows already decoded when row i is asked for ride along in ITS launch (micro-batch), their results kept for
+# their own calls: the per-image loop's GPU work becomes a few batch-4..8 forwards instead of one batch-1 forward and one blocking read-back per image
+_MICRO_BATCH = 8                                             # at most this many images in one per-image-API launch: the row asked for + decoded rows ahead
+_AHEAD_DEPTH = 2 * _MICRO_BATCH                              # rows announced ahead (fabrika's python iterator, fn.lookahead_depth): the rows of the NEXT launch
+                                                             # are announced while the rows of this one return from the cache, and decode during this launch
+_AHEAD = {"pool": None, "pending": {}, "gen": 0, "results": {}, "inflight": []}
 
 
 def _file_stamp(path: str):
@@ -186,8 +212,17 @@ def _file_stamp(path: str):
 
 
 def _decode_ahead(path: str):
+    """-> (planes, hand-out number of the pinned buffer) or None"""
     from .imread import png_shape
-    return load_planes_u8([path]) if png_shape(path) == (512, 512) else None
+    if png_shape(path) != (512, 512):
+        return None
+    planes = load_planes_u8([path])
+    return None if planes is None else (planes, getattr(planes, "_wsu_issue", None))
+
+
+def _ring_valid(res):
+    """the pinned buffer of a finished ahead-decode still holds that decode (it has not been handed out again since)"""
+    return res is not None and getattr(res[0], "_wsu_issue", None) == res[1]
 
 
 def _lookahead(fname) -> None:
@@ -197,28 +232,126 @@ def _lookahead(fname) -> None:
     pend = _AHEAD["pending"]
     while len(pend) > _AHEAD_DEPTH:                          # rows that were announced and never asked for
         pend.pop(next(iter(pend)))[0].cancel()
-    # an entry = (future, ring generation at submission, file stamp): a decode lives in one slot of load_planes_u8's pinned ring, which is
-    # re-issued after _NBUF further decodes -- an entry older than that, or of a file rewritten since, is dropped instead of uploaded
+    # an entry = (future, announce number, file stamp): a decode lives in one buffer of load_planes_u8's pinned ring, which is handed out again
+    # after _NBUF1 further decodes -- a decode whose buffer was re-issued (_ring_valid), or of a file rewritten since, is dropped instead of uploaded
     pend[str(fname)] = (_AHEAD["pool"].submit(_decode_ahead, str(fname)), _AHEAD["gen"], _file_stamp(str(fname)))
     _AHEAD["gen"] += 1
 
 
 def _lookahead_reset() -> None:
-    """Forget every announced-but-unconsumed decode (start and end of a fabrika pass; a pass that raised midway leaves entries behind)."""
+    """Forget every announced-but-unconsumed decode and every computed-ahead result (start and end of a fabrika pass; a pass that raised midway
+    leaves entries behind)."""
     pend = _AHEAD["pending"]
     while pend:
         pend.pop(next(iter(pend)))[0].cancel()
+    _AHEAD["results"].clear()
+    del _AHEAD["inflight"][:]                                # (queued launches of an abandoned pass simply finish; nobody reads them)
 
 
-def _take_ahead(path: str):
+def _ready_ahead() -> int:
+    """how many announced rows, oldest first, have finished decoding"""
+    k = 0
+    for fut, _, _ in _AHEAD["pending"].values():
+        if not fut.done():
+            break
+        k += 1
+    return k
+
+
+def _take_ready_ahead(limit: int):
+    """Announced rows whose decode has FINISHED, oldest first, at most `limit`: [(path, planes, stamp)].  Stops at the first row still decoding
+    (nothing waits here); rows whose ring slot may have been re-issued, whose file changed, or that are not 512x512 are dropped -- their own call
+    decodes them again."""
+    out = []
+    pend = _AHEAD["pending"]
+    for path in list(pend):
+        if len(out) >= limit:
+            break
+        fut, gen, stamp = pend[path]
+        if not fut.done():
+            break
+        pend.pop(path)
+        if fut.cancelled():                                  # (a file rewritten since it was announced is caught when its row takes the result: the
+            continue                                         # result carries the announce-time stamp -- no stat per candidate here)
+        try:
+            res = fut.result()
+        except Exception:                                    # unreadable file: its own row raises the error, in order
+            continue
+        if _ring_valid(res):
+            out.append((path, res[0], stamp))
+    return out
+
+
+def _submit_rows(rows, model):
+    """rows [(path, pinned planes (1,H,W), stamp)] -> upload, forward, statistics and the copy of (beta_hat[n], l1[n], range flag) into a pinned
+    host buffer, all queued on the current stream, nothing waits.  The handle joins _AHEAD['inflight']."""
+    dev = _model_device(model)
+    n = len(rows)
+    if n == 1:
+        x_u8 = rows[0][1].to(dev, non_blocking=True)
+        mark_uploaded(rows[0][1])
+    else:
+        x_u8 = torch.empty((n,) + tuple(rows[0][1].shape[1:]), dtype=torch.uint8, device=dev)
+        for k, (_, pl, _) in enumerate(rows):
+            x_u8[k].copy_(pl[0], non_blocking=True)
+        mark_uploaded([r[1] for r in rows])                  # one event behind the n uploads
+    beta, l1 = predict_u8_batch(x_u8, model)
+    rf = getattr(model, "_range_flag", None)
+    planar = rf is not None and getattr(model, "mode", None) in ("f16f8p", "f16f8q", "f16f4p")
+    parts = [beta.reshape(-1), l1.reshape(-1)] + ([rf.reshape(-1).view(torch.float32)] if planar else [])
+    dev_v = torch.cat(parts)
+    host = torch.empty(dev_v.shape, dtype=torch.float32, pin_memory=dev_v.is_cuda)
+    host.copy_(dev_v, non_blocking=True)
+    ev = None
+    if dev_v.is_cuda:
+        ev = torch.cuda.Event()
+        ev.record()
+    h = {"paths": [r[0] for r in rows], "stamps": [r[2] for r in rows], "x": x_u8, "host": host, "ev": ev, "n": n, "planar": planar,
+         "model": id(model), "mode": getattr(model, "mode", None)}
+    _AHEAD["inflight"].append(h)
+    return h
+
+
+def _collect_rows(h, model):
+    """wait for ONE launch's results (its own event, not the stream): (beta_hat[n], l1[n]) as numpy.  A tripped range flag -- or a model that left
+    the arithmetic this launch was computed in since (an earlier launch tripped it) -- recomputes the launch's images in the present arithmetic."""
+    if h["ev"] is not None:
+        h["ev"].synchronize()
+    v = h["host"].numpy()
+    n = h["n"]
+    beta, l1 = v[:n].copy(), v[n:2 * n].copy()
+    tripped = bool(h["planar"] and v[2 * n:].view(np.int32)[0] != 0)
+    if (tripped and range_fallback(model)) or h["mode"] != getattr(model, "mode", None):
+        beta, l1, _ = predict_u8_one_readback(h["x"], model)
+    return beta, l1
+
+
+def _inflight_of(path: str, model, now):
+    """the queued launch that holds `path` (as the file is `now`) for this model, or None"""
+    for h in _AHEAD["inflight"]:
+        if h["model"] == id(model) and path in h["paths"] and h["stamps"][h["paths"].index(path)] == now:
+            return h
+    return None
+
+
+def _take_result(path: str, model, now):
+    """(beta_hat, l1) of `path` if an earlier launch of this pass already computed it with this model in its present arithmetic and the file is unchanged."""
+    ent = _AHEAD["results"].pop(path, None)
+    if ent is None or ent[3] != id(model) or ent[4] != getattr(model, "mode", None) or ent[2] != now:
+        return None
+    return ent[0], ent[1]
+
+
+def _take_ahead(path: str, now=None):
     ent = _AHEAD["pending"].pop(path, None)
     if ent is None:
         return None
     fut, gen, stamp = ent
-    if _AHEAD["gen"] - gen > _NBUF - 1 or stamp != _file_stamp(path):    # its ring slot may have been re-issued / the file changed: decode again
+    if stamp != (now if now is not None else _file_stamp(path)):                           # the file changed since it was announced: decode again
         fut.cancel()
         return None
-    return fut.result()
+    res = fut.result()
+    return res[0] if _ring_valid(res) else None              # (a buffer handed out again since holds another file: decode again)
 
 
 def _predict_unet_cover(*args, **kw):
@@ -281,7 +414,8 @@ def predict_u8_one_readback(x_u8: torch.Tensor, model: torch.nn.Module):
 
 
 _PINNED = {}
-_NBUF = 6
+_NBUF = 6                                                    # pinned buffers per chunk shape (decode of chunk k + 1 beside upload of chunk k ...)
+_NBUF1 = 2 * _AHEAD_DEPTH                                    # ... and per single-image shape: more than the rows decoded ahead + the rows of the launch in flight
 _PINNED_LOCK = __import__("threading").Lock()
 
 
@@ -388,11 +522,15 @@ def load_planes_u8(fnames, imread: typing.Callable = imread4_u8) -> typing.Optio
                 if len(_PINNED) > 8:
                     _PINNED.clear()
                 pin = torch.cuda.is_available()
-                _PINNED[key] = {"bufs": [torch.empty(key, dtype=torch.uint8, pin_memory=pin) for _ in range(_NBUF)], "next": 0,
-                                "uploaded": [None] * _NBUF}
+                nbuf = _NBUF1 if key[0] == 1 else _NBUF
+                _PINNED[key] = {"bufs": [torch.empty(key, dtype=torch.uint8, pin_memory=pin) for _ in range(nbuf)], "next": 0,
+                                "uploaded": [None] * nbuf}
             slot = _PINNED[key]
             i = slot["next"]                                 # a ring: chunk k+1 is decoded while chunk k is uploaded and chunk k-1 may still wait
-            slot["next"] = (i + 1) % _NBUF                   # in the stream (submit / collect pipelining); the per-image API decodes three rows ahead
+            slot["next"] = (i + 1) % len(slot["bufs"])       # in the stream (submit / collect pipelining); the per-image API decodes 16 rows ahead
+            slot["count"] = slot.get("count", 0) + 1
+            slot["bufs"][i]._wsu_issue = slot["count"]       # which hand-out of this buffer the caller holds (_decode_ahead / _ring_valid)
+            slot["bufs"][i]._wsu_ring = (slot, i)            # where mark_uploaded records the upload's event
         if slot["uploaded"][i] is not None:                  # the upload that last read this buffer (mark_uploaded)
             slot["uploaded"][i].synchronize()
             slot["uploaded"][i] = None
@@ -410,18 +548,19 @@ def load_planes_u8(fnames, imread: typing.Callable = imread4_u8) -> typing.Optio
     return torch.from_numpy(np.stack(imgs))
 
 
-def mark_uploaded(planes: torch.Tensor) -> None:
-    """Record, for a pinned buffer handed out by load_planes_u8, the point in the current stream after which it may be overwritten."""
-    if not planes.is_pinned():
+def mark_uploaded(planes, event=None) -> None:
+    """Record, for pinned buffer(s) handed out by load_planes_u8, the point in the current stream after which they may be overwritten
+    (one event for all of them; `event`: an already recorded one)."""
+    bufs = [planes] if isinstance(planes, torch.Tensor) else list(planes)
+    rings = [getattr(b, "_wsu_ring", None) for b in bufs]
+    if not any(r is not None for r in rings) or not torch.cuda.is_available():
         return
-    with _PINNED_LOCK:                                        # (helper threads insert into / clear _PINNED in load_planes_u8)
-        slots = list(_PINNED.values())
-    for slot in slots:
-        for i, b in enumerate(slot["bufs"]):
-            if b.data_ptr() == planes.data_ptr():
-                ev = torch.cuda.Event()
-                ev.record()
-                slot["uploaded"][i] = ev
+    if event is None:
+        event = torch.cuda.Event()
+        event.record()
+    for r in rings:
+        if r is not None:
+            r[0]["uploaded"][r[1]] = event
 
 
 def submit_unet_batch(fnames, *, model: torch.nn.Module, imread: typing.Callable = imread4_u8, prefetched=None):
