@@ -263,7 +263,7 @@ def compact_line(result: dict) -> dict:
         roof["per_layer"]["layers"] = [[row["layer"], row["ms"], row.get(key, row.get("frac"))] for row in pl["layers"]]
     for k in ("note", "traffic_unit"):
         roof.pop(k, None)
-    for sub in ("mfma_issue", "mfma_busy", "convt2x2", "fused_up", "all_conv"):
+    for sub in ("mfma_issue", "mfma_busy", "convt2x2", "fused_up", "all_conv", "whole_forward"):
         if isinstance(roof.get(sub), dict):
             roof[sub].pop("note", None)
     if isinstance(r.get("latency_b1"), dict):
@@ -569,6 +569,11 @@ def main():
             tot_f, tot_t = conv["flops"] + fu["flops"], conv["total_ms"] + fu["total_ms"]
             roofline["all_conv"] = {"achieved": tot_f / (tot_t * 1e-3) / 1e12, "frac": tot_f / (tot_t * 1e-3) / PEAK[args.mode], "ms_per_step": tot_t / args.steps,
                                     "note": "conv3x3_q_kernel + conv3x3_qu_kernel launches together"}
+        # the whole forward against the same peak: every launch's algorithmic FLOPs (3x3 convs, transposed convs, first layer, head) over the
+        # step's wall time -- the number a change of kernel boundaries (fusions) cannot move by re-labelling work
+        tot_flops = sum(v["flops"] for v in ks.values())
+        roofline["whole_forward"] = {"achieved": tot_flops / dt / 1e12, "frac": tot_flops / dt / PEAK[args.mode], "gflop_per_image": tot_flops / (args.batch * args.steps) / 1e9,
+                                     "note": "sum of all launches' algorithmic FLOPs / wall time of the timed steps"}
         roofline.update(pmc_traffic(args, conv["bytes"] / conv["launches"], ckey + "_kernel"))
         busy = sq_counters(args, ckey)
         if busy is not None and "mfma_issue" in roofline:

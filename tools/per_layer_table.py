@@ -23,8 +23,10 @@ for r in rows:
           f"{f(g(r, 'tflops'), '.1f')} | {f(g(r, 'hbm_GBps'), '.1f')} | {g(r, 'tiles') or '-'} | {g(r, 'steps_per_tile') or '-'} |")
 ro = d["roofline"]
 print(f"\nSum: {tot:.4f} ms measured; {roof3:.4f} ms at the roofs (3 B) -> {roof3 / tot:.4f}; {roof2:.4f} ms (2 B) -> {roof2 / tot:.4f}.  Headline of this run: "
-      f"{d['value']:.0f} images/s, {d['ms_per_step']:.2f} ms per step; 3x3 convs {ro['achieved']:.0f} TFLOP/s algorithmic = {ro['frac']:.3f} of 2.5 PFLOP/s; "
-      f"transposed convs {ro['convt2x2']['achieved']:.0f} GB/s = {ro['convt2x2']['frac']:.2f} of 8 TB/s.\n")
+      f"{d['value']:.0f} images/s, {d['ms_per_step']:.2f} ms per step; {ro.get('kernel', '3x3 convs')} {ro['achieved']:.0f} TFLOP/s algorithmic = {ro['frac']:.3f} of 2.5 PFLOP/s"
+      + (f"; fused decoder entries ({ro['fused_up']['kernel']}) {ro['fused_up']['achieved']:.0f} TFLOP/s = {ro['fused_up']['frac']:.3f}; both together {ro['all_conv']['frac']:.3f}" if "fused_up" in ro else "")
+      + (f"; whole forward {ro['whole_forward']['achieved']:.0f} TFLOP/s = {ro['whole_forward']['frac']:.3f}" if "whole_forward" in ro else "")
+      + (f"; transposed convs {ro['convt2x2']['achieved']:.0f} GB/s = {ro['convt2x2']['frac']:.2f} of 8 TB/s" if "convt2x2" in ro else "") + ".\n")
 lb = d.get("latency_b1")
 if lb:
     print(f"## Batch 1 (`latency_b1`): {lb['gpu_ms_per_image']:.3f} ms GPU time per image, {lb['wall_ms_per_image_synchronised']:.3f} ms synchronised call, "

@@ -17,7 +17,7 @@ import sys
 from collections import defaultdict
 from pathlib import Path
 
-KERNELS = ["conv3x3_q_kernel", "conv3x3_pl_kernel", "convt2x2_pl_kernel", "first_pl_kernel", "wgrad_ring_kernel", "wgrad_pl_kernel", "pool_bwd_pl", "convt2x2_bwd_pl", "head_bwd_pl"]
+KERNELS = ["conv3x3_qu_kernel", "conv3x3_q_kernel", "conv3x3_pl_kernel", "convt2x2_pl_kernel", "first_pl_kernel", "wgrad_ring_kernel", "wgrad_pl_kernel", "pool_bwd_pl", "convt2x2_bwd_pl", "head_bwd_pl"]
 
 
 def git_blob_sha1(path: Path) -> str:
@@ -85,7 +85,7 @@ def main():
         for k, c in load(d).items():
             res.setdefault(k, {}).setdefault(pass_name, summarise(c))
     repo = Path(__file__).resolve().parent.parent
-    meta = {"kernel_source_blobs": {f: git_blob_sha1(repo / "ws_unet_amd" / "csrc" / f) for f in ("conv3x3_q.hip", "conv3x3_pl.hip", "wgrad.hip")},
+    meta = {"kernel_source_blobs": {f: git_blob_sha1(repo / "ws_unet_amd" / "csrc" / f) for f in ("conv3x3_q.hip", "conv3x3_qu.hip", "conv3x3_pl.hip", "wgrad.hip")},
             "counters": "rocprofv3 --pmc passes of bench.py / tools/bench_train.py on the product libwsu.so (tools/profile_sq.sh)"}
     print("| kernel | pass | launches | avg ms | clock GHz | MFMA busy (cycles) | MFMA busy (time) | wait_any | wait_inst | active_inst |")
     print("|---|---|---|---|---|---|---|---|---|---|")
