@@ -179,6 +179,15 @@ int wsu_conv3x3_q_fwd(const void* x1, const void* x2, const void* w_packed_f4, c
                       const float* head_w, const float* head_b, float* head_out, float* head_logit, int head_cout,
                       int n, int h, int w, int c1, int c2, int cout, int relu, int y_format, unsigned* range_flag, void* stream);
 
+/* ---- K0p + K1q fused (round 4): e11 -> e12 -> pool of the DEFAULT mode in one launch for single-plane inputs (unet.py:141-144; kernel variant F1 of
+ *      csrc/conv3x3_q.hip).  The loader waves of the persistent kernel compute e11's 64 channels from the image straight into the LDS input slots -- fp32
+ *      fused multiply-adds in the tap order of wsu_conv3x3_first_pl_fwd, the same planar-Q encoding -- instead of fetching them: bitwise the result of
+ *      wsu_conv3x3_first_pl_fwd(y_format Q) followed by wsu_conv3x3_q_fwd, and xe11 never reaches HBM.  img (N,1,H,W) fp32; w1_taps (9, 64) fp32 = e11's
+ *      weights TAP-MAJOR (w1.reshape(64, 9).T -- a tap's 16 channels are one scalar 16-dword load of the loader waves), b1 (64); both 64-byte aligned;
+ *      w_packed_f4 / bias: the second conv (cin = 64; wsu_conv3x3_pack_f4); y, y_pool: planar Q tensors (both required).  h, w even; cout % 64 == 0. */
+int wsu_conv3x3_q_fused_first_fwd(const float* img, const float* w1_taps, const float* b1, const void* w_packed_f4, const float* bias, void* y, void* y_pool,
+                                  int n, int h, int w, int cout, int relu, unsigned* range_flag, void* stream);
+
 /* ---- K1u (round 4): a decoder block's transposed conv + concat + first 3x3 conv in ONE launch, default inference mode (csrc/conv3x3_qu.hip):
  *          y = relu(conv3x3_reflect(cat[conv_transpose2x2_s2(x_low), x_skip]))        (unet.py:171-173, 177-179, 183-185)
  *      There is no non-linearity between the two convs, so the upsampled half is a 2 x 2-tap conv on x_low with weights combined per PARITY CLASS of

@@ -277,3 +277,41 @@ def test_four_matrix_waves_give_the_same_bits():
         assert rr.returncode == 0, rr.stderr[-2000:]
         outs.append(torch.load(out, weights_only=True)); os.remove(out)
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("n,h,w,cout", [(2, 64, 96, 64), (1, 16, 32, 128), (3, 50, 70, 64), (1, 512, 512, 64)])
+def test_fused_first_q_is_bitwise_the_two_kernel_path(n, h, w, cout):
+    """e11 + e12 + pool in one launch (kernel variant F1: the loader waves compute e11's channels into the LDS input slots) against
+    conv3x3_first_pl(y_format Q) -> conv3x3_q(pool): the same fp32 FMA order, the same planar-Q encoding -- the same bytes; the range flag covers the
+    computed (never stored) xe11 values."""
+    from ws_unet_amd import ops
+    g = torch.Generator().manual_seed(31)
+    x = torch.rand((n, 1, h, w), generator=g).to(DEV)
+    w1, b1 = (torch.randn((64, 1, 3, 3), generator=g) * 0.5).to(DEV), (torch.randn(64, generator=g) * 0.1).to(DEV)
+    w2 = (torch.randn((cout, 64, 3, 3), generator=g) * (2.0 / (9 * 64)) ** 0.5).to(DEV)
+    b2 = (torch.randn(cout, generator=g) * 0.1).to(DEV)
+    wp = ops.pack_conv3x3_f4(w2)
+    xe11 = ops.conv3x3_first_pl(x, w1, b1, y_format=ops.PLANAR_Q)
+    y0, p0 = ops.conv3x3_q(xe11, None, wp, b2, cout, pool=True)
+    y1, p1 = ops.conv3x3_q_fused_first(x, w1, b1, wp, b2, cout)
+    assert _q_same(y1, y0) and _q_same(p1, p0)
+    for _ in range(5):
+        y2, p2 = ops.conv3x3_q_fused_first(x, w1, b1, wp, b2, cout)
+        assert _q_same(y2, y0) and _q_same(p2, p0)
+    rf = torch.zeros(1, dtype=torch.int32, device=DEV)
+    ops.conv3x3_q_fused_first(x, w1, b1, wp, b2, cout, range_flag=rf)
+    assert int(rf.item()) == 0
+    ops.conv3x3_q_fused_first(x, w1 * 4000.0, b1, wp, b2 * 0, cout, range_flag=rf)        # xe11 beyond +-448: only the loaders see it
+    assert int(rf.item()) == 1
+
+
+def test_whole_net_with_and_without_the_fused_first_layer():
+    from gpu_util import gpu_model, images01
+    _, x = images01(2, 96, 160, seed=3)
+    m = gpu_model(2, "he", "f16f4p")
+    assert m.fuse_first_q
+    with torch.no_grad():
+        y1 = m(x.to(DEV)).cpu()
+        m.fuse_first_q = False
+        y0 = m(x.to(DEV)).cpu()
+    assert torch.equal(y0, y1)

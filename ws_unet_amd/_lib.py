@@ -57,6 +57,7 @@ SIGNATURES = {
     "wsu_conv3x3_q_fwd": (c_int, [_P] * 10 + [c_int] * 9 + [_P, _P]),
     "wsu_conv3x3_packed_f4_bytes": (c_size_t, [c_int] * 2),
     "wsu_conv3x3_pack_f4": (c_int, [_P, _P, c_int, c_int, _P]),
+    "wsu_conv3x3_q_fused_first_fwd": (c_int, [_P] * 7 + [c_int] * 5 + [_P, _P]),
     "wsu_conv3x3_up_packed_bytes": (c_size_t, [c_int] * 2),
     "wsu_conv3x3_up_pack": (c_int, [_P] * 7 + [c_int] * 4 + [_P]),
     "wsu_conv3x3_up_q_fwd": (c_int, [_P] * 6 + [c_int] * 7 + [_P, _P]),

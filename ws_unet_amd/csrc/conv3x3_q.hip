@@ -67,6 +67,7 @@ struct QArgs {
     unsigned* range_flag;
     int msplit;                                           // 1: work items are half-blocks of 32 output channels (kernel variant MSPLIT); ncb = 2 * cout / 64
     int ablate;                                           // timing-only experiments (WSU_PL_ABLATE bits; results wrong when != 0): 1 = no DMA after step 0, 2 = no epilogue
+    const float* img; const float* w1; const float* b1;   // fused first layer (kernel variant F1): the 64 input channels are computed by the loader waves; w1 = tap-major [9][64]
 };
 
 struct Tile { int n, y0, x0, cb, mh; };
@@ -159,10 +160,121 @@ __device__ __forceinline__ void q_loader(const QArgs& a, char* smem, int lane, i
     }
 }
 
+// ================= loader waves of the kernel variant F1 (e11 + e12 in one launch, unet.py:141-144) ==========================================
+// The loaders COMPUTE the input slot of a step instead of fetching it: relu(b1 + w1 * 3x3 window of the image) for the step's 16 channels at the
+// tile's 612 halo pixels -- fp32 fused multiply-adds in the tap order of first_pl_kernel, the same wsu_q4_encode16, written where the DMA would
+// have put the three granule planes and the scale slot: the operands of the matrix waves are bitwise those of wsu_conv3x3_first_pl_fwd ->
+// wsu_conv3x3_q_fwd, and xe11 (1.4 GB written and read back at batch 32) never exists.  Lane = up to 3 of the tile's pixels, their 27 image
+// values stay in registers over the tile's 4 chunks; only the weight pieces still come by LDS-DMA.  ONE copy of the body with a run-time wave
+// index (four inlined copies beside the matrix waves' code cost the e4m3 kernel of round 2 ~160 spilled registers).
+__device__ __forceinline__ void q_loader_f1(const QArgs& a, char* smem, int lane, int lw, int G, int J, int lw8) {
+    if (J <= 0) return;
+    if (a.ablate & 16) __builtin_amdgcn_s_setprio(3);                 // experiment (WSU_Q_F1_PRIO=1): the computing loaders' instructions ahead of the matrix waves'
+    lds_char* smem3 = (lds_char*)smem;
+    constexpr int F1_PX = 3;                                          // segments lw8, lw8 + 4, lw8 + 8 (< 10)
+    float pimg[F1_PX][9];
+    float f1_max = 0.f;                                               // range flag of the computed (never stored) xe11 values
+    Tile ti = tile_of(a, lw); int ci = 0, kti = 0;                    // cursor of the computed inputs
+    int cbw = ti.cb, cw = 0, ktw = 0;                                 // cursor of the weight issue (block, chunk)
+    auto window = [&](const Tile& tt) __attribute__((always_inline)) {
+        const float* img = a.img + (size_t)tt.n * a.h * a.w;
+#pragma unroll
+        for (int k = 0; k < F1_PX; ++k) {
+            const int idx = min((lw8 + NLOAD * k) * 64 + lane, NPIX - 1);
+            const int r = idx / IW, cc = idx - r * IW;
+            const int yy = wsu_reflect(tt.y0 - 1 + r, a.h), xx = wsu_reflect(tt.x0 - 1 + cc, a.w);
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp)
+                pimg[k][tp] = img[(size_t)wsu_reflect(yy + tp / 3 - 1, a.h) * a.w + wsu_reflect(xx + tp % 3 - 1, a.w)];
+        }
+    };
+    // e11's weights and bias are wave-uniform: they come through scalar loads (constant address space: `s_load_dwordx16` per tap) straight into
+    // the packed multiply-adds' scalar operand -- no LDS table, no vector loads; two channels per instruction (v_pk_fma_f32 = two independent
+    // fused multiply-adds, bitwise the fmaf chain of first_pl_kernel).  Packed-f32 read-after-write hazard (Makefile): an accumulator pair is
+    // re-read 24 instructions later by its own next tap, and an `s_nop 0` separates the last update from the first read of the encoding.
+    typedef __attribute__((address_space(4))) const f32x2 cst_f32x2;
+    auto compute_in = [&](int s) __attribute__((always_inline)) {
+        char* slot = smem + (s % NIN) * IN_SLOT;
+        cst_f32x2* wt = (cst_f32x2*)(a.w1 + ci * 16);                   // tap-major table [9][64]: + tap * 32 pairs
+        cst_f32x2* bt = (cst_f32x2*)(a.b1 + ci * 16);
+        f32x2 acc[F1_PX][8];
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const f32x2 b = bt[g];
+#pragma unroll
+            for (int k = 0; k < F1_PX; ++k) acc[k][g] = b;
+        }
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp) {
+            f32x2 wv[8];
+#pragma unroll
+            for (int g = 0; g < 8; ++g) wv[g] = wt[tp * 32 + g];
+#pragma unroll
+            for (int k = 0; k < F1_PX; ++k) {
+                // (packed operands are 64-bit register pairs: the window value rides in one half of a pair and op_sel / op_sel_hi pick that half for both products)
+                const f32x2 pw = {pimg[k][tp & ~1], pimg[k][(tp | 1) < 9 ? (tp | 1) : tp]};
+#pragma unroll
+                for (int g = 0; g < 8; ++g) {
+                    if (tp & 1) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc[k][g]) : "v"(pw), "s"(wv[g]));
+                    else asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(acc[k][g]) : "v"(pw), "s"(wv[g]));
+                }
+            }
+        }
+        asm volatile("s_nop 0" ::: "memory");
+#pragma unroll
+        for (int k = 0; k < F1_PX; ++k) {
+            const int idx = (lw8 + NLOAD * k) * 64 + lane;
+            f32x4 v[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) v[g] = mk_f4(acc[k][2 * g][0], acc[k][2 * g][1], acc[k][2 * g + 1][0], acc[k][2 * g + 1][1]);
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[g][e] = fmaxf(v[g][e], 0.f); f1_max = fmaxf(f1_max, v[g][e]); }
+            u32x4 h0, h1, qg; uint32_t sb;
+            wsu_q4_encode16(v, h0, h1, qg, sb);
+            if (lw8 + NLOAD * k < IN_SEG && idx < NPIX) {               // (waves 2, 3 have two segments: their third is computed on a clamped pixel and dropped)
+                char* d = slot + idx * 16;
+                *reinterpret_cast<u32x4*>(d) = h0;
+                *reinterpret_cast<u32x4*>(d + PLANE) = h1;
+                *reinterpret_cast<u32x4*>(d + 2 * PLANE) = qg;
+                *reinterpret_cast<uint32_t*>(slot + 3 * PLANE + idx * 4) = sb;       // the pixel's dword slot: byte 0 = its scale byte
+            }
+        }
+        if (++ci == a.nch && s + 1 < J) { ci = 0; ++kti; ti = tile_of(a, lw + kti * G); window(ti); }
+    };
+    const int w0 = lw8 < 2 ? lw8 * 5 : 10 + (lw8 - 2) * 9, nwp = lw8 < 2 ? 5 : 9;      // the weight pieces of q_loader<LW>
+    auto issue_w = [&](int s) __attribute__((always_inline)) {
+        const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(a.wp), 0, 0x7FFFFFF0, 0x00020000);
+        const int w_base = (cbw * a.nch + cw) * W_SLOT;
+        lds_char* slot = smem3 + W_BASE + (s % NWS) * W_SLOT;
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+            if (k < nwp)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void*)(slot + (w0 + k) * 1024), 16, (unsigned)lane * 16u, w_base + (w0 + k) * 1024, 0, 0);
+        if (++cw == a.nch && s + 1 < J) { cw = 0; ++ktw; cbw = tile_of(a, lw + ktw * G).cb; }
+    };
+    window(ti);
+    issue_w(0);
+    compute_in(0);
+    if (J > 1) compute_in(1);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    for (int j = 0; ; ++j) {
+        __builtin_amdgcn_s_barrier();                                 // barrier j: step j is complete in LDS; every matrix wave has left step j - 1
+        asm volatile("" ::: "memory");
+        if (j + 1 >= J) break;
+        issue_w(j + 1);                                               // its slot held step j - 1
+        if (j + 2 < J) compute_in(j + 2);                             // its slot held step j - 1
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
+    if (a.range_flag && __builtin_amdgcn_ballot_w64(!(f1_max <= WSU_F8_RANGE)) != 0 && lane == 0) atomicOr(a.range_flag, 1u);
+}
+
 // RQ: rows of the 16-row tile per matrix wave (4: four matrix waves, one per SIMD; 2: eight).  HC = head planes compiled in: 0, 1 or 4 (1..4).
 // FQ: the stored outputs (y, y_pool) are planar Q tensors (else the e4m3-residual format of conv3x3_pl.hip: what the transposed convs read).
 // MSPLIT (small grids): a work item is HALF a tile's output channels (m-half = item & 1).
-template <int RQ, int HC, bool POOL, bool FQ, bool MSPLIT>
+// F1: the input channels (64 = e11's outputs) are computed from the image by the loader waves (q_loader_f1) instead of fetched.
+template <int RQ, int HC, bool POOL, bool FQ, bool MSPLIT, bool F1 = false>
 __global__ __launch_bounds__((16 / RQ + NLOAD) * 64) __attribute__((amdgpu_waves_per_eu(RQ == 4 ? 2 : 3, RQ == 4 ? 2 : 3)))
 void conv3x3_q_kernel(const QArgs a) {
     constexpr int NWAVE = 16 / RQ, NT = (NWAVE + NLOAD) * 64;
@@ -188,6 +300,7 @@ void conv3x3_q_kernel(const QArgs a) {
     // publishes them)
 
     if (wv >= NWAVE) {
+        if constexpr (F1) { q_loader_f1(a, smem, lane, lw, G, J, wv - NWAVE); return; }
         switch (wv - NWAVE) {
             case 0: q_loader<0>(a, smem, lane, lw, G, J); break;
             case 1: q_loader<1>(a, smem, lane, lw, G, J); break;
@@ -620,6 +733,7 @@ __global__ void pack_conv3x3_f4_kernel(const float* __restrict__ w, char* __rest
     template __global__ void conv3x3_q_kernel<RQ, 0, false, true, true>(const QArgs);
 WSU_Q_INST(4)
 WSU_Q_INST(2)
+template __global__ void conv3x3_q_kernel<2, 0, true, true, false, true>(const QArgs);
 
 template <int RQ>
 int q_launch_rq(QArgs a, int yq, hipStream_t s, int ncu, bool msplit_on) {
@@ -671,6 +785,48 @@ int wsu_conv3x3_pack_f4(const float* w_oihw, void* w_packed, int cin, int cout, 
     return wsu_check_launch("pack_conv3x3_f4_kernel");
 }
 
+// e11 + e12 (+ pool) of the default inference mode in ONE launch for single-plane inputs (unet.py:141-144; kernel variant F1 above): img (N,1,H,W)
+// fp32; w1_taps (9, 64) fp32 = e11's weights tap-major (w1.reshape(64, 9).T: the loaders fetch a tap's 16 channels with one scalar load), b1 (64);
+// w_packed_f4 / bias: the second conv (cin = 64, wsu_conv3x3_pack_f4); y and y_pool: planar Q tensors, cout
+// channels at (h, w) and (h/2, w/2).  Bitwise the result of wsu_conv3x3_first_pl_fwd(y_format Q) followed by wsu_conv3x3_q_fwd; xe11 never reaches
+// HBM.  h, w even; cout a multiple of 64.  range_flag as in wsu_conv3x3_q_fwd (it also covers the computed xe11 values).
+int wsu_conv3x3_q_fused_first_fwd(const float* img, const float* w1_taps, const float* b1, const void* w_packed_f4, const float* bias, void* y, void* y_pool,
+                                  int n, int h, int w, int cout, int relu, unsigned* range_flag, void* stream) {
+    const float* w1 = w1_taps;
+    WSU_REQUIRE(img && w1 && b1 && w_packed_f4 && y && y_pool, "conv3x3_q_fused_first: null pointer");
+    WSU_REQUIRE(((uintptr_t)w1 & 63) == 0 && ((uintptr_t)b1 & 63) == 0, "conv3x3_q_fused_first: w1_taps and b1 must be 64-byte aligned (scalar 16-dword loads)");
+    WSU_REQUIRE(n > 0 && h >= 2 && w >= 2 && h % 2 == 0 && w % 2 == 0, "conv3x3_q_fused_first: bad shape n=%d h=%d w=%d (even h, w: the pooled output)", n, h, w);
+    WSU_REQUIRE(cout > 0 && cout % WSU_COB == 0 && cout <= 1024, "conv3x3_q_fused_first: cout=%d must be a multiple of %d (<= 1024)", cout, WSU_COB);
+    WSU_REQUIRE((long long)h * w * 50 < 0xFFFFFFF0LL, "conv3x3_q_fused_first: h*w too large (a chunk must stay below 4 GiB)");
+    QArgs a;
+    a.x1 = nullptr; a.x2 = nullptr; a.wp = (const char*)w_packed_f4; a.bias = bias;
+    a.y = (char*)y; a.ypool = (char*)y_pool;
+    a.head_w = nullptr; a.head_b = nullptr; a.head_out = nullptr; a.head_logit = nullptr; a.head_cout = 0;
+    a.range_flag = range_flag;
+    a.n = n; a.h = h; a.w = w; a.c1 = 64; a.c2 = 0; a.cout = cout;
+    a.tiles_x = (w + TW - 1) / TW; a.tiles_y = (h + TH - 1) / TH; a.ncb = cout / WSU_COB;
+    static int prio = -1;
+    if (prio < 0) { const char* e = getenv("WSU_Q_F1_PRIO"); prio = (e && atoi(e)) ? 1 : 0; }
+    a.nch1 = 4; a.nch = 4; a.relu = relu; a.msplit = 0; a.ablate = prio ? 16 : 0;
+    a.img = img; a.w1 = w1; a.b1 = b1;
+    const long long nt = (long long)n * a.tiles_x * a.tiles_y * a.ncb;
+    WSU_REQUIRE(nt > 0 && nt < 0x3FFFFFFFLL, "conv3x3_q_fused_first: %lld tiles out of range", nt);
+    a.ntiles = (int)nt;
+    static int ncu = 0;
+    if (ncu == 0) {
+        int dev = 0; hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+            wsu_set_error("conv3x3_q_fused_first: cannot query the device"); return WSU_ERR_HIP;
+        }
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_q_kernel<2, 0, true, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
+        if (e != hipSuccess) { wsu_set_error("hipFuncSetAttribute(conv3x3_q<F1>): %s", hipGetErrorString(e)); return WSU_ERR_HIP; }
+        ncu = prop.multiProcessorCount;
+    }
+    hipLaunchKernelGGL((conv3x3_q_kernel<2, 0, true, true, false, true>), dim3(a.ntiles < ncu ? a.ntiles : ncu), dim3((8 + NLOAD) * 64), LDS_TOTAL,
+                       static_cast<hipStream_t>(stream), a);
+    return wsu_check_launch("conv3x3_q_kernel<F1>");
+}
+
 // Bytes of a planar Q tensor (n images, c channels -- a multiple of 16 -- at h x w): n * c/16 chunks of 48 h w + 512 ceil(h/16) ceil(w/32) bytes.
 size_t wsu_planar_q_bytes(int n, int c, int h, int w) {
     if (n <= 0 || c <= 0 || c % 16 || h <= 0 || w <= 0) return 0;
@@ -703,6 +859,7 @@ int wsu_conv3x3_q_fwd(const void* x1, const void* x2, const void* w_packed_f4, c
     a.n = n; a.h = h; a.w = w; a.c1 = c1; a.c2 = c2; a.cout = cout;
     a.tiles_x = (w + TW - 1) / TW; a.tiles_y = (h + TH - 1) / TH; a.ncb = cout / WSU_COB;
     a.nch1 = c1 / 16; a.nch = (c1 + c2) / 16; a.relu = relu;
+    a.img = nullptr; a.w1 = nullptr; a.b1 = nullptr;
     const long long nt = (long long)n * a.tiles_x * a.tiles_y * a.ncb;
     WSU_REQUIRE(nt > 0 && nt < 0x3FFFFFFFLL, "conv3x3_q: %lld tiles out of range", nt);
     a.ntiles = (int)nt;

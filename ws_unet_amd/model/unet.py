@@ -114,6 +114,9 @@ class UNet(nn.Module):
         # default mode: every decoder block's transposed conv + concat + first conv is ONE launch (ops.conv3x3_up_q, csrc/conv3x3_qu.hip); 0 = the
         # two-kernel path (convt2x2_pl -> conv3x3_q), kept as the A/B reference
         self.fuse_up_planar = os.environ.get("WSU_FUSE_UP", "1") != "0"
+        # default mode, single-plane inputs: e11 is folded into e12's launch (its 64 channels are computed by the loader waves, bitwise the two-kernel
+        # result; ops.conv3x3_q_fused_first); 0 = conv3x3_first_pl -> conv3x3_q
+        self.fuse_first_q = os.environ.get("WSU_FUSE_FIRST_Q", "1") != "0"
         # arithmetic of the autograd path: exact fp32 MFMA for an 'f32' model; 'f16f8p' for a planar model -- the f16f8 arithmetic on planar
         # activations AND gradients (3 bytes per element, model/autograd.py; single-plane inputs, falls back to 'bf16x3' otherwise and when the
         # input gradient is asked for); else split-bf16 on fp32 tensors (~2^-16 relative per product -- finer than the TF32 convs PyTorch
@@ -175,6 +178,8 @@ class UNet(nn.Module):
             packed = ops.pack_conv3x3(p, mode, dgrad=True)
         elif kind == "ring":
             packed = ops.pack_conv3x3_ring(p)
+        elif kind == "taps":                                         # e11's weights tap-major (9, 64): the scalar loads of ops.conv3x3_q_fused_first
+            packed = p.detach().reshape(p.shape[0], 9).t().contiguous()
         elif kind == "convt_dgrad_pl":
             packed = ops.pack_convt2x2_pl_dgrad(p)
         elif kind == "convt_dgrad":
@@ -362,13 +367,21 @@ class UNet(nn.Module):
         # e11 is folded into e12 (its 64 channels are computed by the loader waves of the persistent kernel) for single-plane inputs -- an
         # experiment switch of the e4m3 modes (the fused kernel multiplies e4m3 cross terms and writes the e4m3-residual format)
         fuse_first = self.fuse_first_planar and not q4 and e11.in_channels == 1 and e11.out_channels == 64 and self.nsteps >= 1
+        fuse_first_q = q4 and self.fuse_first_q and e11.in_channels == 1 and e11.out_channels == 64 and self.nsteps >= 1 and self.e12.in_channels == 64
         cur = None
-        if not fuse_first:
+        if not fuse_first and not fuse_first_q:
             tag("e11")
             cur = ops.conv3x3_first_pl(x, e11.weight, e11.bias.detach(), range_flag=rf, y_format=Q if q4 else A)
         skips: List = []
         for lvl in range(self.nsteps + 1):
             a, b = ENC[lvl]
+            if lvl == 0 and fuse_first_q:
+                lb = self.e12
+                tag("e11+e12")
+                full, cur = ops.conv3x3_q_fused_first(x, self._packed("e11", W, "taps"), None if e11.bias is None else e11.bias.detach(),
+                                                      self._packed("e12", W, CK), lb.bias.detach(), lb.out_channels, range_flag=rf)
+                skips.append(full)
+                continue
             if lvl == 0 and fuse_first:
                 lb = self.e12
                 tag("e11+e12")

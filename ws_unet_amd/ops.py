@@ -344,6 +344,32 @@ def conv3x3_q(x1: PlanarQ, x2: Optional[PlanarQ], w_packed_f4: torch.Tensor, bia
     return (y, yp) if pool else y
 
 
+def conv3x3_q_fused_first(x_nchw: torch.Tensor, w1: torch.Tensor, b1: Optional[torch.Tensor], w_packed_f4: torch.Tensor,
+                          bias: Optional[torch.Tensor], cout: int, relu: bool = True, range_flag: Optional[torch.Tensor] = None):
+    """e11 + e12 + pool of the default mode in one launch (wsu_conv3x3_q_fused_first_fwd): x_nchw (N,1,H,W) fp32 -> (y, y_pool) PlanarQ.  Bitwise
+    conv3x3_first_pl(y_format=PLANAR_Q) followed by conv3x3_q(pool=True); xe11 never reaches HBM."""
+    lib = _lib.load()
+    w1 = w1.detach()
+    _dev_check(x_nchw, w1, b1, w_packed_f4, bias)
+    n, cin, h, w = x_nchw.shape
+    assert cin == 1 and x_nchw.dtype == torch.float32 and x_nchw.is_contiguous()
+    # w1: (64,1,3,3) OIHW, or already the tap-major table (9, 64) the kernel's scalar loads read (UNet caches it per weight version)
+    assert tuple(w1.shape) in ((64, 1, 3, 3), (9, 64)) and w1.dtype == torch.float32
+    w1t = w1.contiguous() if tuple(w1.shape) == (9, 64) else w1.reshape(64, 9).t().contiguous()
+    b1 = torch.zeros(64, dtype=torch.float32, device=x_nchw.device) if b1 is None else b1.detach().contiguous()
+    assert w_packed_f4.numel() == int(lib.wsu_conv3x3_packed_f4_bytes(64, cout)), "conv3x3_q_fused_first needs weights from pack_conv3x3_f4 of (64, cout)"
+    y = PlanarQ.empty(n, cout, h, w, x_nchw.device)
+    yp = PlanarQ.empty(n, cout, h // 2, w // 2, x_nchw.device)
+    act = n * h * w * cout + n * (h // 2) * (w // 2) * cout
+    meta = {"flops": 2.0 * 9 * 64 * cout * n * h * w + 2.0 * 9 * 64 * n * h * w,
+            "bytes": float(n * h * w * 4 + act * 49 / 16 + 9 * 64 * cout * 28 / 9), "bytes_2B": float(n * h * w * 4 + act * 2 + 9 * 64 * cout * 2),
+            "tiles": n * ((h + 15) // 16) * ((w + 31) // 32) * (cout // 64), "steps_per_tile": 4}
+    check(_launch("conv3x3_q", meta, lambda: lib.wsu_conv3x3_q_fused_first_fwd(
+        x_nchw.data_ptr(), w1t.data_ptr(), b1.data_ptr(), w_packed_f4.data_ptr(), _ptr(bias), y.data_ptr(), yp.data_ptr(),
+        n, h, w, cout, int(relu), _ptr(range_flag), _stream())), "wsu_conv3x3_q_fused_first_fwd")
+    return y, yp
+
+
 def pack_conv3x3_up(w3: torch.Tensor, wt: torch.Tensor, bt: Optional[torch.Tensor], b3: Optional[torch.Tensor], want_dense: bool = False):
     """Weights of the fused decoder-block entry conv3x3_up_q (wsu_conv3x3_up_pack, csrc/conv3x3_qu.hip).  w3: (Cout, Cup + C2, 3, 3) fp32, the
     block's first conv (input channels [0, Cup) = the transposed conv's output, torch.cat([xu, skip]) order, unet.py:172,178,184); wt: (Cl, Cup, 2, 2)
