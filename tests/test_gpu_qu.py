@@ -173,3 +173,18 @@ def test_whole_net_fused_decoder_entries_against_the_two_kernel_path_and_the_ora
     e_f, e_t = float((y_f - ref).abs().mean()), float((y_t - ref).abs().mean())
     assert e_f < 1e-4 and e_f <= 1.15 * e_t, (e_f, e_t)
     assert float((y_f - y_t).abs().max()) < 6e-4
+
+
+@pytest.mark.parametrize("n,h,w", [(1, 1024, 1024), (2, 384, 640)])
+def test_default_mode_at_the_pair_training_resolution_and_non_square(n, h, w):
+    """BASELINE.json configs[4] runs 1024x1024 images: the default inference path (fused first layer, fused decoder entries: many tiles per
+    workgroup, the ring wrapping across hundreds of tiles) against the fp32 CPU oracle at that size, and at a non-square size."""
+    from gpu_util import gpu_model, images01, oracle_forward
+    _, x = images01(n, h, w, seed=13)
+    ref = oracle_forward(x, 2, "he")
+    m = gpu_model(2, "he", None)
+    with torch.no_grad():
+        y = m(x.to(DEV)).cpu()
+        y2 = m(x.to(DEV)).cpu()
+    assert torch.equal(y, y2)
+    assert float((y - ref).abs().mean()) <= 5e-5 and float((y - ref).abs().max()) <= 9e-4, (float((y - ref).abs().mean()), float((y - ref).abs().max()))

@@ -114,9 +114,10 @@ class UNet(nn.Module):
         # default mode: every decoder block's transposed conv + concat + first conv is ONE launch (ops.conv3x3_up_q, csrc/conv3x3_qu.hip); 0 = the
         # two-kernel path (convt2x2_pl -> conv3x3_q), kept as the A/B reference
         self.fuse_up_planar = os.environ.get("WSU_FUSE_UP", "1") != "0"
-        # default mode, single-plane inputs: e11 is folded into e12's launch (its 64 channels are computed by the loader waves, bitwise the two-kernel
-        # result; ops.conv3x3_q_fused_first); 0 = conv3x3_first_pl -> conv3x3_q
-        self.fuse_first_q = os.environ.get("WSU_FUSE_FIRST_Q", "1") != "0"
+        # default mode, single-plane inputs, optional (WSU_FUSE_FIRST_Q=1): e11 folded into e12's launch (its 64 channels are computed by the loader
+        # waves, bitwise the two-kernel result; ops.conv3x3_q_fused_first).  Measured a tie in time (profiles/r04/ab_fused_first_q.md); it frees
+        # xe11's memory (1.4 GB at batch 32 @ 512x512, 5.5 GB at 1024x1024) -- a switch for memory-bound callers, off by default
+        self.fuse_first_q = os.environ.get("WSU_FUSE_FIRST_Q", "0") != "0"
         # arithmetic of the autograd path: exact fp32 MFMA for an 'f32' model; 'f16f8p' for a planar model -- the f16f8 arithmetic on planar
         # activations AND gradients (3 bytes per element, model/autograd.py; single-plane inputs, falls back to 'bf16x3' otherwise and when the
         # input gradient is asked for); else split-bf16 on fp32 tensors (~2^-16 relative per product -- finer than the TF32 convs PyTorch
