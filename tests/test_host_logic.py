@@ -506,3 +506,70 @@ def test_train_products_setting(monkeypatch):
     monkeypatch.setenv("WSU_TRAIN_PRODUCTS", "fp4")
     with pytest.raises(ValueError, match="products"):
         get_model("unet_0", in_channels=1, out_channels=1, channel=[0], drop_rate=None, mode="f16f8p")
+
+
+def test_per_image_api_rows_ride_along_host_logic(tmp_path, monkeypatch):
+    """The host side of the per-image evaluate API without a GPU (the device legs replaced by a stub that returns each plane's own mean / max):
+    rows decoded ahead join the launch of the row asked for, one launch is queued ahead, every row gets ITS image's numbers in the reference's
+    order, every image is computed once, a file rewritten after it was announced is recomputed, nothing is left behind -- also when the
+    predictor raises in the middle of a pass."""
+    from PIL import Image
+    from ws_unet_amd import evaluate
+    n = 30
+    rng = np.random.default_rng(3)
+    u8 = rng.integers(0, 256, size=(n, 512, 512), dtype=np.uint8)
+    (tmp_path / "images").mkdir()
+    for i in range(n):
+        Image.fromarray(u8[i]).save(tmp_path / "images" / f"{i:02d}.png", compress_level=1)
+    (tmp_path / "images" / "files.csv").write_text("name,height,width\n" + "".join(f"images/{i:02d}.png,512,512\n" for i in range(n)))
+
+    class Stub(torch.nn.Module):
+        mode = "f32"
+        def forward_features(self, x):
+            return x
+    model = Stub()
+    sizes = []
+
+    def fake_batch(x_u8, m):
+        sizes.append(int(x_u8.shape[0]))
+        f = x_u8.float()
+        return f.mean(dim=(1, 2)), f.amax(dim=(1, 2))
+    monkeypatch.setattr(evaluate, "predict_u8_batch", fake_batch)
+    monkeypatch.setattr(evaluate, "_model_device", lambda m: torch.device("cpu"))
+    df = evaluate.predict_unet_cover(tmp_path, model=model, progress_on=False)
+    assert df["name"].tolist() == [f"images/{i:02d}.png" for i in range(n)]
+    np.testing.assert_allclose(df["beta_hat"].to_numpy(float), u8.reshape(n, -1).mean(axis=1), rtol=1e-6)
+    np.testing.assert_array_equal(df["l1"].to_numpy(float), u8.reshape(n, -1).max(axis=1).astype(float))
+    assert sum(sizes) == n and max(sizes) <= evaluate._MICRO_BATCH
+    assert not evaluate._AHEAD["results"] and not evaluate._AHEAD["pending"] and not evaluate._AHEAD["inflight"]
+    # a file rewritten between its announcement and its row
+    files = [str(tmp_path / "images" / f"{i:02d}.png") for i in range(4)]
+    evaluate._lookahead_reset()
+    for f in files[1:]:
+        evaluate._lookahead(f)
+    for fut, _, _ in list(evaluate._AHEAD["pending"].values()):
+        fut.result()
+    r0 = evaluate.predict_unet(files[0], model)
+    assert float(r0["beta_hat"]) == pytest.approx(u8[0].mean(), rel=1e-6) and set(evaluate._AHEAD["results"]) == set(files[1:])
+    Image.fromarray(u8[9]).save(files[1], compress_level=1)
+    r1 = evaluate.predict_unet(files[1], model)
+    assert float(r1["beta_hat"]) == pytest.approx(u8[9].mean(), rel=1e-6)
+    r2 = evaluate.predict_unet(files[2], model)                      # ... the others come from the cache
+    k = len(sizes)
+    assert float(r2["beta_hat"]) == pytest.approx(u8[2].mean(), rel=1e-6) and len(sizes) == k
+    evaluate._lookahead_reset()
+    # a predictor that raises mid-pass: the next pass starts clean
+    calls = {"n": 0}
+
+    def boom(x_u8, m):
+        calls["n"] += 1
+        if calls["n"] == 3:
+            raise RuntimeError("device lost")
+        return fake_batch(x_u8, m)
+    monkeypatch.setattr(evaluate, "predict_u8_batch", boom)
+    with pytest.raises(RuntimeError, match="device lost"):
+        evaluate.predict_unet_cover(tmp_path, model=model, progress_on=False)
+    assert not evaluate._AHEAD["results"] and not evaluate._AHEAD["pending"] and not evaluate._AHEAD["inflight"]
+    monkeypatch.setattr(evaluate, "predict_u8_batch", fake_batch)
+    df2 = evaluate.predict_unet_cover(tmp_path, model=model, progress_on=False, take_num_images=5)
+    np.testing.assert_allclose(df2["beta_hat"].to_numpy(float)[2:], u8.reshape(n, -1).mean(axis=1)[2:5], rtol=1e-6)
