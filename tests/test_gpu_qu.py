@@ -77,7 +77,8 @@ def _case(n, hl, wl, cl, cup, c2, cout, seed=11):
     (2, 16, 32, 128, 64, 64, 64),             # d41's channels: 4 skip steps + 16 low half-steps per tile
     (1, 24, 40, 64, 32, 32, 128),             # two output blocks, tiles past the image in both directions (48 x 80)
     (3, 5, 7, 16, 16, 48, 64),                # 10 x 14 pixels: a single ragged tile, more skip than low chunks
-    (1, 64, 64, 32, 16, 32, 64),              # 32 tiles: with few CUs a workgroup walks several tiles, the ring wraps across tiles
+    (1, 64, 64, 32, 16, 32, 64),              # 32 tiles
+    (8, 64, 128, 32, 16, 16, 128),            # 1024 work items on 256 CUs: every workgroup walks four tiles, the ring and the loaders' cursor cross tile borders
 ])
 def test_conv3x3_up_q_matches_the_composition_and_its_emulation(n, hl, wl, cl, cup, c2, cout):
     from ws_unet_amd import ops

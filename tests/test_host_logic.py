@@ -573,3 +573,14 @@ def test_per_image_api_rows_ride_along_host_logic(tmp_path, monkeypatch):
     monkeypatch.setattr(evaluate, "predict_u8_batch", fake_batch)
     df2 = evaluate.predict_unet_cover(tmp_path, model=model, progress_on=False, take_num_images=5)
     np.testing.assert_allclose(df2["beta_hat"].to_numpy(float)[2:], u8.reshape(n, -1).mean(axis=1)[2:5], rtol=1e-6)
+
+
+def test_forward_organisation_switches_are_read_at_construction(monkeypatch):
+    """WSU_FUSE_UP (default on: the decoder blocks' fused entries), WSU_FUSE_FIRST_Q (default off): attributes of the model, so that a caller can A/B them."""
+    from ws_unet_amd.model import get_model
+    m = get_model("unet_2", in_channels=1, out_channels=1, channel=[0], drop_rate=0.)
+    assert m.fuse_up_planar is True and m.fuse_first_q is False and m.mode == "f16f4p"
+    monkeypatch.setenv("WSU_FUSE_UP", "0")
+    monkeypatch.setenv("WSU_FUSE_FIRST_Q", "1")
+    m = get_model("unet_2", in_channels=1, out_channels=1, channel=[0], drop_rate=0.)
+    assert m.fuse_up_planar is False and m.fuse_first_q is True
