@@ -305,7 +305,7 @@ def test_rows_computed_ahead_follow_the_file_and_the_model(tmp_path):
     evaluate._lookahead_reset()
     for f in files[1:]:
         evaluate._lookahead(f)
-    for fut, _, _ in list(evaluate._AHEAD["pending"].values()):
+    for fut, _ in list(evaluate._AHEAD["pending"].values()):
         fut.result()                                                                # all five decoded
     r0 = evaluate.predict_unet(files[0], model)                                      # ... and computed with row 0
     assert set(evaluate._AHEAD["results"]) == set(files[1:]) and not evaluate._AHEAD["inflight"] and r0["beta_hat"] == plain[0]["beta_hat"]

@@ -45,7 +45,7 @@ def _q_conv_terms(xp, w):
 
 def _up_q_ref(xl, xs, w3, wc, bias, cup):
     """the kernel's arithmetic on the CPU: ordinary 3x3 terms on the skip half + per parity class a 2x2-tap conv on the clamp-padded low tensor"""
-    n, _, hl, wl = xl.shape
+    _, _, hl, wl = xl.shape
     y = _q_conv_terms(F.pad(xs, (1, 1, 1, 1), mode="reflect"), w3[:, cup:])
     xlp = F.pad(xl, (1, 1, 1, 1), mode="replicate")
     for py in range(2):

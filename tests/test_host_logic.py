@@ -547,7 +547,7 @@ def test_per_image_api_rows_ride_along_host_logic(tmp_path, monkeypatch):
     evaluate._lookahead_reset()
     for f in files[1:]:
         evaluate._lookahead(f)
-    for fut, _, _ in list(evaluate._AHEAD["pending"].values()):
+    for fut, _ in list(evaluate._AHEAD["pending"].values()):
         fut.result()
     r0 = evaluate.predict_unet(files[0], model)
     assert float(r0["beta_hat"]) == pytest.approx(u8[0].mean(), rel=1e-6) and set(evaluate._AHEAD["results"]) == set(files[1:])

@@ -199,7 +199,7 @@ def predict_unet(
 _MICRO_BATCH = 8                                             # at most this many images in one per-image-API launch: the row asked for + decoded rows ahead
 _AHEAD_DEPTH = 2 * _MICRO_BATCH                              # rows announced ahead (fabrika's python iterator, fn.lookahead_depth): the rows of the NEXT launch
                                                              # are announced while the rows of this one return from the cache, and decode during this launch
-_AHEAD = {"pool": None, "pending": {}, "gen": 0, "results": {}, "inflight": []}
+_AHEAD = {"pool": None, "pending": {}, "results": {}, "inflight": []}
 
 
 def _file_stamp(path: str):
@@ -232,10 +232,9 @@ def _lookahead(fname) -> None:
     pend = _AHEAD["pending"]
     while len(pend) > _AHEAD_DEPTH:                          # rows that were announced and never asked for
         pend.pop(next(iter(pend)))[0].cancel()
-    # an entry = (future, announce number, file stamp): a decode lives in one buffer of load_planes_u8's pinned ring, which is handed out again
-    # after _NBUF1 further decodes -- a decode whose buffer was re-issued (_ring_valid), or of a file rewritten since, is dropped instead of uploaded
-    pend[str(fname)] = (_AHEAD["pool"].submit(_decode_ahead, str(fname)), _AHEAD["gen"], _file_stamp(str(fname)))
-    _AHEAD["gen"] += 1
+    # an entry = (future, file stamp): a decode lives in one buffer of load_planes_u8's pinned ring, which is handed out again after _NBUF1
+    # further decodes -- a decode whose buffer was re-issued (_ring_valid), or of a file rewritten since, is dropped instead of uploaded
+    pend[str(fname)] = (_AHEAD["pool"].submit(_decode_ahead, str(fname)), _file_stamp(str(fname)))
 
 
 def _lookahead_reset() -> None:
@@ -251,7 +250,7 @@ def _lookahead_reset() -> None:
 def _ready_ahead() -> int:
     """how many announced rows, oldest first, have finished decoding"""
     k = 0
-    for fut, _, _ in _AHEAD["pending"].values():
+    for fut, _ in _AHEAD["pending"].values():
         if not fut.done():
             break
         k += 1
@@ -267,7 +266,7 @@ def _take_ready_ahead(limit: int):
     for path in list(pend):
         if len(out) >= limit:
             break
-        fut, gen, stamp = pend[path]
+        fut, stamp = pend[path]
         if not fut.done():
             break
         pend.pop(path)
@@ -346,7 +345,7 @@ def _take_ahead(path: str, now=None):
     ent = _AHEAD["pending"].pop(path, None)
     if ent is None:
         return None
-    fut, gen, stamp = ent
+    fut, stamp = ent
     if stamp != (now if now is not None else _file_stamp(path)):                           # the file changed since it was announced: decode again
         fut.cancel()
         return None
