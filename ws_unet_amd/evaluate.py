@@ -193,10 +193,10 @@ def predict_unet(
 
 
 # ---- files ahead for the per-image API: while predict_unet works on row i (upload, forward, two scalars back: ~0.6 ms), helper threads decode
-# the files of rows i + 1 .. i + 16 into the pinned ring -- one decode (~1.5 ms) is longer than everything else of a row (reference: serial,
+# the files of rows i + 1 .. i + 32 into the pinned ring -- one decode (~1.5 ms) is longer than everything else of a row (reference: serial,
 # evaluate.py:142-149) -- and the rows already decoded when row i is asked for ride along in ITS launch (micro-batch), their results kept for
-# their own calls: the per-image loop's GPU work becomes a few batch-4..8 forwards instead of one batch-1 forward and one blocking read-back per image
-_MICRO_BATCH = 8                                             # at most this many images in one per-image-API launch: the row asked for + decoded rows ahead
+# their own calls: the per-image loop's GPU work becomes a few batch-8..16 forwards instead of one batch-1 forward and one blocking read-back per image
+_MICRO_BATCH = max(1, int(__import__("os").environ.get("WSU_PER_IMAGE_BATCH", "16")))     # at most this many images in one per-image-API launch: the row asked for + decoded rows ahead
 _AHEAD_DEPTH = 2 * _MICRO_BATCH                              # rows announced ahead (fabrika's python iterator, fn.lookahead_depth): the rows of the NEXT launch
                                                              # are announced while the rows of this one return from the cache, and decode during this launch
 _AHEAD = {"pool": None, "pending": {}, "results": {}, "inflight": []}
@@ -526,7 +526,7 @@ def load_planes_u8(fnames, imread: typing.Callable = imread4_u8) -> typing.Optio
                                 "uploaded": [None] * nbuf}
             slot = _PINNED[key]
             i = slot["next"]                                 # a ring: chunk k+1 is decoded while chunk k is uploaded and chunk k-1 may still wait
-            slot["next"] = (i + 1) % len(slot["bufs"])       # in the stream (submit / collect pipelining); the per-image API decodes 16 rows ahead
+            slot["next"] = (i + 1) % len(slot["bufs"])       # in the stream (submit / collect pipelining); the per-image API decodes 32 rows ahead
             slot["count"] = slot.get("count", 0) + 1
             slot["bufs"][i]._wsu_issue = slot["count"]       # which hand-out of this buffer the caller holds (_decode_ahead / _ring_valid)
             slot["bufs"][i]._wsu_ring = (slot, i)            # where mark_uploaded records the upload's event
