@@ -563,7 +563,7 @@ def test_per_image_api_rows_ride_along_host_logic(tmp_path, monkeypatch):
 
     def boom(x_u8, m):
         calls["n"] += 1
-        if calls["n"] == 3:
+        if calls["n"] == 2:
             raise RuntimeError("device lost")
         return fake_batch(x_u8, m)
     monkeypatch.setattr(evaluate, "predict_u8_batch", boom)
