@@ -70,4 +70,4 @@ print(json.dumps({"metric": "evaluate loop images/s (PNG on disk -> beta_hat, l1
                   "decode_threads_needed_per_rank_at_gpu_rate": budget["threads_needed_per_rank"], "usable_cores": budget["usable_cores"],
                   "decode_threads_used": budget["decode_threads_used"],
                   "batched_from_u8_shards_images_per_s": a.images / t_s, "u8_shards_table_identical": same,
-                  "note": "batched path: PNG decode by libwsu_io on C++ threads, one chunk ahead of the GPU (fabrika iterator='batched' prefetch); the per-image API decodes the files of the next 32 rows on helper threads (libwsu_io); rows already decoded ride along in the launch of the row asked for (<= 16 images), one launch is queued ahead, statistics + range flag of a launch come back in one copy"}))
+                  "note": "batched path: PNG decode by libwsu_io on C++ threads, one chunk ahead of the GPU (fabrika iterator='batched' prefetch); the per-image API decodes the files of the next 48 rows on helper threads (libwsu_io); rows already decoded ride along in the launch of the row asked for (<= 16 images), two launches are queued ahead, statistics + range flag of a launch come back in one copy"}))

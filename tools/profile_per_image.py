@@ -22,3 +22,4 @@ t0 = time.perf_counter(); evaluate.predict_unet_cover(root, model=m, progress_on
 print(f"per-image API: {a.images / dt:.0f} images/s ({dt / a.images * 1e3:.3f} ms per row)")
 pr = cProfile.Profile(); pr.enable(); evaluate.predict_unet_cover(root, model=m, progress_on=False); pr.disable()
 pstats.Stats(pr).sort_stats("tottime").print_stats(22)
+pstats.Stats(pr).sort_stats("cumulative").print_stats(30)

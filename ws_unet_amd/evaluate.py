@@ -146,8 +146,8 @@ def predict_unet(
         hit = _take_result(str(fname), model, now)           # computed in an earlier row's launch (the rows announced ahead ride along, below)
         if hit is not None:
             return {**kw, "beta_hat": hit[0], "l1": hit[1]}
-        # rows announced ahead whose files are already decoded join this row's launch (up to _MICRO_BATCH images), and ONE further launch of
-        # such rows is queued behind it before this call blocks on its own result: the reference's loop is one image per forward and one
+        # rows announced ahead whose files are already decoded join this row's launch (up to _MICRO_BATCH images), and up to two further launches of
+        # such rows are queued behind it before this call blocks on its own result: the reference's loop is one image per forward and one
         # blocking read-back per image (evaluate.py:48); rows, order and numbers stay those of that loop -- an image's statistics do not depend
         # on what else is in its batch -- but the GPU sees launches it can fill and works on the next one while Python hands out this one's rows
         h = _inflight_of(str(fname), model, now)
@@ -158,10 +158,11 @@ def predict_unet(
             if planes is not None:
                 h = _submit_rows([(str(fname), planes, now)] + _take_ready_ahead(_MICRO_BATCH - 1), model)
         if h is not None:
-            if len(_AHEAD["inflight"]) < 2 and _ready_ahead() >= max(1, _MICRO_BATCH // 2):      # (a launch of one or two rows costs the host what a full one does)
+            while len(_AHEAD["inflight"]) < _QUEUE_DEPTH and _ready_ahead() >= max(1, _MICRO_BATCH // 2):      # (a launch of one or two rows costs the host what a full one does)
                 more = _take_ready_ahead(_MICRO_BATCH)
-                if more:
-                    _submit_rows(more, model)
+                if not more:
+                    break
+                _submit_rows(more, model)
             while True:                                      # collect in submission order up to this row's launch; the other rows' results wait for their calls
                 g = _AHEAD["inflight"].pop(0)
                 if g["model"] != id(model):                  # queued for another model (a caller alternating models outside a fabrika pass): not ours
@@ -193,11 +194,12 @@ def predict_unet(
 
 
 # ---- files ahead for the per-image API: while predict_unet works on row i (upload, forward, two scalars back: ~0.6 ms), helper threads decode
-# the files of rows i + 1 .. i + 32 into the pinned ring -- one decode (~1.5 ms) is longer than everything else of a row (reference: serial,
+# the files of rows i + 1 .. i + 48 into the pinned ring -- one decode (~1.5 ms) is longer than everything else of a row (reference: serial,
 # evaluate.py:142-149) -- and the rows already decoded when row i is asked for ride along in ITS launch (micro-batch), their results kept for
 # their own calls: the per-image loop's GPU work becomes a few batch-8..16 forwards instead of one batch-1 forward and one blocking read-back per image
 _MICRO_BATCH = max(1, int(__import__("os").environ.get("WSU_PER_IMAGE_BATCH", "16")))     # at most this many images in one per-image-API launch: the row asked for + decoded rows ahead
-_AHEAD_DEPTH = 2 * _MICRO_BATCH                              # rows announced ahead (fabrika's python iterator, fn.lookahead_depth): the rows of the NEXT launch
+_QUEUE_DEPTH = 3                                             # launches in flight: the one a call waits for + two behind it (the GPU works while Python hands out rows)
+_AHEAD_DEPTH = _QUEUE_DEPTH * _MICRO_BATCH                   # rows announced ahead (fabrika's python iterator, fn.lookahead_depth): the rows of the NEXT launches
                                                              # are announced while the rows of this one return from the cache, and decode during this launch
 _AHEAD = {"pool": None, "pending": {}, "results": {}, "inflight": []}
 
@@ -228,7 +230,8 @@ def _ring_valid(res):
 def _lookahead(fname) -> None:
     if _AHEAD["pool"] is None:
         from concurrent.futures import ThreadPoolExecutor
-        _AHEAD["pool"] = ThreadPoolExecutor(max_workers=_AHEAD_DEPTH)
+        from ._io import usable_cores
+        _AHEAD["pool"] = ThreadPoolExecutor(max_workers=max(4, min(_AHEAD_DEPTH, usable_cores())))
     pend = _AHEAD["pending"]
     while len(pend) > _AHEAD_DEPTH:                          # rows that were announced and never asked for
         pend.pop(next(iter(pend)))[0].cancel()
@@ -414,7 +417,7 @@ def predict_u8_one_readback(x_u8: torch.Tensor, model: torch.nn.Module):
 
 _PINNED = {}
 _NBUF = 6                                                    # pinned buffers per chunk shape (decode of chunk k + 1 beside upload of chunk k ...)
-_NBUF1 = 2 * _AHEAD_DEPTH                                    # ... and per single-image shape: more than the rows decoded ahead + the rows of the launch in flight
+_NBUF1 = _AHEAD_DEPTH + 2 * _MICRO_BATCH                     # ... and per single-image shape: more than the rows decoded ahead + the rows being uploaded
 _PINNED_LOCK = __import__("threading").Lock()
 
 
@@ -526,7 +529,7 @@ def load_planes_u8(fnames, imread: typing.Callable = imread4_u8) -> typing.Optio
                                 "uploaded": [None] * nbuf}
             slot = _PINNED[key]
             i = slot["next"]                                 # a ring: chunk k+1 is decoded while chunk k is uploaded and chunk k-1 may still wait
-            slot["next"] = (i + 1) % len(slot["bufs"])       # in the stream (submit / collect pipelining); the per-image API decodes 32 rows ahead
+            slot["next"] = (i + 1) % len(slot["bufs"])       # in the stream (submit / collect pipelining); the per-image API decodes 48 rows ahead
             slot["count"] = slot.get("count", 0) + 1
             slot["bufs"][i]._wsu_issue = slot["count"]       # which hand-out of this buffer the caller holds (_decode_ahead / _ring_valid)
             slot["bufs"][i]._wsu_ring = (slot, i)            # where mark_uploaded records the upload's event
