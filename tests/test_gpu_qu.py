@@ -176,7 +176,7 @@ def test_whole_net_fused_decoder_entries_against_the_two_kernel_path_and_the_ora
     assert float((y_f - y_t).abs().max()) < 6e-4
 
 
-@pytest.mark.parametrize("n,h,w", [(1, 1024, 1024), (2, 384, 640)])
+@pytest.mark.parametrize("n,h,w", [(1, 1024, 1024), (2, 384, 640), (1, 2048, 1536)])
 def test_default_mode_at_the_pair_training_resolution_and_non_square(n, h, w):
     """BASELINE.json configs[4] runs 1024x1024 images: the default inference path (fused first layer, fused decoder entries: many tiles per
     workgroup, the ring wrapping across hundreds of tiles) against the fp32 CPU oracle at that size, and at a non-square size."""
